@@ -1,0 +1,174 @@
+/*
+ * t2v_hip.h — C-ABI of libt2v_hip.so: the MI355X (gfx950) kernels under the
+ * t2v-turbo denoise hot path (VideoCrafter2 3D-UNet forward + KL-VAE decoder).
+ *
+ * The reference (Ji4chenLi/t2v-turbo) is 100 % Python and has no FFI layer; what
+ * this library replaces is the set of ATen/cuDNN/cuBLAS/xformers calls its hot
+ * path issues.  Each entry point cites the reference call site(s) it stands in
+ * for (paths relative to the reference root).
+ *
+ * Conventions
+ *  - plain C: raw device pointers, ints, a stream handle; no torch types.
+ *  - activations are bf16, token-major ("NHWC"): row m = ((b*F + f)*H + y)*W + x,
+ *    C contiguous channels per row (row stride `ld*` in elements).
+ *  - the caller owns every buffer (inputs, outputs, workspaces); the library
+ *    allocates nothing per call, never synchronises and launches only on the
+ *    stream it is given (hipStream_t passed as void*; NULL = default stream).
+ *  - every function returns 0 on success, a negative T2V_E* code on a bad
+ *    argument / unsupported shape, and never throws across the boundary.
+ */
+#ifndef T2V_HIP_H
+#define T2V_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define T2V_OK 0
+#define T2V_EINVAL (-1)   /* bad argument */
+#define T2V_ESHAPE (-2)   /* shape/alignment not supported by the kernel */
+#define T2V_EHIP (-3)     /* HIP runtime error at launch */
+
+/* element types of boundary tensors */
+#define T2V_F32 0
+#define T2V_BF16 1
+#define T2V_F16 2
+
+/* library version / build info; also forces lazy per-device state (16-byte zero page
+ * used for conv zero padding) to exist before a stream capture starts. */
+int t2v_version(void);
+int t2v_init(void);
+const char* t2v_last_error(void);
+
+/* ---------------------------------------------------------------- GEMM / implicit-GEMM conv
+ * out[M,N] = epilogue( alpha * gather(A)[M,K] * W[N,K]^T )
+ *
+ * Replaces: nn.Linear (lvdm/modules/attention.py:71-76,348,370,433,468,519,537-538;
+ * openaimodel3d.py:403-430,172-178), nn.Conv2d 3x3 / 3x3-s2 / 1x1
+ * (openaimodel3d.py:155-159,179-184,63-72,98-100,192-193,669; ae_modules.py:149-175,550-552),
+ * nn.Conv3d (3,1,1) (openaimodel3d.py:274-296), nn.Conv1d k=1 (attention.py:425-431),
+ * F.interpolate(nearest x2)+conv (openaimodel3d.py:104-111; ae_modules.py:118-121),
+ * torch.cat skip concat feeding a conv (openaimodel3d.py:733), and the bmm pairs of the
+ * VAE AttnBlock (ae_modules.py:59-69).
+ */
+#define T2V_GEMM_LINEAR 0      /* K = Cin; A row m is source row m                          */
+#define T2V_GEMM_CONV3X3 1     /* 3x3, stride 1, pad 1; K = 9*Cin, tap-major (ky,kx) then c */
+#define T2V_GEMM_CONV3X3_S2 2  /* 3x3, stride 2, pad 1                                      */
+#define T2V_GEMM_CONV3X3_UP2 3 /* 3x3 s1 p1 over the nearest-x2 upsampled input (never materialised) */
+#define T2V_GEMM_TCONV3 4      /* (3,1,1) temporal conv, pad (1,0,0); K = 3*Cin, tap = frame offset   */
+#define T2V_GEMM_CONV3X3_S2_PAD01 5 /* 3x3 s2, pad right/bottom only (VAE encoder Downsample, ae_modules.py:98-102) */
+
+#define T2V_ACT_NONE 0
+#define T2V_ACT_GEGLU 1 /* out[m,j] = x*gelu(gate); W rows packed in 64-row groups [32 x | 32 gate]; out has N/2 cols */
+#define T2V_ACT_SILU 2
+
+typedef struct t2v_gemm_desc {
+    /* A: bf16 activations; optional second source = virtual channel concat [a0 | a1] */
+    const void* a0;
+    const void* a1;
+    int c0, c1;     /* channels per source (c1 = 0 without a1); c0, c1 multiples of 64 */
+    int lda0, lda1; /* row strides, elements */
+    int mode;       /* T2V_GEMM_* */
+    int n_img, h_in, w_in; /* input grid for conv modes (n_img = B*F) */
+    int frames;     /* TCONV3: frames per clip */
+    int M, N;       /* output rows / cols (LINEAR: M = source rows) */
+    /* W: bf16 [N][K], row stride ldw (elements), K = taps*(c0+c1) */
+    const void* w;
+    int ldw;
+    /* batching: z in [0,batch): z0 = z / batch_inner, z1 = z % batch_inner; strides in elements */
+    int batch, batch_inner;
+    long long a_stride0, a_stride1, w_stride0, w_stride1, o_stride0, o_stride1;
+    /* epilogue */
+    float alpha;
+    const float* bias;   /* [N] fp32 or NULL */
+    const float* rowvec; /* fp32: += rowvec[(m / rowvec_div) * ld_rowvec + n], or NULL (time-embedding add) */
+    int rowvec_div, ld_rowvec;
+    const void* residual; /* bf16 [M][ldr] (batched with the o_strides), or NULL */
+    int ldr;
+    int act;     /* T2V_ACT_* */
+    void* out;   /* bf16 (or fp32 if out_f32) [M][ldo] */
+    int ldo;
+    int out_f32;
+} t2v_gemm_desc;
+
+int t2v_gemm(const t2v_gemm_desc* d, void* stream);
+/* tuning/test hook: force the workgroup tile (0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 256x64) */
+int t2v_gemm_force_config(int cfg);
+
+/* direct 3x3 s1 p1 conv for tiny Cin (the 4-channel latent): x bf16 [M][cin] (cin <= 8),
+ * w fp32 [cout][9][cin], bias fp32 [cout], out bf16 [M][cout].
+ * Replaces input_blocks.0 (openaimodel3d.py:435) and Decoder.conv_in (ae_modules.py:550-552). */
+int t2v_conv3x3_small_cin(const void* x, int n_img, int h, int w, int cin, const float* wgt,
+                          const float* bias, int cout, void* out, void* stream);
+
+/* ---------------------------------------------------------------- normalisation
+ * GroupNorm(32) in two phases over token-major data with optional virtual concat.
+ * A "unit" is the statistics extent: one frame (ResBlock / SpatialTransformer / VAE, 4-D input)
+ * or all frames of a clip (TemporalConvBlock / TemporalTransformer, 5-D input):
+ * rows_per_unit consecutive rows.  Replaces GroupNormSpecific / nn.GroupNorm (+ nn.SiLU)
+ * (lvdm/basics.py:78-89; openaimodel3d.py:155-157,179-181,275-292,666-668;
+ * attention.py:340-342,422-424; ae_modules.py:11-19).
+ * ws: fp32 workspace of t2v_gn_ws_floats(...) floats.  stats out: [n_units][groups][2] = (mean, rstd). */
+long long t2v_gn_ws_floats(int n_units, int rows_per_unit, int groups);
+int t2v_gn_stats(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units,
+                 int rows_per_unit, int groups, float eps, float* ws, float* stats, void* stream);
+int t2v_gn_apply(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units,
+                 int rows_per_unit, int groups, const float* stats, const float* gamma,
+                 const float* beta, int silu, void* out, int ldo, void* stream);
+
+/* LayerNorm over the channel dim, eps, affine; bf16 in/out (attention.py:279-281). */
+int t2v_layernorm(const void* x, int ldx, int M, int C, const float* gamma, const float* beta,
+                  float eps, void* out, int ldo, void* stream);
+
+/* row softmax in place on bf16 [rows][ld]: cols [0,n) normalised, cols [n, n_pad) set to 0
+ * (score matrix of the GEMM-formulated attention: attention.py:143, ae_modules.py:61). */
+int t2v_softmax_rows(void* s, long long rows, int n, int n_pad, int ld, void* stream);
+
+/* ---------------------------------------------------------------- attention
+ * Fused spatial attention (flash style), head dim 64: softmax(Q K^T * scale) V per (image, head).
+ * q: bf16 rows (img*seq_q + i), head h at columns [h*64, h*64+64); k likewise over seq_kv rows;
+ * vt: V transposed per image: bf16 [img_kv][heads*64][ld_vt] (keys contiguous).
+ * kv image of q image b is b / kv_div (text cross-attention shares K/V across the frames of a clip).
+ * Replaces CrossAttention.forward / efficient_forward (attention.py:102-164,166-240 = xformers
+ * memory_efficient_attention). */
+int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, const void* vt, int ld_vt,
+                     void* out, int ldo, int n_img, int seq_q, int seq_kv, int heads, int kv_div,
+                     float scale, void* stream);
+
+/* Temporal self-attention, head dim 64, sequence = frames: for every (clip b, pixel p, head h)
+ * softmax(Q K^T * scale) V over the F frames, reading rows ((b*F+f)*HW + p) directly from the
+ * token-major q/k/v (no '(b h w) t c' rearrange copies, attention.py:475-511,102-164).
+ * probs (optional, fp32 [(b*HW+p)*heads+h][F][F]) = CrossAttention.attention_probs
+ * (attention.py:124-126). */
+int t2v_attn_temporal(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                      void* out, int ldo, int n_clips, int frames, int hw, int heads, float scale,
+                      float* probs, void* stream);
+
+/* ---------------------------------------------------------------- layout / elementwise
+ * (b,c,f,h,w) tensor of dtype `dt` <-> token-major bf16/fp32 rows (openaimodel3d.py:714,739). */
+int t2v_ncfhw_to_tokens(const void* x, int dt, int b, int c, int f, int hw, void* out, int ldo,
+                        void* stream);
+int t2v_tokens_to_ncfhw(const void* tok, int tok_f32, int ld, int b, int c, int f, int hw,
+                        void* out, int dt, void* stream);
+/* sinusoidal embedding cos||sin of t (int64) -> bf16 [n][dim] (utils_diffusion.py:8-32);
+ * flip_sin_cos=1, scale: sin||cos of t*scale with the (half-1) divisor = guidance embedding
+ * (pipeline/t2v_turbo_vc2_pipeline.py:99-120) taking fp32 t. */
+int t2v_timestep_embedding(const void* t, int t_is_f32, int n, int dim, int guidance_style,
+                           void* out_bf16, void* stream);
+int t2v_silu(const void* x, void* out, long long n, void* stream); /* bf16 -> bf16 */
+int t2v_cast(const void* x, int dt_in, void* out, int dt_out, long long n, void* stream);
+/* out = ca[b]*x + cb[b]*y + cc[b]*z over (b, inner) fp32 tensors; y/z may be NULL. Host coefficient
+ * arrays of length nb (<= 64).  The scheduler / consistency-distillation elementwise family
+ * (t2v_turbo_scheduler.py:437-462,470-495; utils/common_utils.py:87-133; ode_solver/ddim_solver.py:67-97). */
+int t2v_lincomb3(const float* x, const float* y, const float* z, const float* ca, const float* cb,
+                 const float* cc, int nb, long long inner, float* out, void* stream);
+/* fused LCM step: x0=(x-sb_t*eps)/sa_t; den=c_out*x0+c_skip*x; prev=sa_p*den+sb_p*noise
+ * (t2v_turbo_scheduler.py:437-462). eps may be bf16 or fp32; x/noise/prev/den fp32. */
+int t2v_lcm_step(const float* x, const void* eps, int eps_dt, const float* noise, float sa_t,
+                 float sb_t, float c_skip, float c_out, float sa_p, float sb_p, long long n,
+                 float* prev, float* denoised, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* T2V_HIP_H */

@@ -1,0 +1,289 @@
+// Attention kernels for gfx950, head dim 64.
+//
+// attn_spatial_kernel: flash-style fused softmax(QK^T)V for the spatial self-attention and the
+//   77-token text cross-attention.  4 waves x 32 queries per workgroup, K / V^T tiles of 64 keys
+//   staged through LDS (register prefetch of tile t+1 under the MFMAs of tile t), scores computed
+//   *transposed* (S^T = K Q^T, v_mfma_f32_32x32x16_bf16) so that a lane owns one query column:
+//   the online-softmax max/sum are lane-local plus one 32-lane exchange, and the probabilities are
+//   already in B-operand position for O^T += V^T P^T — the MFMA contraction index is simply
+//   enumerated in the order the score registers come out, and V^T is read from LDS in that order,
+//   so P never goes through LDS or cross-lane shuffles.
+// attn_temporal_kernel: the sequence is the F (=16) frames of one pixel; one wave per
+//   (clip, pixel, head), rows fetched with the frame stride straight from the token-major
+//   buffers (no rearrange copies); tiny FLOPs, bandwidth bound.
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 64;          // keys per tile
+constexpr int K_TILE_BYTES = KT * 128;
+constexpr int VT_STRIDE = 136;  // bytes per V^T row (64 keys * 2 B + 8 B pad: conflict-free ds_read_b64)
+constexpr int VT_TILE_BYTES = 64 * VT_STRIDE;
+constexpr int AT_STAGE = K_TILE_BYTES + VT_TILE_BYTES;
+
+__global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restrict__ q, int ldq,
+                                                           const bf16_t* __restrict__ k, int ldk,
+                                                           const bf16_t* __restrict__ vt, int ld_vt,
+                                                           bf16_t* __restrict__ out, int ldo, int seq_q, int seq_kv,
+                                                           int heads, int kv_div, float scale) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * AT_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int head = blockIdx.y, img = blockIdx.z, img_kv = img / kv_div;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int qi = q0 + l31;
+    const bool q_ok = qi < seq_q;
+
+    // Q fragments (B operand: column = query, k = d)
+    bf16x8_t qf[4];
+    {
+        const bf16_t* qp = q + ((long long)img * seq_q + (q_ok ? qi : 0)) * ldq + head * 64 + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            uint4 u = q_ok ? *(const uint4*)(qp + kk * 16) : make_uint4(0, 0, 0, 0);
+            qf[kk] = *(bf16x8_t*)&u;
+        }
+    }
+    const bf16_t* kbase = k + (long long)img_kv * seq_kv * ldk + head * 64;
+    const bf16_t* vbase = vt + ((long long)img_kv * heads + head) * 64 * ld_vt;
+    const int ntile = (seq_kv + KT - 1) / KT;
+
+    // cooperative tile staging: 512 16-byte chunks per operand, 2 per thread
+    uint4 kreg[2], vreg[2];
+    auto load_tile = [&](int t) {
+        const int key0 = t * KT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int id = tid + j * 256, row = id >> 3, c = id & 7;
+            const int key = key0 + row;
+            kreg[j] = key < seq_kv ? *(const uint4*)(kbase + (long long)key * ldk + c * 8) : make_uint4(0, 0, 0, 0);
+            // V^T rows are d, columns keys; the buffer is padded to a multiple of 64 keys
+            uint4 v = *(const uint4*)(vbase + (long long)row * ld_vt + key0 + c * 8);
+            if (key0 + c * 8 + 8 > seq_kv) {  // zero the keys past the end (their P is 0, but 0*garbage must stay 0)
+                bf16_t* e = (bf16_t*)&v;
+#pragma unroll
+                for (int x = 0; x < 8; ++x)
+                    if (key0 + c * 8 + x >= seq_kv) e[x] = 0;
+            }
+            vreg[j] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* sk = smem + buf * AT_STAGE;
+        char* sv = sk + K_TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int id = tid + j * 256, row = id >> 3, c = id & 7;
+            *(uint4*)(sk + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kreg[j];
+            uint2* d = (uint2*)(sv + row * VT_STRIDE + c * 16);
+            d[0] = make_uint2(vreg[j].x, vreg[j].y);
+            d[1] = make_uint2(vreg[j].z, vreg[j].w);
+        }
+    };
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const int swz = (lane >> 1) & 7;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntile) load_tile(t + 1);
+        const char* sk = smem + buf * AT_STAGE;
+        const char* sv = sk + K_TILE_BYTES;
+        // ---- S^T = K Q^T ------------------------------------------------------------------------
+        f32x16_t s[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[h2][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8_t kf = *(const bf16x8_t*)(sk + (h2 * 32 + l31) * 128 + (((kk * 2 + hi) ^ swz) << 4));
+                s[h2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[h2], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (this lane: one query, 32 of the 64 keys; partner lane^32 the rest) ---
+        const int key_base = t * KT + 4 * hi;
+        const bool tail = (t + 1) * KT > seq_kv;
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[h2][r] * scale;
+                if (tail && key_base + h2 * 32 + (r & 3) + 8 * (r >> 2) >= seq_kv) v = -INFINITY;
+                s[h2][r] = v;
+                mloc = fmaxf(mloc, v);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float lsum = 0.f;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __expf(s[h2][r] - m_new);
+                s[h2][r] = p;
+                lsum += p;
+            }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        // ---- O^T += V^T P^T ------------------------------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int h2 = ks >> 1, st = ks & 1;
+            uint4 pu;
+            pu.x = pack2bf(s[h2][st * 8 + 0], s[h2][st * 8 + 1]);
+            pu.y = pack2bf(s[h2][st * 8 + 2], s[h2][st * 8 + 3]);
+            pu.z = pack2bf(s[h2][st * 8 + 4], s[h2][st * 8 + 5]);
+            pu.w = pack2bf(s[h2][st * 8 + 6], s[h2][st * 8 + 7]);
+            const bf16x8_t pb = *(bf16x8_t*)&pu;
+            const int kofs = (h2 * 32 + st * 16 + 4 * hi) * 2;  // byte offset of this lane's first key
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const char* vp = sv + (db * 32 + l31) * VT_STRIDE + kofs;
+                const uint2 v0 = *(const uint2*)vp;         // keys base+0..3
+                const uint2 v1 = *(const uint2*)(vp + 16);  // keys base+8..11
+                uint4 vu = make_uint4(v0.x, v0.y, v1.x, v1.y);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&vu, pb, o[db], 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntile) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (q_ok) {
+        bf16_t* op = out + ((long long)img * seq_q + qi) * ldo + head * 64 + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 w;
+                w.x = pack2bf(o[db][g * 4 + 0] * inv, o[db][g * 4 + 1] * inv);
+                w.y = pack2bf(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv);
+                *(uint2*)(op + db * 32 + g * 8) = w;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int FMAX>
+__global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __restrict__ q, int ldq,
+                                                            const bf16_t* __restrict__ k, int ldk,
+                                                            const bf16_t* __restrict__ v, int ldv,
+                                                            bf16_t* __restrict__ out, int ldo, long long n_items, int F,
+                                                            int HW, int heads, float scale, float* __restrict__ probs) {
+    const int lane = threadIdx.x & 63;
+    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const int head = (int)(item % heads);
+    const long long bp = item / heads;
+    const int p = (int)(bp % HW);
+    const long long b = bp / HW;
+    const long long row0 = b * F * HW + p;  // row of frame f = row0 + f*HW
+    const int dq = lane & 3, col = head * 64 + dq * 16;
+    for (int qb = 0; qb * 16 < F; ++qb) {
+        const int i = qb * 16 + (lane >> 2);
+        const bool ok = i < F;
+        float qv[16];
+        {
+            const bf16_t* qp = q + (row0 + (long long)(ok ? i : 0) * HW) * ldq + col;
+            unpack8(*(const uint4*)qp, qv);
+            unpack8(*(const uint4*)(qp + 8), qv + 8);
+        }
+        float s[FMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < FMAX; ++j) {
+            s[j] = -INFINITY;
+            if (j < F) {
+                const bf16_t* kp = k + (row0 + (long long)j * HW) * ldk + col;
+                float kv[16];
+                unpack8(*(const uint4*)kp, kv);
+                unpack8(*(const uint4*)(kp + 8), kv + 8);
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) d += qv[e] * kv[e];
+                d += __shfl_xor(d, 1, 64);
+                d += __shfl_xor(d, 2, 64);
+                s[j] = d * scale;
+                mx = fmaxf(mx, s[j]);
+            }
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < FMAX; ++j) {
+            s[j] = (j < F) ? __expf(s[j] - mx) : 0.f;
+            sum += s[j];
+        }
+        const float inv = 1.f / sum;
+        float o[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < FMAX; ++j) {
+            if (j < F) {
+                const float pj = s[j] * inv;
+                if (probs && dq == 0 && ok) probs[(item * F + i) * F + j] = pj;
+                const bf16_t* vp = v + (row0 + (long long)j * HW) * ldv + col;
+                float vv[16];
+                unpack8(*(const uint4*)vp, vv);
+                unpack8(*(const uint4*)(vp + 8), vv + 8);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[e] += pj * vv[e];
+            }
+        }
+        if (ok) {
+            bf16_t* op = out + (row0 + (long long)i * HW) * ldo + col;
+            *(uint4*)op = pack8(o);
+            *(uint4*)(op + 8) = pack8(o + 8);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, const void* vt, int ld_vt, void* out,
+                                int ldo, int n_img, int seq_q, int seq_kv, int heads, int kv_div, float scale,
+                                void* stream) {
+    T2V_REQUIRE(q && k && vt && out, T2V_EINVAL, "t2v_attn_spatial: null pointer");
+    T2V_REQUIRE(n_img > 0 && seq_q > 0 && seq_kv > 0 && heads > 0 && kv_div > 0, T2V_EINVAL, "t2v_attn_spatial: bad size");
+    T2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ld_vt % 8 == 0 && ldo % 4 == 0, T2V_ESHAPE, "t2v_attn_spatial: strides");
+    T2V_REQUIRE(ld_vt >= ((seq_kv + 63) / 64) * 64, T2V_ESHAPE, "t2v_attn_spatial: V^T rows must be padded to 64 keys");
+    T2V_REQUIRE(heads <= 65535 && n_img <= 65535, T2V_ESHAPE, "t2v_attn_spatial: grid");
+    dim3 grid((seq_q + 127) / 128, heads, n_img);
+    hipLaunchKernelGGL(attn_spatial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
+                       (const bf16_t*)k, ldk, (const bf16_t*)vt, ld_vt, (bf16_t*)out, ldo, seq_q, seq_kv, heads, kv_div, scale);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+
+extern "C" int t2v_attn_temporal(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out,
+                                 int ldo, int n_clips, int frames, int hw, int heads, float scale, float* probs,
+                                 void* stream) {
+    T2V_REQUIRE(q && k && v && out, T2V_EINVAL, "t2v_attn_temporal: null pointer");
+    T2V_REQUIRE(n_clips > 0 && frames > 0 && hw > 0 && heads > 0, T2V_EINVAL, "t2v_attn_temporal: bad size");
+    T2V_REQUIRE(frames <= 64, T2V_ESHAPE, "t2v_attn_temporal: more than 64 frames not supported");
+    T2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, T2V_ESHAPE, "t2v_attn_temporal: strides");
+    const long long n_items = (long long)n_clips * hw * heads;
+    const unsigned blocks = (unsigned)((n_items + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_T(FM)                                                                                                   \
+    hipLaunchKernelGGL(attn_temporal_kernel<FM>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)q, ldq, (const bf16_t*)k, \
+                       ldk, (const bf16_t*)v, ldv, (bf16_t*)out, ldo, n_items, frames, hw, heads, scale, probs)
+    if (frames <= 16) LAUNCH_T(16);
+    else if (frames <= 32) LAUNCH_T(32);
+    else LAUNCH_T(64);
+#undef LAUNCH_T
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}

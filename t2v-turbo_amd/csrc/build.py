@@ -1,0 +1,57 @@
+"""Build libt2v_hip.so (gfx950) in-tree with hipcc.  No CMake, no JIT cache: the .so lands next
+to the package so it travels with the repo snapshot to the GPU box."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+ROOT = os.path.dirname(PKG)
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+LIB = os.path.join(PKG, "libt2v_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
+         "-I", os.path.join(ROOT, "include"), "-I", HERE]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"),
+                                                        os.path.join(ROOT, "include", "t2v_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(HERE, s.replace(".hip", ".o"))
+        objs.append(o)
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(HERE, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,69 @@
+// Internal helpers shared by the gfx950 kernels of libt2v_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "t2v_hip.h"
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16_t;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4_t;
+
+#define T2V_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even fp32 -> bf16 (matches torch's .to(bfloat16)); NaN kept quiet
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+    v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, as torch.nn.functional.gelu default
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// host side
+void t2v_set_error(const char* msg);
+const void* t2v_zero_page();  // >= 256 B of device zeros (lazily allocated per process)
+#define T2V_CHECK_LAUNCH()                                              \
+    do {                                                                \
+        hipError_t e__ = hipGetLastError();                             \
+        if (e__ != hipSuccess) {                                        \
+            t2v_set_error(hipGetErrorString(e__));                      \
+            return T2V_EHIP;                                            \
+        }                                                               \
+    } while (0)
+#define T2V_REQUIRE(cond, code, msg)        \
+    do {                                    \
+        if (!(cond)) {                      \
+            t2v_set_error(msg);             \
+            return code;                    \
+        }                                   \
+    } while (0)

@@ -1,0 +1,238 @@
+// Layout conversion, embeddings, small direct conv and the scheduler / consistency-distillation
+// elementwise family for gfx950.  All bandwidth/latency bound; vectorised where the layout allows.
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float load_as_f32(const void* p, int dt, long long i) {
+    if (dt == T2V_F32) return ((const float*)p)[i];
+    if (dt == T2V_BF16) return bf2f(((const bf16_t*)p)[i]);
+    return (float)(((const _Float16*)p)[i]);
+}
+__device__ __forceinline__ void store_from_f32(void* p, int dt, long long i, float v) {
+    if (dt == T2V_F32) ((float*)p)[i] = v;
+    else if (dt == T2V_BF16) ((bf16_t*)p)[i] = f2bf(v);
+    else ((_Float16*)p)[i] = (_Float16)v;
+}
+
+// (b,c,f,hw) -> rows ((b*f + fi)*hw + p), c columns.  One thread per (row): reads c strided
+// planes (each coalesced across threads), writes c contiguous values.
+__global__ void ncfhw_to_tokens_kernel(const void* x, int dt, int B, int C, int F, int HW, bf16_t* out, int ldo) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long M = (long long)B * F * HW;
+    if (m >= M) return;
+    const int p = (int)(m % HW);
+    const long long bf = m / HW;
+    const int f = (int)(bf % F);
+    const long long b = bf / F;
+    for (int c = 0; c < C; ++c)
+        out[m * ldo + c] = f2bf(load_as_f32(x, dt, ((b * C + c) * F + f) * HW + p));
+}
+__global__ void tokens_to_ncfhw_kernel(const void* tok, int tok_f32, int ld, int B, int C, int F, int HW, void* out, int dt) {
+    const long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long M = (long long)B * F * HW;
+    if (m >= M) return;
+    const int p = (int)(m % HW);
+    const long long bf = m / HW;
+    const int f = (int)(bf % F);
+    const long long b = bf / F;
+    for (int c = 0; c < C; ++c) {
+        const float v = tok_f32 ? ((const float*)tok)[m * ld + c] : bf2f(((const bf16_t*)tok)[m * ld + c]);
+        store_from_f32(out, dt, ((b * C + c) * F + f) * HW + p, v);
+    }
+}
+
+__global__ void timestep_embedding_kernel(const void* t, int t_is_f32, int n, int dim, int guidance_style, bf16_t* out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (idx >= n * half) return;
+    const int row = idx / half, i = idx % half;
+    float tv = t_is_f32 ? ((const float*)t)[row] : (float)((const long long*)t)[row];
+    float c, s;
+    if (guidance_style) {  // sin||cos of (w*1000) * exp(-i*ln(1e4)/(half-1))
+        const float freq = expf((float)i * -(logf(10000.0f) / (float)(half - 1)));
+        const float a = tv * 1000.0f * freq;
+        sincosf(a, &s, &c);
+        out[row * dim + i] = f2bf(s);
+        out[row * dim + half + i] = f2bf(c);
+    } else {  // cos||sin of t * exp(-ln(1e4) * i / half)
+        const float freq = expf(-logf(10000.0f) * (float)i / (float)half);
+        const float a = tv * freq;
+        sincosf(a, &s, &c);
+        out[row * dim + i] = f2bf(c);
+        out[row * dim + half + i] = f2bf(s);
+    }
+    if ((dim & 1) && i == 0) out[row * dim + dim - 1] = 0;
+}
+
+__global__ void silu_kernel(const bf16_t* x, bf16_t* out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = f2bf(silu_f(bf2f(x[i])));
+}
+__global__ void cast_kernel(const void* x, int dt_in, void* out, int dt_out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) store_from_f32(out, dt_out, i, load_as_f32(x, dt_in, i));
+}
+
+struct Coef3 { float a[64], b[64], c[64]; };
+__global__ void lincomb3_kernel(const float* x, const float* y, const float* z, Coef3 k, long long inner, long long total, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int b = (int)(i / inner);
+    float v = k.a[b] * x[i];
+    if (y) v += k.b[b] * y[i];
+    if (z) v += k.c[b] * z[i];
+    out[i] = v;
+}
+__global__ void lcm_step_kernel(const float* x, const void* eps, int eps_dt, const float* noise, float sa_t, float sb_t,
+                                float c_skip, float c_out, float sa_p, float sb_p, long long n, float* prev, float* den) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float xv = x[i];
+    const float e = load_as_f32(eps, eps_dt, i);
+    const float x0 = (xv - sb_t * e) / sa_t;
+    const float dn = c_out * x0 + c_skip * xv;
+    den[i] = dn;
+    prev[i] = noise ? sa_p * dn + sb_p * noise[i] : dn;
+}
+
+// direct 3x3 s1 p1 conv for cin <= 8: thread = (token, 8 output channels); weights fp32 in LDS
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_small_kernel(const bf16_t* x, int n_img, int H, int W, const float* wgt,
+                                                         const float* bias, int cout, bf16_t* out) {
+    extern __shared__ float sw[];  // [cout][9*CIN]
+    for (int i = threadIdx.x; i < cout * 9 * CIN; i += 256) sw[i] = wgt[i];
+    __syncthreads();
+    const int nch = cout / 8;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long M = (long long)n_img * H * W;
+    const long long m = e / nch;
+    if (m >= M) return;
+    const int oc0 = (int)(e % nch) * 8;
+    const int px = (int)(m % W), py = (int)((m / W) % H);
+    const long long nbase = (m / ((long long)W * H)) * H * W;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) acc[o] = bias ? bias[oc0 + o] : 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = py + ky - 1, ix = px + kx - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const bf16_t* xp = x + (nbase + (long long)iy * W + ix) * CIN;
+            float xv[CIN];
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) xv[c] = bf2f(xp[c]);
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                const float* wp = sw + (oc0 + o) * 9 * CIN + (ky * 3 + kx) * CIN;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) acc[o] += xv[c] * wp[c];
+            }
+        }
+    *(uint4*)(out + m * cout + oc0) = pack8(acc);
+}
+
+inline unsigned nblk(long long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+}  // namespace
+
+extern "C" int t2v_ncfhw_to_tokens(const void* x, int dt, int b, int c, int f, int hw, void* out, int ldo, void* stream) {
+    T2V_REQUIRE(x && out && b > 0 && c > 0 && f > 0 && hw > 0 && ldo >= c && dt >= 0 && dt <= 2, T2V_EINVAL, "t2v_ncfhw_to_tokens");
+    hipLaunchKernelGGL(ncfhw_to_tokens_kernel, dim3(nblk((long long)b * f * hw)), dim3(256), 0, (hipStream_t)stream, x, dt, b,
+                       c, f, hw, (bf16_t*)out, ldo);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+extern "C" int t2v_tokens_to_ncfhw(const void* tok, int tok_f32, int ld, int b, int c, int f, int hw, void* out, int dt,
+                                   void* stream) {
+    T2V_REQUIRE(tok && out && b > 0 && c > 0 && f > 0 && hw > 0 && ld >= c && dt >= 0 && dt <= 2, T2V_EINVAL, "t2v_tokens_to_ncfhw");
+    hipLaunchKernelGGL(tokens_to_ncfhw_kernel, dim3(nblk((long long)b * f * hw)), dim3(256), 0, (hipStream_t)stream, tok,
+                       tok_f32, ld, b, c, f, hw, out, dt);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+extern "C" int t2v_timestep_embedding(const void* t, int t_is_f32, int n, int dim, int guidance_style, void* out, void* stream) {
+    T2V_REQUIRE(t && out && n > 0 && dim >= 4, T2V_EINVAL, "t2v_timestep_embedding");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(nblk((long long)n * (dim / 2))), dim3(256), 0, (hipStream_t)stream, t,
+                       t_is_f32, n, dim, guidance_style, (bf16_t*)out);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+extern "C" int t2v_silu(const void* x, void* out, long long n, void* stream) {
+    T2V_REQUIRE(x && out && n > 0, T2V_EINVAL, "t2v_silu");
+    hipLaunchKernelGGL(silu_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out, n);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+extern "C" int t2v_cast(const void* x, int dt_in, void* out, int dt_out, long long n, void* stream) {
+    T2V_REQUIRE(x && out && n > 0 && dt_in >= 0 && dt_in <= 2 && dt_out >= 0 && dt_out <= 2, T2V_EINVAL, "t2v_cast");
+    hipLaunchKernelGGL(cast_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, x, dt_in, out, dt_out, n);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+extern "C" int t2v_lincomb3(const float* x, const float* y, const float* z, const float* ca, const float* cb,
+                            const float* cc, int nb, long long inner, float* out, void* stream) {
+    T2V_REQUIRE(x && out && ca && nb > 0 && nb <= 64 && inner > 0, T2V_EINVAL, "t2v_lincomb3");
+    T2V_REQUIRE((!y || cb) && (!z || cc), T2V_EINVAL, "t2v_lincomb3: missing coefficients");
+    Coef3 k;
+    for (int i = 0; i < nb; ++i) { k.a[i] = ca[i]; k.b[i] = cb ? cb[i] : 0.f; k.c[i] = cc ? cc[i] : 0.f; }
+    hipLaunchKernelGGL(lincomb3_kernel, dim3(nblk(inner * nb)), dim3(256), 0, (hipStream_t)stream, x, y, z, k, inner,
+                       inner * nb, out);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+extern "C" int t2v_lcm_step(const float* x, const void* eps, int eps_dt, const float* noise, float sa_t, float sb_t,
+                            float c_skip, float c_out, float sa_p, float sb_p, long long n, float* prev, float* denoised,
+                            void* stream) {
+    T2V_REQUIRE(x && eps && prev && denoised && n > 0 && sa_t != 0.f, T2V_EINVAL, "t2v_lcm_step");
+    hipLaunchKernelGGL(lcm_step_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, x, eps, eps_dt, noise, sa_t, sb_t,
+                       c_skip, c_out, sa_p, sb_p, n, prev, denoised);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+extern "C" int t2v_conv3x3_small_cin(const void* x, int n_img, int h, int w, int cin, const float* wgt, const float* bias,
+                                     int cout, void* out, void* stream) {
+    T2V_REQUIRE(x && wgt && out && n_img > 0 && h > 0 && w > 0, T2V_EINVAL, "t2v_conv3x3_small_cin");
+    T2V_REQUIRE((cin == 4 || cin == 8) && cout % 8 == 0 && cout * 9 * cin * 4 <= 150 * 1024, T2V_ESHAPE,
+                "t2v_conv3x3_small_cin: cin must be 4 or 8, cout a multiple of 8");
+    const long long work = (long long)n_img * h * w * (cout / 8);
+    const int smem = cout * 9 * cin * 4;
+    hipStream_t s = (hipStream_t)stream;
+    if (cin == 4) {
+        static bool set4 = false;
+        if (!set4) { hipFuncSetAttribute((const void*)conv_small_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set4 = true; }
+        hipLaunchKernelGGL(conv_small_kernel<4>, dim3(nblk(work)), dim3(256), smem, s, (const bf16_t*)x, n_img, h, w, wgt, bias, cout, (bf16_t*)out);
+    } else {
+        static bool set8 = false;
+        if (!set8) { hipFuncSetAttribute((const void*)conv_small_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set8 = true; }
+        hipLaunchKernelGGL(conv_small_kernel<8>, dim3(nblk(work)), dim3(256), smem, s, (const bf16_t*)x, n_img, h, w, wgt, bias, cout, (bf16_t*)out);
+    }
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+
+// ---- library state ---------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+void t2v_set_error(const char* msg) {
+    size_t i = 0;
+    for (; msg && msg[i] && i + 1 < sizeof(g_err); ++i) g_err[i] = msg[i];
+    g_err[i] = 0;
+}
+static void* g_zero[64] = {nullptr};
+const void* t2v_zero_page() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!g_zero[dev]) {
+        void* p = nullptr;
+        if (hipMalloc(&p, 4096) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, 4096) != hipSuccess) return nullptr;
+        g_zero[dev] = p;
+    }
+    return g_zero[dev];
+}
+extern "C" const char* t2v_last_error(void) { return g_err; }
+extern "C" int t2v_version(void) { return 100; }
+extern "C" int t2v_init(void) { return t2v_zero_page() ? T2V_OK : T2V_EHIP; }

@@ -1,0 +1,245 @@
+"""ctypes binding of libt2v_hip.so (include/t2v_hip.h) and the tensor-level HIP op backend.
+
+There is NO fallback here: if the shared library is missing or a kernel rejects a shape, the
+caller gets an exception.  torch is used only for device memory (tensors own the buffers) and for
+the current stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libt2v_hip.so")
+
+# include/t2v_hip.h constants
+F32, BF16, F16 = 0, 1, 2
+GEMM_LINEAR, GEMM_CONV3X3, GEMM_CONV3X3_S2, GEMM_CONV3X3_UP2, GEMM_TCONV3, GEMM_CONV3X3_S2_PAD01 = range(6)
+ACT_NONE, ACT_GEGLU, ACT_SILU = 0, 1, 2
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+
+class GemmDesc(C.Structure):
+    """struct t2v_gemm_desc"""
+    _fields_ = [
+        ("a0", C.c_void_p), ("a1", C.c_void_p), ("c0", C.c_int), ("c1", C.c_int),
+        ("lda0", C.c_int), ("lda1", C.c_int), ("mode", C.c_int),
+        ("n_img", C.c_int), ("h_in", C.c_int), ("w_in", C.c_int), ("frames", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("w", C.c_void_p), ("ldw", C.c_int),
+        ("batch", C.c_int), ("batch_inner", C.c_int),
+        ("a_stride0", C.c_longlong), ("a_stride1", C.c_longlong),
+        ("w_stride0", C.c_longlong), ("w_stride1", C.c_longlong),
+        ("o_stride0", C.c_longlong), ("o_stride1", C.c_longlong),
+        ("alpha", C.c_float), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
+        ("rowvec_div", C.c_int), ("ld_rowvec", C.c_int), ("residual", C.c_void_p), ("ldr", C.c_int),
+        ("act", C.c_int), ("out", C.c_void_p), ("ldo", C.c_int), ("out_f32", C.c_int),
+    ]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_SIGS = {
+    "t2v_version": (C.c_int, []),
+    "t2v_init": (C.c_int, []),
+    "t2v_last_error": (C.c_char_p, []),
+    "t2v_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "t2v_gemm_force_config": (C.c_int, [C.c_int]),
+    "t2v_conv3x3_small_cin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_void_p, C.c_void_p]),
+    "t2v_gn_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "t2v_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2v_gn_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                               C.c_void_p]),
+    "t2v_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
+                                C.c_void_p, C.c_int, C.c_void_p]),
+    "t2v_softmax_rows": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "t2v_attn_spatial": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "t2v_attn_temporal": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                    C.c_void_p]),
+    "t2v_ncfhw_to_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p]),
+    "t2v_tokens_to_ncfhw": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_int, C.c_void_p]),
+    "t2v_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "t2v_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "t2v_cast": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
+    "t2v_lincomb3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                               C.c_longlong, C.c_void_p, C.c_void_p]),
+    "t2v_lcm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                               C.c_float, C.c_float, C.c_float, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+EXPORTED = sorted(_SIGS)
+
+
+def load(path=None):
+    """dlopen the library and attach signatures.  Raises NativeError if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get("T2V_HIP_LIB", LIB_PATH)
+    if not os.path.exists(path):
+        raise NativeError(
+            f"{path} not found: build it with `python __graft_entry__.py` / "
+            f"`python t2v-turbo_amd/csrc/build.py` (hipcc, gfx950). There is no fallback path.")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise NativeError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = _lib.t2v_last_error().decode(errors="replace") if _lib is not None else ""
+        raise NativeError(f"{what} failed with code {rc}: {msg}")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _row_stride(t):
+    assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), "expected a row-major 2-D view"
+    return t.stride(0)
+
+
+class HipOps:
+    """Tensor-level view of the C-ABI.  Every method launches on torch's current stream; while
+    ``recording`` is a list, the raw (function, args) tuples are appended to it as well so that a
+    whole forward can be replayed without Python-side tensor work (and captured into a hipGraph)."""
+
+    act_dtype = torch.bfloat16
+    is_native = True
+
+    def __init__(self):
+        self.lib = load()
+        self.recording = None
+        self._keep = []  # objects that must outlive recorded calls (descs, host arrays)
+
+    # -- plumbing ------------------------------------------------------------------------------
+    @staticmethod
+    def stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def init(self):
+        _check(self.lib.t2v_init(), "t2v_init")
+
+    def _call(self, name, *args, keep=None):
+        fn = getattr(self.lib, name)
+        _check(fn(*args, self.stream()), name)
+        if self.recording is not None:
+            self.recording.append((fn, args, name))
+            if keep is not None:
+                self._keep.append(keep)
+
+    @staticmethod
+    def replay(recording, stream):
+        for fn, args, name in recording:
+            rc = fn(*args, stream)
+            if rc != 0:
+                _check(rc, name)
+
+    # -- ops ----------------------------------------------------------------------------------------
+    def gemm(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
+             rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
+             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0)):
+        d = GemmDesc()
+        d.a0, d.c0, d.lda0 = _p(a0), a0.shape[1], _row_stride(a0)
+        if a1 is not None:
+            d.a1, d.c1, d.lda1 = _p(a1), a1.shape[1], _row_stride(a1)
+        d.mode, d.n_img, d.h_in, d.w_in, d.frames = mode, n_img, h, wd, frames
+        d.M, d.N = M, N
+        d.w, d.ldw = _p(w), _row_stride(w)
+        d.batch, d.batch_inner = batch, batch_inner
+        d.a_stride0, d.a_stride1 = a_strides
+        d.w_stride0, d.w_stride1 = w_strides
+        d.o_stride0, d.o_stride1 = o_strides
+        d.alpha = alpha
+        d.bias = _p(bias)
+        if rowvec is not None:
+            d.rowvec, d.rowvec_div, d.ld_rowvec = _p(rowvec), rowvec_div, _row_stride(rowvec)
+        if residual is not None:
+            d.residual, d.ldr = _p(residual), _row_stride(residual)
+        d.act = act
+        d.out, d.ldo = _p(out), _row_stride(out)
+        d.out_f32 = 1 if out.dtype == torch.float32 else 0
+        self._call("t2v_gemm", C.byref(d), keep=d)
+
+    def conv_small(self, x, n_img, h, w, wgt, bias, out):
+        self._call("t2v_conv3x3_small_cin", _p(x), n_img, h, w, x.shape[1], _p(wgt), _p(bias), out.shape[1], _p(out))
+
+    def gn_ws_floats(self, n_units, rows_per_unit, groups=32):
+        return int(self.lib.t2v_gn_ws_floats(n_units, rows_per_unit, groups))
+
+    def gn_stats(self, x0, x1, n_units, rows_per_unit, eps, ws, stats, groups=32):
+        self._call("t2v_gn_stats", _p(x0), x0.shape[1], _row_stride(x0), _p(x1),
+                   0 if x1 is None else x1.shape[1], 0 if x1 is None else _row_stride(x1),
+                   n_units, rows_per_unit, groups, eps, _p(ws), _p(stats))
+
+    def gn_apply(self, x0, x1, n_units, rows_per_unit, stats, gamma, beta, silu, out, groups=32):
+        self._call("t2v_gn_apply", _p(x0), x0.shape[1], _row_stride(x0), _p(x1),
+                   0 if x1 is None else x1.shape[1], 0 if x1 is None else _row_stride(x1),
+                   n_units, rows_per_unit, groups, _p(stats), _p(gamma), _p(beta), int(silu), _p(out), _row_stride(out))
+
+    def layernorm(self, x, gamma, beta, eps, out):
+        self._call("t2v_layernorm", _p(x), _row_stride(x), x.shape[0], x.shape[1], _p(gamma), _p(beta), eps, _p(out),
+                   _row_stride(out))
+
+    def softmax_rows(self, s, rows, n, n_pad, ld):
+        self._call("t2v_softmax_rows", _p(s), rows, n, n_pad, ld)
+
+    def attn_spatial(self, q, k, vt, ld_vt, out, n_img, seq_q, seq_kv, heads, kv_div, scale):
+        self._call("t2v_attn_spatial", _p(q), _row_stride(q), _p(k), _row_stride(k), _p(vt), ld_vt, _p(out),
+                   _row_stride(out), n_img, seq_q, seq_kv, heads, kv_div, scale)
+
+    def attn_temporal(self, q, k, v, out, n_clips, frames, hw, heads, scale, probs=None):
+        self._call("t2v_attn_temporal", _p(q), _row_stride(q), _p(k), _row_stride(k), _p(v), _row_stride(v), _p(out),
+                   _row_stride(out), n_clips, frames, hw, heads, scale, _p(probs))
+
+    def ncfhw_to_tokens(self, x, out):
+        b, c, f, h, w = x.shape
+        assert x.is_contiguous()
+        self._call("t2v_ncfhw_to_tokens", _p(x), _DT[x.dtype], b, c, f, h * w, _p(out), _row_stride(out))
+
+    def tokens_to_ncfhw(self, tok, out):
+        b, c, f, h, w = out.shape
+        assert out.is_contiguous()
+        self._call("t2v_tokens_to_ncfhw", _p(tok), 1 if tok.dtype == torch.float32 else 0, _row_stride(tok), b, c, f,
+                   h * w, _p(out), _DT[out.dtype])
+
+    def timestep_embedding(self, t, dim, guidance_style, out):
+        assert t.dtype in (torch.int64, torch.float32) and t.is_contiguous()
+        self._call("t2v_timestep_embedding", _p(t), 1 if t.dtype == torch.float32 else 0, t.numel(), dim,
+                   int(guidance_style), _p(out))
+
+    def silu(self, x, out):
+        self._call("t2v_silu", _p(x), _p(out), x.numel())
+
+    def cast(self, x, out):
+        assert x.is_contiguous() and out.is_contiguous() and x.numel() == out.numel()
+        self._call("t2v_cast", _p(x), _DT[x.dtype], _p(out), _DT[out.dtype], x.numel())
+
+    def lincomb3(self, x, y, z, ca, cb, cc, out):
+        nb = len(ca)
+        arr = (C.c_float * nb)
+        ha, hb, hc = arr(*ca), (arr(*cb) if cb is not None else None), (arr(*cc) if cc is not None else None)
+        self._call("t2v_lincomb3", _p(x), _p(y), _p(z), C.cast(ha, C.c_void_p), C.cast(hb, C.c_void_p) if hb else None,
+                   C.cast(hc, C.c_void_p) if hc else None, nb, x.numel() // nb, _p(out), keep=(ha, hb, hc))
+
+    def lcm_step(self, x, eps, noise, sa_t, sb_t, c_skip, c_out, sa_p, sb_p, prev, denoised):
+        self._call("t2v_lcm_step", _p(x), _p(eps), _DT[eps.dtype], _p(noise), sa_t, sb_t, c_skip, c_out, sa_p, sb_p,
+                   x.numel(), _p(prev), _p(denoised))
