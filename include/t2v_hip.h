@@ -156,6 +156,8 @@ int t2v_tokens_to_ncfhw(const void* tok, int tok_f32, int ld, int b, int c, int 
 int t2v_timestep_embedding(const void* t, int t_is_f32, int n, int dim, int guidance_style,
                            void* out_bf16, void* stream);
 int t2v_silu(const void* x, void* out, long long n, void* stream); /* bf16 -> bf16 */
+/* stream-ordered memset(0) of a caller buffer (padding columns of the GEMM-formulated attention) */
+int t2v_fill_zero(void* p, long long nbytes, void* stream);
 int t2v_cast(const void* x, int dt_in, void* out, int dt_out, long long n, void* stream);
 /* out = ca[b]*x + cb[b]*y + cc[b]*z over (b, inner) fp32 tensors; y/z may be NULL. Host coefficient
  * arrays of length nb (<= 64).  The scheduler / consistency-distillation elementwise family

@@ -167,6 +167,11 @@ extern "C" int t2v_silu(const void* x, void* out, long long n, void* stream) {
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
+extern "C" int t2v_fill_zero(void* p, long long nbytes, void* stream) {
+    T2V_REQUIRE(p && nbytes > 0, T2V_EINVAL, "t2v_fill_zero");
+    if (hipMemsetAsync(p, 0, (size_t)nbytes, (hipStream_t)stream) != hipSuccess) { t2v_set_error("hipMemsetAsync failed"); return T2V_EHIP; }
+    return T2V_OK;
+}
 extern "C" int t2v_cast(const void* x, int dt_in, void* out, int dt_out, long long n, void* stream) {
     T2V_REQUIRE(x && out && n > 0 && dt_in >= 0 && dt_in <= 2 && dt_out >= 0 && dt_out <= 2, T2V_EINVAL, "t2v_cast");
     hipLaunchKernelGGL(cast_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, x, dt_in, out, dt_out, n);

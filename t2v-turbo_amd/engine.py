@@ -1,0 +1,585 @@
+"""Native execution engines for the UNet forward and the VAE decode.
+
+An engine walks the (reference-shaped) ``nn.Module`` tree once per input signature, packs the
+leaf parameters into kernel layouts and *records* the sequence of C-ABI launches with all
+buffers preallocated; later calls only refresh the small input buffers and replay the recorded
+launches (optionally as one hipGraph).  Activations stay token-major ``[(b f)(h w), C]`` bf16 from
+the first kernel to the last, so none of the reference's ``rearrange(...).contiguous()`` copies,
+``repeat_interleave`` of context/embedding, ``torch.cat`` of skip connections or materialised
+upsamples exist here.
+
+The engine is written against an *ops backend* (``native.HipOps``); tests substitute a torch
+emulation of the same interface to check the recorded dataflow on CPU.
+"""
+import collections
+import math
+import os
+
+import torch
+import torch.nn as nn
+
+from . import native as nt
+from .unet3d import (Downsample, ResBlock, SpatialTransformer, TemporalTransformer, TimestepEmbedSequential,
+                     Upsample)
+
+
+# =================================================================================== buffers
+class BufferPool:
+    """Size-bucketed device buffer reuse.  Launch order is fixed at record time, so a buffer released
+    after its last consumer was recorded can be handed to a later producer (stream order = record order)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free = collections.defaultdict(list)
+        self.live = {}
+        self.bytes = 0
+
+    def get(self, rows, cols, dtype, zero=False):
+        n = rows * cols
+        nbytes = ((n * torch.empty((), dtype=dtype).element_size() + 255) // 256) * 256
+        if self.free[nbytes]:
+            base = self.free[nbytes].pop()
+        else:
+            base = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.bytes += nbytes
+        t = base.view(dtype)[:n].view(rows, cols)
+        if zero:
+            t.zero_()
+        self.live[t.data_ptr()] = (nbytes, base)
+        return t
+
+    def put(self, *tensors):
+        for t in tensors:
+            if t is None:
+                continue
+            nbytes, base = self.live.pop(t.data_ptr())
+            self.free[nbytes].append(base)
+
+
+class Act:
+    """A token-major activation: one tensor, or two channel-concatenated parts (virtual concat)."""
+
+    def __init__(self, parts, n_img, h, w):
+        self.parts = parts if isinstance(parts, (list, tuple)) else [parts]
+        self.n_img, self.h, self.w = n_img, h, w
+
+    @property
+    def t(self):
+        assert len(self.parts) == 1
+        return self.parts[0]
+
+    @property
+    def C(self):
+        return sum(p.shape[1] for p in self.parts)
+
+    @property
+    def M(self):
+        return self.parts[0].shape[0]
+
+    @property
+    def p1(self):
+        return self.parts[1] if len(self.parts) > 1 else None
+
+
+# =================================================================================== weights
+def effective_weight_bias(mod):
+    """(weight, bias) of a Linear/Conv leaf; LoRA-injected leaves (utils/lora.py:19-230 layout:
+    .linear|.conv, .lora_down, .lora_up, .scale[, .selector]) are merged on the fly:
+    W + scale * up @ diag(sel) @ down — what ``collapse_lora`` (utils/lora.py:793-830) would bake in."""
+    base = getattr(mod, "linear", None) or getattr(mod, "conv", None)
+    if base is not None and hasattr(mod, "lora_up") and hasattr(mod, "lora_down"):
+        w = base.weight.detach().float()
+        up = mod.lora_up.weight.detach().float().flatten(1)
+        down = mod.lora_down.weight.detach().float().flatten(1)
+        sel = getattr(mod, "selector", None)
+        if isinstance(sel, (nn.Linear, nn.Conv2d, nn.Conv3d)):
+            up = up @ sel.weight.detach().float().flatten(1)
+        delta = (up @ down).reshape(w.shape)
+        return w + float(mod.scale) * delta, base.bias
+    return mod.weight.detach(), mod.bias
+
+
+def leaf_out_channels(mod):
+    return effective_weight_bias(mod)[0].shape[0]
+
+
+class Packer:
+    """Packs leaf parameters into kernel layouts; cached until any parameter changes."""
+
+    def __init__(self, wdtype, device):
+        self.wdtype, self.device = wdtype, device
+        self.cache = {}
+
+    def _memo(self, key, fn):
+        if key not in self.cache:
+            self.cache[key] = fn()
+        return self.cache[key]
+
+    def f32(self, p):
+        return None if p is None else self._memo(("f32", id(p)), lambda: p.detach().to(self.device, torch.float32).contiguous())
+
+    def bias(self, mod):
+        b = effective_weight_bias(mod)[1]
+        return None if b is None else self._memo(("bias", id(mod)), lambda: b.detach().to(self.device, torch.float32).contiguous())
+
+    def mat(self, mod):
+        """[N, K] row-major weight of a Linear / 1x1 conv / k=1 Conv1d."""
+        def make():
+            w = effective_weight_bias(mod)[0]
+            return w.reshape(w.shape[0], -1).to(self.device, self.wdtype).contiguous()
+        return self._memo(("mat", id(mod)), make)
+
+    def conv(self, mod):
+        """[N, taps*Cin], tap-major: Conv2d [N,C,3,3] -> (ky,kx,c); Conv3d [N,C,3,1,1] -> (kt,c)."""
+        def make():
+            w = effective_weight_bias(mod)[0]
+            if w.dim() == 5:
+                w = w[:, :, :, 0, 0].permute(0, 2, 1)
+            else:
+                w = w.permute(0, 2, 3, 1)
+            return w.reshape(w.shape[0], -1).to(self.device, self.wdtype).contiguous()
+        return self._memo(("conv", id(mod)), make)
+
+    def cat_mats(self, mods, tag):
+        return self._memo((tag,) + tuple(id(m) for m in mods),
+                          lambda: torch.cat([self.mat(m) for m in mods], dim=0).contiguous())
+
+    def geglu(self, proj):
+        """GEGLU projection packed in 64-row groups [32 value rows | 32 gate rows] (T2V_ACT_GEGLU)."""
+        def make():
+            w, b = effective_weight_bias(proj)
+            inner = w.shape[0] // 2
+            assert inner % 32 == 0
+            wv, wg = w[:inner].reshape(inner // 32, 32, -1), w[inner:].reshape(inner // 32, 32, -1)
+            wp = torch.cat([wv, wg], dim=1).reshape(2 * inner, -1).to(self.device, self.wdtype).contiguous()
+            bp = torch.cat([b[:inner].reshape(-1, 32), b[inner:].reshape(-1, 32)], dim=1).reshape(-1)
+            return wp, bp.detach().to(self.device, torch.float32).contiguous()
+        return self._memo(("geglu", id(proj)), make)
+
+    def small_conv(self, mod, cin_pad=None):
+        """fp32 [cout][9][cin] for the direct small-Cin conv."""
+        def make():
+            w = effective_weight_bias(mod)[0].float().permute(0, 2, 3, 1)  # N,3,3,C
+            if cin_pad and cin_pad > w.shape[-1]:
+                w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[-1]))
+            return w.reshape(w.shape[0], -1).to(self.device).contiguous()
+        return self._memo(("small", id(mod), cin_pad), make)
+
+
+def params_fingerprint(module):
+    fp = 0
+    for p in module.parameters():
+        fp = (fp * 1000003 + p._version + (p.data_ptr() & 0xFFFFFFF)) & 0xFFFFFFFFFFFF
+    return fp
+
+
+# =================================================================================== base engine
+class _Engine:
+    def __init__(self, ops):
+        self.ops = ops
+        self.adt = ops.act_dtype
+        self.plans = {}
+        self.fingerprint = None
+        self.use_graph = os.environ.get("T2V_HIP_GRAPH", "0") == "1"
+
+    # ---- helpers bound to the current recording -------------------------------------------------
+    def _begin(self, device):
+        self.device = device
+        self.pool = BufferPool(device)
+        self.pk = Packer(self.adt, device)
+        self.keep = []
+
+    def buf(self, rows, cols, dtype=None, zero=False):
+        return self.pool.get(rows, cols, dtype or self.adt, zero)
+
+    def gn(self, x, norm, units, rows_per_unit, silu, eps=None):
+        """GroupNorm(+SiLU) of an Act (possibly a virtual concat) -> new single-part tensor."""
+        ops = self.ops
+        G = norm.num_groups
+        ws = self.buf(1, max(ops.gn_ws_floats(units, rows_per_unit, G), 1), torch.float32)
+        stats = self.buf(units, G * 2, torch.float32)
+        eps = norm.eps if eps is None else eps
+        ops.gn_stats(x.parts[0], x.p1, units, rows_per_unit, eps, ws, stats, G)
+        out = self.buf(x.M, x.C)
+        ops.gn_apply(x.parts[0], x.p1, units, rows_per_unit, stats, self.pk.f32(norm.weight), self.pk.f32(norm.bias),
+                     silu, out, G)
+        self.pool.put(ws, stats)
+        return out
+
+    def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None):
+        w = self.pk.mat(mod) if w is None else w
+        bias = self.pk.bias(mod) if isinstance(bias, str) else bias
+        N = w.shape[0] if N is None else N
+        out = self.buf(a.shape[0], N // 2 if act == nt.ACT_GEGLU else N, out_dtype)
+        self.ops.gemm(a, w, out, M=a.shape[0], N=N, bias=bias, residual=residual, act=act)
+        return out
+
+    def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None):
+        """3x3 / strided / upsampled / temporal conv of an Act (virtual concat allowed)."""
+        w = self.pk.conv(mod)
+        N = w.shape[0]
+        if mode == nt.GEMM_CONV3X3_S2:
+            ho, wo = (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1
+        elif mode == nt.GEMM_CONV3X3_UP2:
+            ho, wo = 2 * x.h, 2 * x.w
+        else:
+            ho, wo = x.h, x.w
+        M = x.n_img * ho * wo
+        out = self.buf(M, N, out_dtype)
+        self.ops.gemm(x.parts[0], w, out, M=M, N=N, a1=x.p1, mode=mode, n_img=x.n_img, h=x.h, wd=x.w, frames=frames,
+                      bias=self.pk.bias(mod), rowvec=rowvec, rowvec_div=rowvec_div, residual=residual)
+        return Act(out, x.n_img, ho, wo)
+
+    # ---- plan management --------------------------------------------------------------------------------
+    def _check_weights(self, module):
+        fp = params_fingerprint(module)
+        if fp != self.fingerprint:
+            self.plans.clear()
+            self.fingerprint = fp
+
+    def _run(self, plan):
+        ops = self.ops
+        if not getattr(ops, "is_native", False):
+            plan["fn"]()
+            return
+        if plan.get("graph") is not None:
+            plan["graph"].replay()
+            return
+        if self.use_graph and plan["runs"] >= 1 and not plan.get("graph_failed"):
+            try:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    ops.replay(plan["rec"], ops.stream())
+                plan["graph"] = g
+                g.replay()
+                return
+            except Exception as e:  # capture unsupported -> stay on plain replay, loudly
+                plan["graph_failed"] = str(e)
+                import warnings
+                warnings.warn(f"hipGraph capture failed, replaying launches instead: {e}")
+        ops.replay(plan["rec"], ops.stream())
+        plan["runs"] += 1
+
+
+# =================================================================================== UNet
+class UNetEngine(_Engine):
+    def __init__(self, model, ops):
+        super().__init__(ops)
+        self.model = model
+
+    def __call__(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None):
+        m = self.model
+        assert x.dim() == 5 and context is not None
+        if m.training:
+            for mod in m.modules():
+                if isinstance(mod, nn.Dropout) and mod.p > 0:
+                    raise RuntimeError("native UNet path is inference-only (dropout active): call .eval() first")
+        self._check_weights(m)
+        fps_is_int = isinstance(fps, int)
+        key = (tuple(x.shape), x.dtype, tuple(context.shape), context.dtype, fps_is_int,
+               None if timestep_cond is None else (tuple(timestep_cond.shape), timestep_cond.dtype),
+               None if motion_cond is None else (tuple(motion_cond.shape), motion_cond.dtype), x.device)
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = self._record(x, timesteps, context, fps, timestep_cond, motion_cond)
+            self.plans[key] = plan
+        else:
+            st = plan["static"]
+            st["x"].copy_(x)
+            st["ts"].copy_(timesteps)
+            st["ctx"].copy_(context)
+            if m.fps_cond:
+                if fps_is_int:
+                    st["fps"].fill_(fps)
+                else:
+                    st["fps"].copy_(fps)
+            if timestep_cond is not None:
+                st["tc"].copy_(timestep_cond)
+            if motion_cond is not None:
+                st["mc"].copy_(motion_cond)
+            self._run(plan)
+        self._publish_probs(plan)
+        return plan["out"].clone()
+
+    def _publish_probs(self, plan):
+        for attn, probs in plan["probs"]:
+            attn.attention_probs = probs
+
+    # ---- recording ----------------------------------------------------------------------------------------
+    def _record(self, x, timesteps, context, fps, timestep_cond, motion_cond):
+        m, ops = self.model, self.ops
+        self._begin(x.device)
+        B, Cin, F, H, W = x.shape
+        self.B, self.F = B, F
+        st = {"x": x.detach().clone().contiguous(), "ts": timesteps.detach().to(torch.int64).clone(),
+              "ctx": context.detach().clone().contiguous()}
+        if m.fps_cond:
+            st["fps"] = (torch.full_like(st["ts"], fps) if isinstance(fps, int) else fps.detach().to(torch.int64).clone())
+        if timestep_cond is not None:
+            st["tc"] = timestep_cond.detach().clone().contiguous()
+        if motion_cond is not None:
+            st["mc"] = motion_cond.detach().clone().contiguous()
+        out = torch.empty_like(st["x"][:, :m.out_channels].contiguous()) if m.out_channels != Cin else torch.empty_like(st["x"])
+        plan = {"static": st, "out": out, "probs": [], "runs": 0}
+        self.plan = plan
+
+        def body():
+            self._forward(st, out)
+
+        if getattr(ops, "is_native", False):
+            ops.init()
+            ops.recording = []
+            try:
+                body()
+            finally:
+                plan["rec"] = ops.recording
+                ops.recording = None
+        else:
+            plan["fn"] = body
+            body()
+        plan["pool_bytes"] = self.pool.bytes
+        return plan
+
+    def _forward(self, st, out):
+        m, ops, pk = self.model, self.ops, self.pk
+        B, F = self.B, self.F
+        x = st["x"]
+        _, Cin, _, H, W = x.shape
+        mc = m.model_channels
+        L, D = st["ctx"].shape[1], st["ctx"].shape[2]
+        # ---- conditioning vectors (M = B rows; openaimodel3d.py:683-706) ----------------------------------
+        t_emb = self.buf(B, mc)
+        ops.timestep_embedding(st["ts"], mc, False, t_emb)
+        emb_in = t_emb
+        if "tc" in st:
+            tcb = self.buf(B, st["tc"].shape[1])
+            ops.cast(st["tc"], tcb)
+            if "mc" in st:
+                cond = self.linear(tcb, m.time_cond_proj)
+                mcb = self.buf(B, st["mc"].shape[1])
+                ops.cast(st["mc"], mcb)
+                mproj = self.linear(mcb, m.motion_cond_proj)
+                emb_in = self.buf(B, mc)
+                ops.gemm(cond, pk.mat(m.combine_proj), emb_in, M=B, N=mc, a1=mproj, residual=t_emb)
+            else:
+                emb_in = self.linear(tcb, m.time_cond_proj, residual=t_emb)
+        e1 = self.linear(emb_in, m.time_embed[0], act=nt.ACT_SILU)
+        emb = self.linear(e1, m.time_embed[2])
+        if m.fps_cond:
+            f_emb = self.buf(B, mc)
+            ops.timestep_embedding(st["fps"], mc, False, f_emb)
+            f1 = self.linear(f_emb, m.fps_embedding[0], act=nt.ACT_SILU)
+            emb = self.linear(f1, m.fps_embedding[2], residual=emb)
+        emb_s = self.buf(B, emb.shape[1])
+        ops.silu(emb, emb_s)
+        # every ResBlock's emb_layers Linear in one GEMM (rows are identical across frames: K17)
+        resblocks = [mod for mod in m.modules() if isinstance(mod, ResBlock)]
+        self.emb_off, off = {}, 0
+        for rb in resblocks:
+            self.emb_off[id(rb)] = off
+            off += rb.out_channels
+        lins = [rb.emb_layers[1] for rb in resblocks]
+        w_all = pk.cat_mats(lins, "emb_all")
+        b_all = pk._memo(("emb_all_bias",) + tuple(id(l) for l in lins),
+                         lambda: torch.cat([pk.bias(l) for l in lins]).contiguous())
+        self.emb_all = self.linear(emb_s, None, w=w_all, bias=b_all, out_dtype=torch.float32)
+        # ---- context in activation dtype, shared by all frames of a clip (K11) ----------------------------
+        self.ctx = self.buf(B * L, D)
+        ops.cast(st["ctx"], self.ctx)
+        self.ctx_len = L
+        self.ctx_kv = {}
+        # ---- input conv on the 4-channel latent -----------------------------------------------------------------
+        xt = self.buf(B * F * H * W, Cin)
+        ops.ncfhw_to_tokens(x, xt)
+        conv_in = m.input_blocks[0][0]
+        h0 = self.buf(B * F * H * W, leaf_out_channels(conv_in))
+        ops.conv_small(xt, B * F, H, W, pk.small_conv(conv_in), pk.bias(conv_in), h0)
+        h = Act(h0, B * F, H, W)
+        hs = []
+        for i, block in enumerate(m.input_blocks):
+            if i > 0:
+                h = self.run_sequential(block, h)
+            if i == 0 and m.addition_attention:
+                h = self.run_sequential(m.init_attn, h)
+            hs.append(h)
+        h = self.run_sequential(m.middle_block, h)
+        for block in m.output_blocks:
+            skip = hs.pop()
+            h = self.run_sequential(block, Act([h.t, skip.t], h.n_img, h.h, h.w), release=[h.t, skip.t])
+        # ---- out: GroupNorm -> SiLU -> conv to 4 channels, fp32, back to (b c f h w) ------------------------------
+        t = self.gn(h, m.out[0], B * F, H * W, True)
+        y = self.conv(Act(t, h.n_img, h.h, h.w), m.out[2], nt.GEMM_CONV3X3, out_dtype=torch.float32)
+        ops.tokens_to_ncfhw(y.t, out)
+
+    def run_sequential(self, seq, h, release=()):
+        assert isinstance(seq, TimestepEmbedSequential)
+        first = True
+        for layer in seq:
+            if isinstance(layer, ResBlock):
+                nh = self.res_block(layer, h)
+            elif isinstance(layer, SpatialTransformer):
+                nh = self.spatial_transformer(layer, h)
+            elif isinstance(layer, TemporalTransformer):
+                nh = self.temporal_transformer(layer, h)
+            elif isinstance(layer, Downsample):
+                assert layer.use_conv, "avg-pool downsample is not used by the VideoCrafter2 config"
+                nh = self.conv(h, layer.op, nt.GEMM_CONV3X3_S2)
+            elif isinstance(layer, Upsample):
+                assert layer.use_conv
+                nh = self.conv(h, layer.conv, nt.GEMM_CONV3X3_UP2)
+            else:
+                raise NotImplementedError(f"native path: unsupported layer {type(layer).__name__}")
+            # intermediates inside a sequential die as soon as the next layer consumed them; the
+            # sequential's *input* belongs to the caller (it may be a skip connection)
+            if not first:
+                self.pool.put(*h.parts)
+            h, first = nh, False
+        self.pool.put(*release)
+        return h
+
+    # ---- blocks ------------------------------------------------------------------------------------------------------
+    def res_block(self, rb, x):
+        B, F = self.B, self.F
+        hw = x.h * x.w
+        off, cout = self.emb_off[id(rb)], rb.out_channels
+        t = self.gn(x, rb.in_layers[0], B * F, hw, True)
+        h1 = self.conv(Act(t, x.n_img, x.h, x.w), rb.in_layers[2], nt.GEMM_CONV3X3,
+                       rowvec=self.emb_all[:, off:off + cout], rowvec_div=F * hw)
+        self.pool.put(t)
+        t2 = self.gn(h1, rb.out_layers[0], B * F, hw, True)
+        self.pool.put(h1.t)
+        if isinstance(rb.skip_connection, nn.Identity):
+            skip, own_skip = x.t, False
+        else:
+            sc = rb.skip_connection
+            w = self.pk.mat(sc) if effective_weight_bias(sc)[0].shape[-1] == 1 else None
+            assert w is not None, "3x3 skip convs (use_conv=True) are not built by the VideoCrafter2 config"
+            skip = self.buf(x.M, cout)
+            self.ops.gemm(x.parts[0], w, skip, M=x.M, N=cout, a1=x.p1, bias=self.pk.bias(sc))
+            own_skip = True
+        h2 = self.conv(Act(t2, x.n_img, x.h, x.w), rb.out_layers[3], nt.GEMM_CONV3X3, residual=skip)
+        self.pool.put(t2)
+        if own_skip:
+            self.pool.put(skip)
+        if rb.use_temporal_conv:
+            tc = rb.temopral_conv
+            y = h2
+            for i, stage in enumerate((tc.conv1, tc.conv2, tc.conv3, tc.conv4)):
+                tt = self.gn(y, stage[0], B, F * hw, True)
+                ny = self.conv(Act(tt, x.n_img, x.h, x.w), stage[-1], nt.GEMM_TCONV3, frames=F,
+                               residual=h2.t if i == 3 else None)
+                self.pool.put(tt)
+                if y is not h2:
+                    self.pool.put(y.t)
+                y = ny
+            self.pool.put(h2.t)
+            h2 = y
+        return h2
+
+    def _check_heads(self, attn):
+        if attn.dim_head != 64:
+            raise nt.NativeError(f"native attention kernels need dim_head == 64 (got {attn.dim_head})")
+
+    def transformer_block(self, blk, y, x_geom, temporal):
+        """BasicTransformerBlock on token rows y [M, C] (attention.py:300-311)."""
+        ops, pk = self.ops, self.pk
+        B, F = self.B, self.F
+        M, C = y.shape
+        n_img, hw = x_geom
+        a1, a2 = blk.attn1, blk.attn2
+        self._check_heads(a1)
+        inner = a1.heads * a1.dim_head
+        ln = self.buf(M, C)
+
+        def lnorm(norm, src):
+            ops.layernorm(src, pk.f32(norm.weight), pk.f32(norm.bias), norm.eps, ln)
+            return ln
+
+        def temporal_attn(attn, src):
+            qkv = self.linear(src, None, w=pk.cat_mats([attn.to_q, attn.to_k, attn.to_v], "qkv"), bias=None)
+            o = self.buf(M, inner)
+            probs = None
+            if attn.record_attn_probs:
+                probs = torch.empty(B * hw * attn.heads, F, F, dtype=torch.float32, device=self.device)
+                self.plan["probs"].append((attn, probs))
+            ops.attn_temporal(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], o, B, F, hw, attn.heads,
+                              attn.scale, probs)
+            self.pool.put(qkv)
+            return o
+
+        def spatial_self_attn(attn, src):
+            qk = self.linear(src, None, w=pk.cat_mats([attn.to_q, attn.to_k], "qk"), bias=None)
+            kp = ((hw + 63) // 64) * 64
+            vt = self.buf(n_img * inner, kp, zero=True)
+            # V^T[c, token] = Wv[c,:] . x[token,:]: weights as the row operand, tokens as the column operand
+            ops.gemm(pk.mat(attn.to_v), src, vt, M=inner, N=hw, batch=n_img, w_strides=(hw * src.stride(0), 0),
+                     o_strides=(inner * kp, 0))
+            o = self.buf(M, inner)
+            ops.attn_spatial(qk[:, :inner], qk[:, inner:], vt, kp, o, n_img, hw, hw, attn.heads, 1, attn.scale)
+            self.pool.put(qk, vt)
+            return o
+
+        def cross_attn(attn, src):
+            q = self.linear(src, attn.to_q, bias=None)
+            if id(attn) not in self.ctx_kv:  # once per clip, not per frame (K11)
+                L = self.ctx_len
+                k = self.linear(self.ctx, attn.to_k, bias=None)
+                kp = ((L + 63) // 64) * 64
+                vt = self.buf(B * inner, kp, zero=True)
+                ops.gemm(pk.mat(attn.to_v), self.ctx, vt, M=inner, N=L, batch=B, w_strides=(L * self.ctx.stride(0), 0),
+                         o_strides=(inner * kp, 0))
+                self.ctx_kv[id(attn)] = (k, vt, kp)
+            k, vt, kp = self.ctx_kv[id(attn)]
+            o = self.buf(M, inner)
+            ops.attn_spatial(q, k, vt, kp, o, n_img, hw, self.ctx_len, attn.heads, F, attn.scale)
+            self.pool.put(q)
+            return o
+
+        # attn1: self attention (spatial or temporal)
+        src = lnorm(blk.norm1, y)
+        o = temporal_attn(a1, src) if temporal else spatial_self_attn(a1, src)
+        y1 = self.linear(o, a1.to_out[0], residual=y)
+        self.pool.put(o)
+        # attn2: temporal self attention again, or text cross attention
+        src = lnorm(blk.norm2, y1)
+        o = temporal_attn(a2, src) if temporal else cross_attn(a2, src)
+        y2 = self.linear(o, a2.to_out[0], residual=y1)
+        self.pool.put(o, y1)
+        # GEGLU feed-forward
+        src = lnorm(blk.norm3, y2)
+        proj = blk.ff.net[0]
+        assert hasattr(proj, "proj"), "non-gated FeedForward is not built by the VideoCrafter2 config"
+        wg, bg = pk.geglu(proj.proj)
+        g = self.linear(src, None, w=wg, bias=bg, act=nt.ACT_GEGLU)
+        y3 = self.linear(g, blk.ff.net[2], residual=y2)
+        self.pool.put(g, y2, ln)
+        return y3
+
+    def spatial_transformer(self, st, x):
+        B, F = self.B, self.F
+        hw = x.h * x.w
+        t = self.gn(x, st.norm, B * F, hw, False)
+        y = self.linear(t, st.proj_in)
+        self.pool.put(t)
+        for blk in st.transformer_blocks:
+            ny = self.transformer_block(blk, y, (x.n_img, hw), temporal=False)
+            self.pool.put(y)
+            y = ny
+        out = self.linear(y, st.proj_out, residual=x.t)
+        self.pool.put(y)
+        return Act(out, x.n_img, x.h, x.w)
+
+    def temporal_transformer(self, tt, x):
+        B, F = self.B, self.F
+        hw = x.h * x.w
+        t = self.gn(x, tt.norm, B, F * hw, False)
+        y = self.linear(t, tt.proj_in)
+        self.pool.put(t)
+        for blk in tt.transformer_blocks:
+            ny = self.transformer_block(blk, y, (x.n_img, hw), temporal=True)
+            self.pool.put(y)
+            y = ny
+        out = self.linear(y, tt.proj_out, residual=x.t)
+        self.pool.put(y)
+        return Act(out, x.n_img, x.h, x.w)

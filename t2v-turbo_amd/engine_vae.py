@@ -1,0 +1,152 @@
+"""Native KL-VAE decode: all frames of a clip in one batched pass of the same gfx950 kernels the
+UNet uses (implicit-GEMM 3x3 convs with folded nearest-x2 upsampling, two-phase GroupNorm+swish,
+the mid AttnBlock as two batched GEMMs + a row softmax).  Replaces the per-frame Python loop of
+``LatentDiffusion.decode_first_stage_2DAE`` (reference lvdm/models/ddpm3d.py:666-679) ->
+``AutoencoderKL.decode`` (autoencoder.py:110-113) -> ``Decoder.forward`` (ae_modules.py:602-641)."""
+import torch
+
+from . import native as nt
+from .engine import Act, _Engine, leaf_out_channels
+from .vae import AttnBlock
+
+
+class VAEDecodeEngine(_Engine):
+    def __init__(self, vae, ops):
+        super().__init__(ops)
+        self.vae = vae
+
+    def decode_frames(self, z, scale):
+        """z (b, zc, t, h, w) -> (b, out_ch, t, 8h, 8w) in z.dtype; z is multiplied by ``scale`` first."""
+        assert z.dim() == 5
+        self._check_weights(self.vae)
+        key = (tuple(z.shape), z.dtype, float(scale), z.device)
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = self._record(z, scale)
+            self.plans[key] = plan
+        else:
+            plan["static"]["z"].copy_(z)
+            self._run(plan)
+        return plan["out"].clone()
+
+    def _record(self, z, scale):
+        ops = self.ops
+        self._begin(z.device)
+        dec = self.vae.decoder
+        b, zc, t, h, w = z.shape
+        up = 2 ** (dec.num_resolutions - 1)
+        st = {"z": z.detach().clone().contiguous()}
+        out = torch.empty(b, leaf_out_channels(dec.conv_out), t, h * up, w * up, dtype=z.dtype, device=z.device)
+        plan = {"static": st, "out": out, "runs": 0}
+
+        def body():
+            self._forward(st["z"], scale, out)
+
+        if getattr(ops, "is_native", False):
+            ops.init()
+            ops.recording = []
+            try:
+                body()
+            finally:
+                plan["rec"] = ops.recording
+                ops.recording = None
+        else:
+            plan["fn"] = body
+            body()
+        plan["pool_bytes"] = self.pool.bytes
+        return plan
+
+    def _forward(self, z, scale, out):
+        ops, pk, vae = self.ops, self.pk, self.vae
+        dec = vae.decoder
+        b, zc, t, h, w = z.shape
+        n_img = b * t
+        assert zc <= 8
+        zt = self.buf(n_img * h * w, zc)
+        ops.ncfhw_to_tokens(z, zt)
+        # post_quant_conv (1x1, zc->zc) as the centre tap of a direct 3x3 with cout padded to 8; the
+        # 1/scale_factor of decode_first_stage_2DAE is folded into its weights
+        pq = vae.post_quant_conv
+
+        def pq_weights():
+            wq = pq.weight.detach().float().reshape(pq.weight.shape[0], zc) * scale
+            w3 = torch.zeros(8, 9, zc, dtype=torch.float32)
+            w3[: wq.shape[0], 4, :] = wq.cpu()
+            b8 = torch.zeros(8, dtype=torch.float32)
+            b8[: wq.shape[0]] = pq.bias.detach().float().cpu()
+            return w3.reshape(8, -1).to(self.device).contiguous(), b8.to(self.device)
+
+        w3, b8 = pk._memo(("pq", id(pq), float(scale)), pq_weights)
+        z8 = self.buf(n_img * h * w, 8)
+        ops.conv_small(zt, n_img, h, w, w3, b8, z8)
+        cin_w = pk.small_conv(dec.conv_in, cin_pad=8)
+        h0 = self.buf(n_img * h * w, leaf_out_channels(dec.conv_in))
+        ops.conv_small(z8, n_img, h, w, cin_w, pk.bias(dec.conv_in), h0)
+        self.pool.put(zt, z8)
+        x = Act(h0, n_img, h, w)
+        x = self.resnet_block(dec.mid.block_1, x)
+        if isinstance(dec.mid.attn_1, AttnBlock):
+            x = self.attn_block(dec.mid.attn_1, x)
+        x = self.resnet_block(dec.mid.block_2, x)
+        for lvl in reversed(range(dec.num_resolutions)):
+            for ib in range(dec.num_res_blocks + 1):
+                x = self.resnet_block(dec.up[lvl].block[ib], x)
+                if len(dec.up[lvl].attn) > 0:
+                    x = self.attn_block(dec.up[lvl].attn[ib], x)
+            if lvl != 0:
+                ups = dec.up[lvl].upsample
+                assert ups.with_conv
+                nx = self.conv(x, ups.conv, nt.GEMM_CONV3X3_UP2)
+                self.pool.put(x.t)
+                x = nx
+        tt = self.gn(x, dec.norm_out, n_img, x.h * x.w, True)
+        self.pool.put(x.t)
+        y = self.conv(Act(tt, n_img, x.h, x.w), dec.conv_out, nt.GEMM_CONV3X3, out_dtype=torch.float32)
+        self.pool.put(tt)
+        ops.tokens_to_ncfhw(y.t, out)
+        self.pool.put(y.t)
+
+    def resnet_block(self, rb, x):
+        """ResnetBlock with temb=None (ae_modules.py:183-203); consumes (frees) its input."""
+        hw = x.h * x.w
+        t1 = self.gn(x, rb.norm1, x.n_img, hw, True)
+        h1 = self.conv(Act(t1, x.n_img, x.h, x.w), rb.conv1, nt.GEMM_CONV3X3)
+        self.pool.put(t1)
+        t2 = self.gn(h1, rb.norm2, x.n_img, hw, True)
+        self.pool.put(h1.t)
+        skip, own = x.t, False
+        if rb.in_channels != rb.out_channels:
+            if rb.use_conv_shortcut:
+                skip = self.conv(x, rb.conv_shortcut, nt.GEMM_CONV3X3).t
+            else:
+                skip = self.linear(x.t, rb.nin_shortcut)
+            own = True
+        h2 = self.conv(Act(t2, x.n_img, x.h, x.w), rb.conv2, nt.GEMM_CONV3X3, residual=skip)
+        self.pool.put(t2, x.t)
+        if own:
+            self.pool.put(skip)
+        return h2
+
+    def attn_block(self, ab, x):
+        """AttnBlock (ae_modules.py:48-73): S = q k^T / sqrt(c) -> softmax -> S v, per image."""
+        ops, pk = self.ops, self.pk
+        c, seq, n_img = x.C, x.h * x.w, x.n_img
+        kp = ((seq + 63) // 64) * 64
+        t = self.gn(x, ab.norm, n_img, seq, False)
+        q = self.linear(t, ab.q)
+        k = self.linear(t, ab.k)
+        vt = self.buf(n_img * c, kp)
+        if kp != seq:
+            ops.fill_zero(vt)
+        # V^T per image (bias of v is added after the PV product: softmax rows sum to 1)
+        ops.gemm(pk.mat(ab.v), t, vt, M=c, N=seq, batch=n_img, w_strides=(seq * t.stride(0), 0), o_strides=(c * kp, 0))
+        s = self.buf(n_img * seq, kp)
+        ops.gemm(q, k, s, M=seq, N=seq, alpha=float(int(c) ** -0.5), batch=n_img, a_strides=(seq * q.stride(0), 0),
+                 w_strides=(seq * k.stride(0), 0), o_strides=(seq * kp, 0))
+        ops.softmax_rows(s, n_img * seq, seq, kp, kp)
+        o = self.buf(n_img * seq, c)
+        ops.gemm(s, vt, o, M=seq, N=c, batch=n_img, a_strides=(seq * kp, 0), w_strides=(c * kp, 0),
+                 o_strides=(seq * c, 0), bias=pk.bias(ab.v))
+        out = self.linear(o, ab.proj_out, residual=x.t)
+        self.pool.put(t, q, k, vt, s, o, x.t)
+        return Act(out, n_img, x.h, x.w)

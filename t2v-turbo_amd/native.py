@@ -71,6 +71,7 @@ _SIGS = {
                                       C.c_int, C.c_void_p]),
     "t2v_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "t2v_silu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "t2v_fill_zero": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p]),
     "t2v_cast": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
     "t2v_lincomb3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                C.c_longlong, C.c_void_p, C.c_void_p]),
@@ -228,6 +229,10 @@ class HipOps:
 
     def silu(self, x, out):
         self._call("t2v_silu", _p(x), _p(out), x.numel())
+
+    def fill_zero(self, t):
+        assert t.is_contiguous()
+        self._call("t2v_fill_zero", _p(t), t.numel() * t.element_size())
 
     def cast(self, x, out):
         assert x.is_contiguous() and out.is_contiguous() and x.numel() == out.numel()

@@ -1,0 +1,225 @@
+"""Torch emulation of the HIP op backend (``t2v_turbo_amd.native.HipOps``) — TEST ONLY.
+
+Implements the *documented semantics* of every C-ABI entry point (include/t2v_hip.h) with plain
+torch ops in fp32, consuming exactly the same tensor views / strides / packed weight layouts the
+engine hands to the real kernels.  It lets the CPU test-suite check the engine's recorded dataflow
+(layouts, weight packing, virtual concat, buffer reuse, batching strides) against the oracle
+without a GPU, and doubles as the per-op reference for the GPU kernel tests.  It is never imported
+by the product package.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from t2v_turbo_amd import native as nt
+
+
+def _strided(t, rows, cols, ld, offset_elems):
+    return torch.as_strided(t, (rows, cols), (ld, 1), t.storage_offset() + offset_elems)
+
+
+class EmuOps:
+    is_native = False
+
+    def __init__(self, act_dtype=torch.float32):
+        self.act_dtype = act_dtype
+        self.calls = []
+
+    def init(self):
+        pass
+
+    def _log(self, name):
+        self.calls.append(name)
+
+    # ------------------------------------------------------------------------------------ gemm
+    def gemm(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
+             rowvec=None, rowvec_div=0, residual=None, act=nt.ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
+             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0)):
+        self._log("gemm")
+        c0 = a0.shape[1]
+        c1 = 0 if a1 is None else a1.shape[1]
+        cin = c0 + c1
+        assert c0 % 64 == 0 and c1 % 64 == 0
+        taps = {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(mode, 9)
+        K = taps * cin
+        n_out = N // 2 if act == nt.ACT_GEGLU else N
+        for z in range(batch):
+            z0, z1 = z // batch_inner, z % batch_inner
+            a_off = z0 * a_strides[0] + z1 * a_strides[1]
+            w_off = z0 * w_strides[0] + z1 * w_strides[1]
+            o_off = z0 * o_strides[0] + z1 * o_strides[1]
+            wz = _strided(w, N, K, w.stride(0), w_off).float()
+            if mode == nt.GEMM_LINEAR:
+                rows = M
+            else:
+                rows = n_img * h * wd
+            src = _strided(a0, rows, c0, a0.stride(0), a_off).float()
+            if a1 is not None:
+                src = torch.cat([src, _strided(a1, rows, c1, a1.stride(0), a_off).float()], dim=1)
+            if mode == nt.GEMM_LINEAR:
+                y = src @ wz.t()
+            elif mode == nt.GEMM_TCONV3:
+                b = n_img // frames
+                x5 = src.reshape(b, frames, h * wd, cin).permute(0, 3, 1, 2)  # b c f p
+                wk = wz.reshape(N, 3, cin).permute(0, 2, 1)[..., None]      # N c 3 1
+                y = F.conv2d(x5, wk, padding=(1, 0)).permute(0, 2, 3, 1).reshape(-1, N)
+            else:
+                x4 = src.reshape(n_img, h, wd, cin).permute(0, 3, 1, 2)
+                wk = wz.reshape(N, 3, 3, cin).permute(0, 3, 1, 2)
+                if mode == nt.GEMM_CONV3X3:
+                    y = F.conv2d(x4, wk, padding=1)
+                elif mode == nt.GEMM_CONV3X3_S2:
+                    y = F.conv2d(x4, wk, stride=2, padding=1)
+                elif mode == nt.GEMM_CONV3X3_S2_PAD01:
+                    y = F.conv2d(F.pad(x4, (0, 1, 0, 1)), wk, stride=2)
+                elif mode == nt.GEMM_CONV3X3_UP2:
+                    y = F.conv2d(F.interpolate(x4, scale_factor=2, mode="nearest"), wk, padding=1)
+                else:
+                    raise ValueError(mode)
+                y = y.permute(0, 2, 3, 1).reshape(-1, N)
+            assert y.shape[0] == M, (y.shape, M)
+            y = y * alpha
+            if bias is not None:
+                y = y + bias.float()[None, :N]
+            if act == nt.ACT_GEGLU:
+                g = y.reshape(M, N // 64, 2, 32)
+                y = (g[:, :, 0] * F.gelu(g[:, :, 1])).reshape(M, N // 2)
+            if rowvec is not None:
+                idx = torch.arange(M) // rowvec_div
+                y = y + rowvec.float()[idx, :n_out]
+            if residual is not None:
+                y = y + _strided(residual, M, n_out, residual.stride(0), o_off).float()
+            if act == nt.ACT_SILU:
+                y = F.silu(y)
+            _strided(out, M, n_out, out.stride(0), o_off).copy_(y.to(out.dtype))
+
+    def conv_small(self, x, n_img, h, w, wgt, bias, out):
+        self._log("conv_small")
+        cin, cout = x.shape[1], out.shape[1]
+        x4 = x.float().reshape(n_img, h, w, cin).permute(0, 3, 1, 2)
+        wk = wgt.float().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+        y = F.conv2d(x4, wk, None if bias is None else bias.float(), padding=1)
+        out.copy_(y.permute(0, 2, 3, 1).reshape(-1, cout).to(out.dtype))
+
+    # ------------------------------------------------------------------------------------ norms
+    def gn_ws_floats(self, n_units, rows_per_unit, groups=32):
+        return 8
+
+    @staticmethod
+    def _cat(x0, x1):
+        return x0.float() if x1 is None else torch.cat([x0.float(), x1.float()], dim=1)
+
+    def gn_stats(self, x0, x1, n_units, rows_per_unit, eps, ws, stats, groups=32):
+        self._log("gn_stats")
+        x = self._cat(x0, x1)
+        C = x.shape[1]
+        xg = x.reshape(n_units, rows_per_unit, groups, C // groups).permute(0, 2, 1, 3).reshape(n_units, groups, -1)
+        mean = xg.mean(dim=2)
+        var = xg.var(dim=2, unbiased=False)
+        stats.copy_(torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=2).reshape(n_units, groups * 2))
+
+    def gn_apply(self, x0, x1, n_units, rows_per_unit, stats, gamma, beta, silu, out, groups=32):
+        self._log("gn_apply")
+        x = self._cat(x0, x1)
+        C = x.shape[1]
+        st = stats.reshape(n_units, groups, 2)
+        mean = st[:, :, 0].repeat_interleave(C // groups, dim=1)[:, None, :]
+        rstd = st[:, :, 1].repeat_interleave(C // groups, dim=1)[:, None, :]
+        y = (x.reshape(n_units, rows_per_unit, C) - mean) * rstd * gamma.float() + beta.float()
+        if silu:
+            y = F.silu(y)
+        out.copy_(y.reshape(-1, C).to(out.dtype))
+
+    def layernorm(self, x, gamma, beta, eps, out):
+        self._log("layernorm")
+        out.copy_(F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps).to(out.dtype))
+
+    def softmax_rows(self, s, rows, n, n_pad, ld):
+        self._log("softmax_rows")
+        v = _strided(s, rows, n_pad, ld, 0)
+        p = torch.zeros(rows, n_pad)
+        p[:, :n] = v[:, :n].float().softmax(dim=1)
+        v.copy_(p.to(s.dtype))
+
+    # ------------------------------------------------------------------------------------ attention
+    def attn_spatial(self, q, k, vt, ld_vt, out, n_img, seq_q, seq_kv, heads, kv_div, scale):
+        self._log("attn_spatial")
+        assert ld_vt >= ((seq_kv + 63) // 64) * 64
+        for img in range(n_img):
+            ikv = img // kv_div
+            for hd in range(heads):
+                Q = q[img * seq_q:(img + 1) * seq_q, hd * 64:(hd + 1) * 64].float()
+                Kk = k[ikv * seq_kv:(ikv + 1) * seq_kv, hd * 64:(hd + 1) * 64].float()
+                Vt = _strided(vt, 64, seq_kv, ld_vt, (ikv * heads + hd) * 64 * ld_vt).float()
+                P = (Q @ Kk.t() * scale).softmax(dim=1)
+                out[img * seq_q:(img + 1) * seq_q, hd * 64:(hd + 1) * 64] = (P @ Vt.t()).to(out.dtype)
+
+    def attn_temporal(self, q, k, v, out, n_clips, frames, hw, heads, scale, probs=None):
+        self._log("attn_temporal")
+        inner = heads * 64
+
+        def seqs(t):  # rows ((b f) p) -> (b p head) f d
+            return t.float().reshape(n_clips, frames, hw, heads, 64).permute(0, 2, 3, 1, 4).reshape(-1, frames, 64)
+
+        Q, Kk, V = seqs(q), seqs(k), seqs(v)
+        P = (Q @ Kk.transpose(1, 2) * scale).softmax(dim=2)
+        if probs is not None:
+            probs.copy_(P)
+        O = (P @ V).reshape(n_clips, hw, heads, frames, 64).permute(0, 3, 1, 2, 4).reshape(-1, inner)
+        out.copy_(O.to(out.dtype))
+
+    # ------------------------------------------------------------------------------------ layout / elementwise
+    def ncfhw_to_tokens(self, x, out):
+        self._log("ncfhw_to_tokens")
+        b, c, f, h, w = x.shape
+        out[:, :c] = x.float().permute(0, 2, 3, 4, 1).reshape(-1, c).to(out.dtype)
+
+    def tokens_to_ncfhw(self, tok, out):
+        self._log("tokens_to_ncfhw")
+        b, c, f, h, w = out.shape
+        out.copy_(tok[:, :c].float().reshape(b, f, h, w, c).permute(0, 4, 1, 2, 3).to(out.dtype))
+
+    def timestep_embedding(self, t, dim, guidance_style, out):
+        self._log("timestep_embedding")
+        half = dim // 2
+        tv = t.float()
+        if guidance_style:
+            freq = torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000.0) / (half - 1)))
+            a = tv[:, None] * 1000.0 * freq[None]
+            e = torch.cat([torch.sin(a), torch.cos(a)], dim=1)
+        else:
+            freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+            a = tv[:, None] * freq[None]
+            e = torch.cat([torch.cos(a), torch.sin(a)], dim=1)
+        out[:, :2 * half] = e.to(out.dtype)
+
+    def silu(self, x, out):
+        self._log("silu")
+        out.copy_(F.silu(x.float()).to(out.dtype))
+
+    def cast(self, x, out):
+        self._log("cast")
+        out.copy_(x.reshape(out.shape).to(out.dtype))
+
+    def fill_zero(self, t):
+        self._log("fill_zero")
+        t.zero_()
+
+    def lincomb3(self, x, y, z, ca, cb, cc, out):
+        self._log("lincomb3")
+        nb = len(ca)
+        shp = (nb,) + (1,) * (x.dim() - 1)
+        v = torch.tensor(ca).reshape(shp) * x
+        if y is not None:
+            v = v + torch.tensor(cb).reshape(shp) * y
+        if z is not None:
+            v = v + torch.tensor(cc).reshape(shp) * z
+        out.copy_(v)
+
+    def lcm_step(self, x, eps, noise, sa_t, sb_t, c_skip, c_out, sa_p, sb_p, prev, denoised):
+        self._log("lcm_step")
+        x0 = (x - sb_t * eps.float()) / sa_t
+        den = c_out * x0 + c_skip * x
+        denoised.copy_(den)
+        prev.copy_(den if noise is None else sa_p * den + sb_p * noise)
