@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""Headline benchmark: VideoCrafter2 UNet denoise steps/s on a 16-frame 320x512 clip
+(latent (1,4,16,40,64), bf16) — BASELINE.json configs[1] — on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one UNet forward of the t2v-turbo sampling loop (timesteps cycle through the 4-step
+LCM table [999,759,519,279]) on synthetic inputs already resident in HBM.  Multi-GPU = independent
+replicas (inference shards by clip, no collective): weak scaling, value = N*K / max-over-ranks time.
+Rank 0 prints ONE JSON line (see DESIGN.md §Measurement for the extra objects).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+UNET_TFLOP_PER_STEP = 12.581   # BASELINE.md §2 (2*MAC, matmul+conv, B=1, 16x40x64)
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
+
+VC2_UNET = dict(
+    in_channels=4, out_channels=4, model_channels=320, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+    channel_mult=[1, 2, 4, 4], num_head_channels=64, transformer_depth=1, context_dim=1024, use_linear=True,
+    use_checkpoint=False, temporal_conv=True, temporal_attention=True, temporal_selfatt_only=True,
+    use_relative_position=False, use_causal_attention=False, temporal_length=16, addition_attention=True,
+    fps_cond=True, time_cond_proj_dim=256)
+
+
+def build_model(device, dtype):
+    from t2v_turbo_amd.unet3d import UNetModel
+    with torch.device(device):
+        m = UNetModel(**VC2_UNET)
+    g = torch.Generator(device=device).manual_seed(1234)
+    with torch.no_grad():
+        for p in m.parameters():  # zero_module'd tensors would make the output identically 0
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0.0, 0.02, generator=g)
+    m = m.to(dtype).eval()
+    m.dtype = dtype
+    return m
+
+
+def synth_inputs(device, dtype):
+    from t2v_turbo_amd.nn_util import guidance_embedding
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 16, 40, 64, generator=g).to(device, dtype)
+    ctx = torch.randn(1, 77, 1024, generator=g).to(device, dtype)
+    tc = guidance_embedding(torch.tensor([7.5]), 256).to(device, dtype)
+    return x, ctx, tc
+
+
+def kernel_breakdown(engine, plan):
+    """Replay the recorded launches with an event pair around each one (same stream the kernels run on)
+    and aggregate per C-ABI entry point; GEMM launches carry their algorithmic FLOPs (2*M*N*K*batch)."""
+    from t2v_turbo_amd import native as nt
+    ops = engine.ops
+    rec = plan["rec"]
+    stream = ops.stream()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(rec) + 1)]
+    torch.cuda.synchronize()
+    evs[0].record()
+    for i, (fn, args, name) in enumerate(rec):
+        fn(*args, stream)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    agg = {}
+    for i, (fn, args, name) in enumerate(rec):
+        ms = evs[i].elapsed_time(evs[i + 1])
+        a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "tflop": 0.0})
+        a["launches"] += 1
+        a["ms"] += ms
+        if name == "t2v_gemm":
+            d = args[0]._obj
+            taps = {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(d.mode, 9)
+            a["tflop"] += 2.0 * d.M * d.N * taps * (d.c0 + d.c1) * max(d.batch, 1) / 1e12
+        elif name == "t2v_attn_spatial":
+            n_img, seq_q, seq_kv, heads = args[8], args[9], args[10], args[11]
+            a["tflop"] += 4.0 * n_img * heads * seq_q * seq_kv * 64 / 1e12
+        elif name == "t2v_attn_temporal":
+            clips, frames, hw, heads = args[8], args[9], args[10], args[11]
+            a["tflop"] += 4.0 * clips * hw * heads * frames * frames * 64 / 1e12
+    return agg
+
+
+def cpu_baseline(model, x, ctx, tc, y_gpu, frames):
+    """The oracle (CPU restatement of the reference forward, pinned to reference goldens) timed on this
+    host's cores on a bounded sample: ONE UNet forward on the first `frames` frames of the same clip."""
+    from oracle import unet_oracle as uo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    xs = x[:, :, :frames].float().cpu()
+    ts = torch.tensor([999])
+    t0 = time.time()
+    y = uo.unet_forward(sd, VC2_UNET, xs, ts, ctx.float().cpu(), fps=16, timestep_cond=tc.float().cpu())
+    dt = time.time() - t0
+    out = {"value": round((frames / 16.0) / dt, 5), "unit": "UNet steps/s (16f-equivalent)", "cores": cores,
+           "kind": "port",
+           "sample": f"1 fp32 forward of oracle.unet_oracle (restated reference UNetModel.forward) on a "
+                     f"(1,4,{frames},40,64) latent, {dt:.1f} s wall, torch CPU {cores} threads"}
+    if y_gpu is not None:
+        num = (y_gpu.float().cpu() - y).double().norm()
+        out["parity_rel_l2_vs_gpu"] = float(num / y.double().norm())
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graph", type=int, default=1, help="replay the recorded forward as one hipGraph")
+    ap.add_argument("--cpu-baseline", type=int, default=1)
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU sample (0 = auto by core count)")
+    ap.add_argument("--clip", type=int, default=1, help="also time the 4-step clip incl. VAE decode")
+    ap.add_argument("--breakdown", type=int, default=1)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (MI355X)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16
+
+    model = build_model(dev, dtype)
+    x, ctx, tc = synth_inputs(dev, dtype)
+    eng = model.native_engine()
+    eng.use_graph = bool(args.graph)
+    table = [999, 759, 519, 279]
+    ts = [torch.tensor([t], device=dev, dtype=torch.long) for t in table]
+
+    def step(i):
+        return model(x, ts[i % 4], context=ctx, fps=16, timestep_cond=tc)
+
+    with torch.no_grad():
+        y0 = step(0)  # recording pass (also packs weights)
+        for i in range(max(args.warmup, 2)):  # >= 2: the second call captures the graph
+            step(i)
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+
+    result = {
+        "metric": "UNet denoise steps/sec (16f 320x512 latent)", "value": round(value, 4), "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "VideoCrafter2 UNet forward, B=1 per GPU, latent (1,4,16,40,64), ctx (1,77,1024), "
+                               "4-step LCM timestep table, random-init weights (zero-init tensors re-drawn)",
+                   "parallelism": f"replicas x{world}", "hip_graph": bool(args.graph)},
+        "tflops_per_gpu": round(UNET_TFLOP_PER_STEP / (ms_per_step / 1e3), 2),
+    }
+    if rank == 0:
+        plan = next(iter(eng.plans.values()))
+        result["config"]["graph_captured"] = plan.get("graph") is not None
+        result["config"]["launches_per_step"] = len(plan["rec"])
+        result["config"]["workspace_gb"] = round(plan["pool_bytes"] / 2 ** 30, 3)
+        if args.breakdown:
+            with torch.no_grad():
+                agg = kernel_breakdown(eng, plan)
+            gm = agg.get("t2v_gemm", {"ms": 0.0, "tflop": 0.0, "launches": 0})
+            ach = gm["tflop"] / (gm["ms"] / 1e3) if gm["ms"] > 0 else 0.0
+            result["roofline"] = {
+                "kernel": "gemm_kernel (implicit-GEMM conv / linear, v_mfma_f32_32x32x16_bf16)",
+                "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": gm["launches"], "tflop_per_step": round(gm["tflop"], 3), "ms_per_step": round(gm["ms"], 3),
+                "whole_step_frac": round(UNET_TFLOP_PER_STEP / (ms_per_step / 1e3) / MFMA_PEAK_TFLOPS, 4),
+            }
+            result["kernel_ms"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflop": round(v["tflop"], 3)}
+                                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        if args.clip and world == 1:
+            result["clip_4step"] = clip_wallclock(model, dev, dtype)
+        if args.cpu_baseline and world == 1:
+            frames = args.cpu_frames or (16 if (os.cpu_count() or 1) >= 32 else 4)
+            with torch.no_grad():
+                y_gpu = model(x[:, :, :frames].contiguous(), ts[0], context=ctx, fps=16, timestep_cond=tc)
+            result["cpu_baseline"] = cpu_baseline(model, x, ctx, tc, y_gpu, frames)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def clip_wallclock(model, dev, dtype):
+    """4 UNet steps + scheduler + 16-frame VAE decode -> (1,3,16,320,512), prompt embeds given."""
+    try:
+        from t2v_turbo_amd.pipeline import T2VTurboVC2Pipeline, make_synthetic_t2v
+    except Exception as e:  # pipeline not built yet in this revision
+        return {"error": f"pipeline unavailable: {e}"}
+    t2v = make_synthetic_t2v(model, dev, dtype)
+    pipe = T2VTurboVC2Pipeline(t2v, None, {"params": {"unet_config": {"params": VC2_UNET}}})
+    g = torch.Generator().manual_seed(0)
+    pe = torch.randn(1, 77, 1024, generator=g).to(dev, dtype)
+    times = []
+    for it in range(3):
+        gen = torch.Generator(device=dev).manual_seed(42)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        vid = pipe(prompt=None, height=320, width=512, frames=16, fps=16, guidance_scale=7.5, num_inference_steps=4,
+                   lcm_origin_steps=50, prompt_embeds=pe, generator=gen, output_type="pt")
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    return {"ms": round(min(times), 2), "ms_all": [round(t, 2) for t in times], "video_shape": list(vid.shape),
+            "finite": bool(torch.isfinite(vid.float()).all())}
+
+
+if __name__ == "__main__":
+    main()

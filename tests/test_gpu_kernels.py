@@ -1,0 +1,285 @@
+"""-m gpu: every HIP kernel, called through the C-ABI, against the torch emulation of the same op
+(tests/emu_ops.py) on identical bf16-rounded inputs.  Tolerances: outputs are bf16 (8 mantissa
+bits) of fp32-accumulated values -> rel-L2 <= 4e-3 per op (fp32 outputs: <= 2e-3, limited by the
+bf16 inputs of MFMA products); statistics (fp32): 1e-4."""
+import pytest
+import torch
+
+from tests.emu_ops import EmuOps
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+BF16_TOL = 4e-3
+
+
+def _rt(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).bfloat16().float()
+
+
+class Pair:
+    """Runs one op on both backends: tensors are created from the same CPU fp32 (bf16-exact) data."""
+
+    def __init__(self):
+        from t2v_turbo_amd.native import HipOps
+        self.hip, self.emu = HipOps(), EmuOps()
+        self.hip.init()
+
+    def act(self, t):  # activation / weight operand
+        return t.cuda().bfloat16().contiguous(), t.clone().float().contiguous()
+
+    def f32(self, t):
+        return t.cuda().float().contiguous(), t.clone().float().contiguous()
+
+    def run(self, name, args_hip, args_emu, kw_hip=None, kw_emu=None):
+        getattr(self.hip, name)(*args_hip, **(kw_hip or {}))
+        getattr(self.emu, name)(*args_emu, **(kw_emu or {}))
+        torch.cuda.synchronize()
+
+
+@pytest.fixture(scope="module")
+def pair():
+    return Pair()
+
+
+def _gemm_case(pair, *, M, N, c0, c1=0, mode=0, n_img=0, h=0, w=0, frames=0, bias=True, rowvec_div=0, residual=False,
+               act=0, alpha=1.0, out_f32=False, cfg=0, rows=None, seed=0):
+    from t2v_turbo_amd import native as nt
+    taps = {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(mode, 9)
+    K = taps * (c0 + c1)
+    rows = rows or M
+    a0 = pair.act(_rt(rows, c0, seed=seed))
+    a1 = pair.act(_rt(rows, c1, seed=seed + 1)) if c1 else (None, None)
+    wt = pair.act(_rt(N, K, seed=seed + 2, scale=K ** -0.5))
+    b = pair.f32(_rt(N, seed=seed + 3)) if bias else (None, None)
+    n_out = N // 2 if act == nt.ACT_GEGLU else N
+    rv = pair.f32(_rt((M + rowvec_div - 1) // rowvec_div, n_out, seed=seed + 4)) if rowvec_div else (None, None)
+    res = pair.act(_rt(M, n_out, seed=seed + 5)) if residual else (None, None)
+    odt = torch.float32 if out_f32 else torch.bfloat16
+    out_h = torch.full((M, n_out), float("nan"), dtype=odt, device="cuda")
+    out_e = torch.zeros(M, n_out)
+    kw = dict(M=M, N=N, mode=mode, n_img=n_img, h=h, wd=w, frames=frames, rowvec_div=rowvec_div, act=act, alpha=alpha)
+    pair.hip.lib.t2v_gemm_force_config(cfg)
+    try:
+        pair.hip.gemm(a0[0], wt[0], out_h, a1=a1[0], bias=b[0], rowvec=rv[0], residual=res[0], **kw)
+    finally:
+        pair.hip.lib.t2v_gemm_force_config(0)
+    pair.emu.gemm(a0[1], wt[1], out_e, a1=a1[1], bias=b[1], rowvec=rv[1], residual=res[1], **kw)
+    torch.cuda.synchronize()
+    got = out_h.float().cpu()
+    assert torch.isfinite(got).all(), "kernel left output elements unwritten / non-finite"
+    return rel_l2(got, out_e)
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_gemm_linear_tiles_and_masking(pair, cfg):
+    assert _gemm_case(pair, M=300, N=320, c0=320, residual=True, cfg=cfg) < BF16_TOL
+    assert _gemm_case(pair, M=1024, N=192, c0=128, c1=64, cfg=cfg, seed=3) < BF16_TOL  # virtual concat
+    assert _gemm_case(pair, M=77, N=64, c0=1024, bias=False, cfg=cfg, seed=5) < BF16_TOL
+
+
+def test_gemm_epilogues(pair):
+    from t2v_turbo_amd import native as nt
+    assert _gemm_case(pair, M=500, N=512, c0=128, act=nt.ACT_GEGLU) < BF16_TOL
+    assert _gemm_case(pair, M=130, N=256, c0=64, act=nt.ACT_SILU, seed=2) < BF16_TOL
+    assert _gemm_case(pair, M=200, N=4, c0=64, out_f32=True, seed=4) < 2e-3          # tiny N, scalar stores
+    assert _gemm_case(pair, M=200, N=3, c0=128, seed=6) < BF16_TOL
+    assert _gemm_case(pair, M=256, N=128, c0=64, alpha=0.125, bias=False, seed=8) < BF16_TOL
+    assert _gemm_case(pair, M=2, N=1280, c0=320, act=nt.ACT_SILU, seed=9) < BF16_TOL  # M = batch rows
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_gemm_conv_modes(pair, cfg):
+    from t2v_turbo_amd import native as nt
+    n, h, w = 3, 10, 12
+    common = dict(n_img=n, h=h, w=w, rows=n * h * w, cfg=cfg)
+    assert _gemm_case(pair, M=n * h * w, N=128, c0=64, mode=nt.GEMM_CONV3X3, rowvec_div=h * w, residual=True, **common) < BF16_TOL
+    assert _gemm_case(pair, M=n * h * w, N=64, c0=64, c1=128, mode=nt.GEMM_CONV3X3, seed=1, **common) < BF16_TOL
+    assert _gemm_case(pair, M=n * 5 * 6, N=64, c0=128, mode=nt.GEMM_CONV3X3_S2, seed=2, **common) < BF16_TOL
+    assert _gemm_case(pair, M=n * 4 * h * w, N=64, c0=64, mode=nt.GEMM_CONV3X3_UP2, seed=3, **common) < BF16_TOL
+    assert _gemm_case(pair, M=n * 5 * 6, N=64, c0=64, mode=nt.GEMM_CONV3X3_S2_PAD01, seed=4, **common) < BF16_TOL
+    # odd sizes: 5x7 grid, stride 2 -> 3x4
+    assert _gemm_case(pair, M=2 * 3 * 4, N=64, c0=64, mode=nt.GEMM_CONV3X3_S2, n_img=2, h=5, w=7, rows=70, cfg=cfg, seed=5) < BF16_TOL
+    # temporal (3,1,1): 2 clips x 4 frames x (3x5) pixels
+    assert _gemm_case(pair, M=2 * 4 * 15, N=128, c0=128, mode=nt.GEMM_TCONV3, n_img=8, h=3, w=5, frames=4, rows=120,
+                      residual=True, cfg=cfg, seed=6) < BF16_TOL
+
+
+def test_gemm_long_k_and_full_size_shapes(pair):
+    from t2v_turbo_amd import native as nt
+    # K = 9*1280 = 11520 (the 5x8 / 10x16 levels), M not a tile multiple
+    assert _gemm_case(pair, M=16 * 5 * 8, N=1280, c0=1280, mode=nt.GEMM_CONV3X3, n_img=16, h=5, w=8, seed=1) < BF16_TOL
+    # top level 320->320 conv on 16x40x64 tokens
+    assert _gemm_case(pair, M=16 * 40 * 64, N=320, c0=320, mode=nt.GEMM_CONV3X3, n_img=16, h=40, w=64,
+                      rowvec_div=16 * 40 * 64, seed=2) < BF16_TOL
+    assert _gemm_case(pair, M=40960, N=2560, c0=320, act=nt.ACT_GEGLU, seed=3) < BF16_TOL
+
+
+def test_gemm_batched_two_level_strides(pair):
+    # out[z0,z1] = A[z0,z1] W[z0,z1]^T with distinct strides (the PV product of the GEMM-formulated attention)
+    B0, B1, M, N, K = 2, 3, 96, 64, 128
+    A = _rt(B0 * B1 * M, K, seed=1)
+    W = _rt(B0 * B1 * N, K, seed=2, scale=K ** -0.5)
+    a_h, a_e = pair.act(A)
+    w_h, w_e = pair.act(W)
+    out_h = torch.zeros(B0 * B1 * M, N, dtype=torch.bfloat16, device="cuda")
+    out_e = torch.zeros(B0 * B1 * M, N)
+    kw = dict(M=M, N=N, batch=B0 * B1, batch_inner=B1, a_strides=(B1 * M * K, M * K), w_strides=(B1 * N * K, N * K),
+              o_strides=(B1 * M * N, M * N))
+    pair.hip.gemm(a_h, w_h, out_h, **kw)
+    pair.emu.gemm(a_e, w_e, out_e, **kw)
+    torch.cuda.synchronize()
+    assert rel_l2(out_h.float().cpu(), out_e) < BF16_TOL
+
+
+def test_conv_small_cin(pair):
+    for cin, cout in ((4, 320), (8, 64), (4, 512)):
+        n, h, w = 2, 9, 11
+        x = pair.act(_rt(n * h * w, cin, seed=cin))
+        wt = pair.f32(_rt(cout, 9 * cin, seed=1, scale=0.2))
+        b = pair.f32(_rt(cout, seed=2))
+        out_h = torch.zeros(n * h * w, cout, dtype=torch.bfloat16, device="cuda")
+        out_e = torch.zeros(n * h * w, cout)
+        pair.run("conv_small", (x[0], n, h, w, wt[0], b[0], out_h), (x[1], n, h, w, wt[1], b[1], out_e))
+        assert rel_l2(out_h.float().cpu(), out_e) < BF16_TOL
+
+
+@pytest.mark.parametrize("C,c1,units,rows", [(320, 0, 16, 160), (1920, 640, 4, 70), (64, 0, 2, 1000), (2560, 1280, 2, 40),
+                                             (960, 320, 1, 2560), (128, 0, 3, 4097)])
+def test_groupnorm(pair, C, c1, units, rows):
+    c0 = C - c1
+    x0 = pair.act((_rt(units * rows, c0, seed=1) * 2.0 + 0.5).bfloat16().float())
+    x1 = pair.act((_rt(units * rows, c1, seed=2) - 1.0).bfloat16().float()) if c1 else (None, None)
+    gamma, beta = pair.f32(_rt(C, seed=3) * 0.1 + 1.0), pair.f32(_rt(C, seed=4) * 0.1)
+    ws = torch.zeros(max(pair.hip.gn_ws_floats(units, rows), 1), device="cuda")
+    st_h, st_e = torch.zeros(units, 64, device="cuda"), torch.zeros(units, 64)
+    pair.run("gn_stats", (x0[0], x1[0], units, rows, 1e-5, ws, st_h), (x0[1], x1[1], units, rows, 1e-5, None, st_e))
+    assert rel_l2(st_h.cpu(), st_e) < 1e-4
+    for silu in (True, False):
+        out_h = torch.zeros(units * rows, C, dtype=torch.bfloat16, device="cuda")
+        out_e = torch.zeros(units * rows, C)
+        pair.run("gn_apply", (x0[0], x1[0], units, rows, st_h, gamma[0], beta[0], silu, out_h),
+                 (x0[1], x1[1], units, rows, st_e, gamma[1], beta[1], silu, out_e))
+        assert rel_l2(out_h.float().cpu(), out_e) < BF16_TOL
+
+
+@pytest.mark.parametrize("M,C", [(1000, 320), (37, 1280), (256, 64), (5, 512)])
+def test_layernorm(pair, M, C):
+    x = pair.act((_rt(M, C, seed=1) * 3.0 + 1.0).bfloat16().float())
+    gamma, beta = pair.f32(_rt(C, seed=3) * 0.1 + 1.0), pair.f32(_rt(C, seed=4) * 0.1)
+    out_h = torch.zeros(M, C, dtype=torch.bfloat16, device="cuda")
+    out_e = torch.zeros(M, C)
+    pair.run("layernorm", (x[0], gamma[0], beta[0], 1e-5, out_h), (x[1], gamma[1], beta[1], 1e-5, out_e))
+    assert rel_l2(out_h.float().cpu(), out_e) < BF16_TOL
+
+
+@pytest.mark.parametrize("rows,n,n_pad", [(300, 2560, 2560), (64, 77, 128), (10, 40, 64)])
+def test_softmax_rows(pair, rows, n, n_pad):
+    s = pair.act(_rt(rows, n_pad, seed=1) * 4.0)
+    pair.run("softmax_rows", (s[0], rows, n, n_pad, n_pad), (s[1], rows, n, n_pad, n_pad))
+    got = s[0].float().cpu()
+    assert rel_l2(got, s[1]) < 6e-3
+    assert float(got[:, n:].abs().max()) == 0.0 if n_pad > n else True
+
+
+@pytest.mark.parametrize("n_img,seq_q,seq_kv,heads,kv_div", [(3, 200, 200, 2, 1), (4, 160, 77, 5, 2), (2, 40, 40, 4, 1),
+                                                             (2, 640, 640, 1, 1), (1, 2560, 2560, 2, 1)])
+def test_attn_spatial_flash(pair, n_img, seq_q, seq_kv, heads, kv_div):
+    inner = heads * 64
+    n_kv = n_img // kv_div
+    kp = ((seq_kv + 63) // 64) * 64
+    q = pair.act(_rt(n_img * seq_q, inner, seed=1))
+    k = pair.act(_rt(n_kv * seq_kv, inner, seed=2))
+    vt_cpu = _rt(n_kv * inner, kp, seed=3)
+    vt_cpu[:, seq_kv:] = float("nan")  # padding must never reach the result
+    vt = pair.act(vt_cpu)
+    out_h = torch.zeros(n_img * seq_q, inner, dtype=torch.bfloat16, device="cuda")
+    out_e = torch.zeros(n_img * seq_q, inner)
+    scale = 0.125
+    pair.run("attn_spatial", (q[0], k[0], vt[0], kp, out_h, n_img, seq_q, seq_kv, heads, kv_div, scale),
+             (q[1], k[1], vt[1], kp, out_e, n_img, seq_q, seq_kv, heads, kv_div, scale))
+    got = out_h.float().cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, out_e) < 8e-3  # P is rounded to bf16 before the PV product
+
+
+def test_attn_spatial_online_softmax_rescale(pair):
+    """Force the running max to jump at a late key tile (spike one key against every query)."""
+    seq, inner = 256, 64
+    qc = _rt(seq, inner, seed=1)
+    kc = _rt(seq, inner, seed=2)
+    kc[200] = qc.mean(dim=0) * 0 + 6.0 * torch.sign(qc[0])  # large dot with many queries, in the 4th tile
+    q, k = pair.act(qc), pair.act(kc)
+    vt = pair.act(_rt(inner, seq, seed=3))
+    out_h = torch.zeros(seq, inner, dtype=torch.bfloat16, device="cuda")
+    out_e = torch.zeros(seq, inner)
+    pair.run("attn_spatial", (q[0], k[0], vt[0], seq, out_h, 1, seq, seq, 1, 1, 0.125),
+             (q[1], k[1], vt[1], seq, out_e, 1, seq, seq, 1, 1, 0.125))
+    assert rel_l2(out_h.float().cpu(), out_e) < 8e-3
+
+
+@pytest.mark.parametrize("clips,frames,hw,heads", [(1, 16, 100, 5), (2, 4, 64, 2), (1, 8, 33, 1), (1, 24, 16, 2)])
+def test_attn_temporal(pair, clips, frames, hw, heads):
+    inner = heads * 64
+    M = clips * frames * hw
+    qkv = pair.act(_rt(M, 3 * inner, seed=1))
+    out_h = torch.zeros(M, inner, dtype=torch.bfloat16, device="cuda")
+    out_e = torch.zeros(M, inner)
+    pr_h = torch.zeros(clips * hw * heads, frames, frames, device="cuda")
+    pr_e = torch.zeros(clips * hw * heads, frames, frames)
+    sl = lambda t: (t[:, :inner], t[:, inner:2 * inner], t[:, 2 * inner:])
+    pair.run("attn_temporal", (*sl(qkv[0]), out_h, clips, frames, hw, heads, 0.125, pr_h),
+             (*sl(qkv[1]), out_e, clips, frames, hw, heads, 0.125, pr_e))
+    assert rel_l2(out_h.float().cpu(), out_e) < BF16_TOL
+    assert rel_l2(pr_h.cpu(), pr_e) < 1e-4
+
+
+def test_layout_embedding_elementwise(pair):
+    x = _rt(2, 4, 3, 5, 7, seed=1)
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        tok = torch.zeros(2 * 3 * 35, 4, dtype=torch.bfloat16, device="cuda")
+        pair.hip.ncfhw_to_tokens(x.to(dt).cuda(), tok)
+        ref = torch.zeros(2 * 3 * 35, 4)
+        pair.emu.ncfhw_to_tokens(x, ref)
+        assert torch.equal(tok.float().cpu(), ref)
+        back = torch.zeros(2, 4, 3, 5, 7, dtype=dt, device="cuda")
+        pair.hip.tokens_to_ncfhw(tok, back)
+        assert torch.equal(back.float().cpu(), x)
+    ts = torch.tensor([999, 0, 519], dtype=torch.int64)
+    e_h = torch.zeros(3, 320, dtype=torch.bfloat16, device="cuda")
+    e_e = torch.zeros(3, 320)
+    pair.run("timestep_embedding", (ts.cuda(), 320, False, e_h), (ts, 320, False, e_e))
+    assert (e_h.float().cpu() - e_e).abs().max() < 1.2e-2  # bf16 rounding + fp32 sincos at |arg| <= 999
+    w = torch.tensor([7.5, 12.25])
+    g_h = torch.zeros(2, 256, dtype=torch.bfloat16, device="cuda")
+    g_e = torch.zeros(2, 256)
+    pair.run("timestep_embedding", (w.cuda(), 256, True, g_h), (w, 256, True, g_e))
+    assert (g_h.float().cpu() - g_e).abs().max() < 2e-2
+    v = _rt(1000, seed=2)
+    s_h = torch.zeros(1000, dtype=torch.bfloat16, device="cuda")
+    pair.hip.silu(v.cuda().bfloat16(), s_h)
+    assert rel_l2(s_h.float().cpu(), torch.nn.functional.silu(v)) < BF16_TOL
+    # scheduler family
+    xs, eps, noise = _rt(2, 4, 3, 5, 5, seed=3), _rt(2, 4, 3, 5, 5, seed=4), _rt(2, 4, 3, 5, 5, seed=5)
+    prev_h, den_h = torch.zeros_like(xs).cuda(), torch.zeros_like(xs).cuda()
+    prev_e, den_e = torch.zeros_like(xs), torch.zeros_like(xs)
+    args = (0.3, 0.95, 0.01, 0.99, 0.6, 0.8)
+    pair.hip.lcm_step(xs.cuda(), eps.cuda(), noise.cuda(), *args, prev_h, den_h)
+    pair.emu.lcm_step(xs, eps, noise, *args, prev_e, den_e)
+    assert rel_l2(prev_h.cpu(), prev_e) < 1e-6 and rel_l2(den_h.cpu(), den_e) < 1e-6
+    o_h, o_e = torch.zeros_like(xs).cuda(), torch.zeros_like(xs)
+    pair.hip.lincomb3(xs.cuda(), eps.cuda(), None, [0.5, 2.0], [1.5, -1.0], None, o_h)
+    pair.emu.lincomb3(xs, eps, None, [0.5, 2.0], [1.5, -1.0], None, o_e)
+    assert rel_l2(o_h.cpu(), o_e) < 1e-6
+
+
+def test_bad_arguments_return_errors(pair):
+    from t2v_turbo_amd.native import NativeError
+    a = torch.zeros(64, 48, dtype=torch.bfloat16, device="cuda")  # channels not a multiple of 64
+    w = torch.zeros(64, 48, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(64, 64, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(NativeError):
+        pair.hip.gemm(a, w, out, M=64, N=64)
+    with pytest.raises(NativeError):
+        pair.hip.attn_temporal(out, out, out, out, 1, 65, 1, 1, 0.125)
