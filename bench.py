@@ -69,7 +69,7 @@ def kernel_breakdown(engine, plan):
         fn(*args, stream)
         evs[i + 1].record()
     torch.cuda.synchronize()
-    agg = {}
+    agg, shapes = {}, {}
     for i, (fn, args, name) in enumerate(rec):
         ms = evs[i].elapsed_time(evs[i + 1])
         a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "tflop": 0.0})
@@ -78,13 +78,26 @@ def kernel_breakdown(engine, plan):
         if name == "t2v_gemm":
             d = args[0]._obj
             taps = {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(d.mode, 9)
-            a["tflop"] += 2.0 * d.M * d.N * taps * (d.c0 + d.c1) * max(d.batch, 1) / 1e12
+            tf = 2.0 * d.M * d.N * taps * (d.c0 + d.c1) * max(d.batch, 1) / 1e12
+            a["tflop"] += tf
+            sh = shapes.setdefault((d.mode, d.M, d.N, taps * (d.c0 + d.c1), max(d.batch, 1), d.act, d.c1 > 0),
+                                   {"n": 0, "ms": 0.0, "tflop": 0.0})
+            sh["n"] += 1
+            sh["ms"] += ms
+            sh["tflop"] += tf
         elif name == "t2v_attn_spatial":
             n_img, seq_q, seq_kv, heads = args[8], args[9], args[10], args[11]
             a["tflop"] += 4.0 * n_img * heads * seq_q * seq_kv * 64 / 1e12
         elif name == "t2v_attn_temporal":
             clips, frames, hw, heads = args[8], args[9], args[10], args[11]
             a["tflop"] += 4.0 * clips * hw * heads * frames * frames * 64 / 1e12
+    report = os.environ.get("T2V_SHAPE_REPORT")
+    if report:
+        rows = [{"mode": k[0], "M": k[1], "N": k[2], "K": k[3], "batch": k[4], "act": k[5], "concat": k[6], "n": v["n"],
+                 "ms": round(v["ms"], 3), "tflops": round(v["tflop"] / (v["ms"] / 1e3), 1)}
+                for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])]
+        with open(report, "w") as f:
+            json.dump(rows, f, indent=0)
     return agg
 
 

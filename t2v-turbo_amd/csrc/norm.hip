@@ -39,16 +39,15 @@ __device__ __forceinline__ const bf16_t* gn_src(const bf16_t* x0, int c0, int ld
     return c < c0 ? x0 + row * ld0 + c : x1 + row * ld1 + (c - c0);
 }
 
-// partial[unit][slab][group][2] = (sum, sumsq)
+// partial[unit][slab][group][2] = (sum, sumsq).  Deterministic: per-thread register sums -> LDS
+// [row-lane][channel] -> fixed-order reduction over row-lanes, then over the channels of a group.
 __global__ __launch_bounds__(256) void gn_stats_partial(const bf16_t* x0, int c0, int ld0, const bf16_t* x1, int c1,
                                                         int ld1, int rows_per_unit, int groups, int slab_rows, float* partial) {
-    extern __shared__ float sgrp[];  // [groups][2]
+    extern __shared__ float sred[];  // [2][ty][C] then reused as [2][C]
     const int C = c0 + c1, cpg = C / groups;
     const GnGeom g = gn_geom(C);
     const int unit = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
     const int tid = threadIdx.x;
-    for (int i = tid; i < groups * 2; i += 256) sgrp[i] = 0.f;
-    __syncthreads();
     const int cx = tid % g.tx, ry = tid / g.tx;
     const int r0 = slab * slab_rows;
     const int r1 = min(r0 + slab_rows, rows_per_unit);
@@ -57,6 +56,8 @@ __global__ __launch_bounds__(256) void gn_stats_partial(const bf16_t* x0, int c0
     for (int j = 0; j < GN_MAX_CPT; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[j][e] = 0.f; q[j][e] = 0.f; }
+    float* ssum = sred;
+    float* ssq = sred + g.ty * C;
     if (ry < g.ty) {
         for (int r = r0 + ry; r < r1; r += g.ty) {
             const long long row = (long long)unit * rows_per_unit + r;
@@ -75,41 +76,56 @@ __global__ __launch_bounds__(256) void gn_stats_partial(const bf16_t* x0, int c0
         for (int j = 0; j < GN_MAX_CPT; ++j) {
             const int ci = cx + j * g.tx;
             if (j < g.cpt && ci < g.cpr) {
-int gcur = (ci * 8) / cpg;
-                float gs = 0.f, gq = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int grp = (ci * 8 + e) / cpg;
-                    if (grp != gcur) {
-                        atomicAdd(&sgrp[gcur * 2], gs);
-                        atomicAdd(&sgrp[gcur * 2 + 1], gq);
-                        gcur = grp; gs = 0.f; gq = 0.f;
-                    }
-                    gs += s[j][e]; gq += q[j][e];
-                }
-                atomicAdd(&sgrp[gcur * 2], gs);
-                atomicAdd(&sgrp[gcur * 2 + 1], gq);
+                *(float4*)(ssum + ry * C + ci * 8) = make_float4(s[j][0], s[j][1], s[j][2], s[j][3]);
+                *(float4*)(ssum + ry * C + ci * 8 + 4) = make_float4(s[j][4], s[j][5], s[j][6], s[j][7]);
+                *(float4*)(ssq + ry * C + ci * 8) = make_float4(q[j][0], q[j][1], q[j][2], q[j][3]);
+                *(float4*)(ssq + ry * C + ci * 8 + 4) = make_float4(q[j][4], q[j][5], q[j][6], q[j][7]);
             }
         }
     }
     __syncthreads();
+    // reduce over row-lanes: thread -> channel(s); result parked in row-lane 0's slots
+    for (int c = tid; c < C; c += 256) {
+        float a = ssum[c], b = ssq[c];
+        for (int y = 1; y < g.ty; ++y) { a += ssum[y * C + c]; b += ssq[y * C + c]; }
+        ssum[c] = a; ssq[c] = b;
+    }
+    __syncthreads();
     float* out = partial + ((long long)unit * nslab + slab) * groups * 2;
-    for (int i = tid; i < groups * 2; i += 256) out[i] = sgrp[i];
+    for (int i = tid; i < groups * 2; i += 256) {
+        const int grp = i >> 1;
+        const float* src = (i & 1) ? ssq : ssum;
+        float a = 0.f;
+        for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) a += src[c];
+        out[i] = a;
+    }
 }
 
-__global__ void gn_stats_final(const float* partial, int nslab, int groups, float inv_count, float eps, float* stats) {
-    const int unit = blockIdx.x;
-    for (int grp = threadIdx.x; grp < groups; grp += blockDim.x) {
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < nslab; ++k) {
-            const float* p = partial + (((long long)unit * nslab + k) * groups + grp) * 2;
-            s += p[0]; q += p[1];
-        }
-        const double mean = s * inv_count;
-        double var = q * inv_count - mean * mean;
+// one block per unit: thread = (part, value) walks slabs part, part+parts, ... in a fixed order;
+// values = (sum, sumsq) of each group (groups*2 <= 256)
+__global__ __launch_bounds__(256) void gn_stats_final(const float* partial, int nslab, int groups, float inv_count, float eps, float* stats) {
+    __shared__ double sh[256];
+    const int unit = blockIdx.x, tid = threadIdx.x;
+    const int width = groups * 2, parts = 256 / width;
+    const int v = tid % width, part = tid / width;
+    const float* base = partial + (long long)unit * nslab * width;
+    double acc = 0.0;
+    if (part < parts)
+        for (int k = part; k < nslab; k += parts) acc += (double)base[(long long)k * width + v];
+    sh[tid] = acc;
+    __syncthreads();
+    double t = 0.0;
+    if (tid < width)
+        for (int pz = 0; pz < parts; ++pz) t += sh[pz * width + tid];
+    __syncthreads();
+    if (tid < width) sh[tid] = t;
+    __syncthreads();
+    if (tid < groups) {
+        const double mean = sh[2 * tid] * inv_count;
+        double var = sh[2 * tid + 1] * inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
-        stats[((long long)unit * groups + grp) * 2] = (float)mean;
-        stats[((long long)unit * groups + grp) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        stats[((long long)unit * groups + tid) * 2] = (float)mean;
+        stats[((long long)unit * groups + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
 
@@ -256,7 +272,7 @@ int gn_check(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, i
     T2V_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0 && ld0 % 8 == 0 && (c1 == 0 || ld1 % 8 == 0), T2V_ESHAPE,
                 "groupnorm: channels / strides must be multiples of 8");
     T2V_REQUIRE(C % groups == 0 && C / 8 <= 256 * GN_MAX_CPT, T2V_ESHAPE, "groupnorm: unsupported channel count");
-    T2V_REQUIRE(groups * 2 * 4 <= 48 * 1024, T2V_ESHAPE, "groupnorm: too many groups");
+    T2V_REQUIRE(groups * 2 <= 256, T2V_ESHAPE, "groupnorm: too many groups");
     return T2V_OK;
 }
 
@@ -280,11 +296,12 @@ extern "C" int t2v_gn_stats(const void* x0, int c0, int ld0, const void* x1, int
     hipStream_t s = (hipStream_t)stream;
     const int nslab = gn_nslab(n_units, rows_per_unit);
     const int slab_rows = gn_slab_rows(n_units, rows_per_unit);
-    hipLaunchKernelGGL(gn_stats_partial, dim3(nslab, n_units), dim3(256), groups * 2 * sizeof(float), s,
+    const GnGeom gg = gn_geom(c0 + c1);
+    hipLaunchKernelGGL(gn_stats_partial, dim3(nslab, n_units), dim3(256), (size_t)2 * gg.ty * (c0 + c1) * sizeof(float), s,
                        (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, rows_per_unit, groups, slab_rows, ws);
     T2V_CHECK_LAUNCH();
     const float inv_count = 1.0f / ((float)rows_per_unit * (float)((c0 + c1) / groups));
-    hipLaunchKernelGGL(gn_stats_final, dim3(n_units), dim3(64), 0, s, (const float*)ws, nslab, groups, inv_count, eps, stats);
+    hipLaunchKernelGGL(gn_stats_final, dim3(n_units), dim3(256), 0, s, (const float*)ws, nslab, groups, inv_count, eps, stats);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
