@@ -89,11 +89,18 @@ typedef struct t2v_gemm_desc {
     void* out;   /* bf16 (or fp32 if out_f32) [M][ldo] */
     int ldo;
     int out_f32;
+    /* scheduling hints (0 = library heuristic): workgroup tile id and split-K factor.  Split-K needs a
+     * caller workspace of >= split_k*batch*M*N*4 bytes; without one the library never splits. */
+    int tile_cfg, split_k;
+    void* ws;
+    long long ws_bytes;
 } t2v_gemm_desc;
 
 int t2v_gemm(const t2v_gemm_desc* d, void* stream);
-/* tuning/test hook: force the workgroup tile (0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 256x64) */
+/* tuning/test hooks: override tile id / split-K factor for every following call (0 = off) */
 int t2v_gemm_force_config(int cfg);
+int t2v_gemm_force_split(int splits);
+int t2v_gemm_num_configs(void);
 
 /* direct 3x3 s1 p1 conv for tiny Cin (the 4-channel latent): x bf16 [M][cin] (cin <= 8),
  * w fp32 [cout][9][cin], bias fp32 [cout], out bf16 [M][cout].

@@ -3,22 +3,26 @@
 //   out[M,N] = epilogue(alpha * gather(A)[M,K] x W[N,K]^T)
 //
 // Design (CDNA4):
-//  * 4 wavefronts (64 lanes) per workgroup, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
-//    MFMA-M = tokens (A operand = activations), MFMA-N = output channels (B operand = weights).
+//  * 4 or 8 wavefronts (64 lanes) per workgroup, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+//    The MFMA "A" operand is the weight tile (rows = output channels) and the "B" operand the
+//    activation tile (columns = tokens), so in the accumulator a lane owns ONE token and 4-channel
+//    runs of it: the epilogue (bias, time-embedding row vector, residual, SiLU, GEGLU with value and
+//    gate in the same lane) runs straight out of registers with 8/16-byte row accesses — no LDS
+//    round trip, no barrier.
 //  * K is walked in 64-element steps.  For the conv modes a K step is one 64-channel slab of one
 //    filter tap: the im2col matrix is never built, each lane aims its 16-byte LDS-DMA
 //    (global_load_lds_dwordx4) at the shifted source row, or at a zero page for padding taps.
 //    Nearest-x2 upsampling, stride 2, the (3,1,1) temporal taps and the skip-connection channel
-//    concat are all just address arithmetic in the same gather.
+//    concat are all address arithmetic in that gather (every mode is a kh x kw conv over an
+//    (n, H, W) grid; LINEAR is 1x1 over (M,1,1)).
 //  * LDS tiles are [rows][64] bf16 (128 B rows) with the 16-byte chunk index XOR-swizzled by
-//    (row>>1)&7, applied on the DMA *source* side (the LDS image of a DMA is lane-linear) and on
+//    (row>>1)&7 — applied on the DMA *source* side (the LDS image of a DMA is lane-linear) and on
 //    the ds_read_b128 fragment reads, which makes those reads bank-conflict free.
-//  * double-buffered tiles: the DMA for step k+1 is issued right after the barrier that publishes
-//    step k and overlaps its MFMAs.
-//  * epilogue: accumulators are staged through (the now free) LDS so that every global store /
-//    residual load is a full 16-byte-per-lane, 128-byte-per-row coalesced access; bias,
-//    time-embedding row vector, residual add, SiLU and GEGLU are fused here.
-//  * workgroup id -> tile mapping is XCD-aware: the 8 XCDs (private L2s) each get a contiguous
+//  * STAGES-deep ring of tiles; waits are counted (s_waitcnt vmcnt(N)) with a raw s_barrier so
+//    that STAGES-2 later tiles stay in flight across the barrier instead of being drained.
+//  * split-K (blockIdx.z) for problems with too few tiles to fill 256 CUs: fp32 partial slabs in a
+//    caller workspace, reduced (fixed order, deterministic) + epilogue by a second small kernel.
+//  * workgroup id -> tile mapping is XCD-aware: each of the 8 XCDs (private L2s) gets a contiguous
 //    run of tiles, N-tile fastest, so the tiles that share an A panel hit the same L2.
 #include "common.h"
 
@@ -26,39 +30,125 @@ struct GemmParams {
     t2v_gemm_desc d;
     const void* zero;
     int K, nk, taps, nsrc;
-    // every mode is a (kh x kw) conv over an (n, H, W) grid: LINEAR = 1x1 over (M,1,1);
-    // TCONV3 = 3x1 over (clip, frame, pixel); UP2 reads the grid through a >>1 (ups = 1)
-    int gh, gw;        // source grid
+    int gh, gw;  // source grid
     int kh, kw, stride, pad_y, pad_x, ups;
     int h_out, w_out;
     int tiles_m, tiles_n;
-    int vec_store;
+    int vec4;          // 4-channel runs may use vector accesses
+    int splits, nk_per_split;
+    float* ws;         // split-K partials [splits][M][N]
 };
 
 namespace {
-
-template <int BM, int BN>
-struct Smem {
-    static constexpr int A_BYTES = BM * 128;
-    static constexpr int B_BYTES = BN * 128;
-    static constexpr int STAGE = A_BYTES + B_BYTES;
-    static constexpr int TILE_BYTES = 2 * STAGE;
-    static constexpr int EPI_BYTES = BM * BN * 4;
-    static constexpr int BYTES = TILE_BYTES > EPI_BYTES ? TILE_BYTES : EPI_BYTES;
-};
 
 __device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
 }
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
-    static_assert(WM * WN == 4, "4 waves");
+// A&S 7.1.26 erf (|err| < 1.5e-7): exact-GELU semantics at a fraction of erff's cost
+__device__ __forceinline__ float fast_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = 1.0f / (1.0f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * __expf(-z * z);
+    const float erf_v = x < 0.f ? -erf_abs : erf_abs;
+    return 0.5f * x * (1.0f + erf_v);
+}
+
+// epilogue on a run of 4 consecutive output channels of one token row
+struct Epi {
+    const t2v_gemm_desc* d;
+    long long o_off;
+    int n_out, vec4;
+    __device__ __forceinline__ void run(float* v, const float* gate, int gm, int ch_in, int ch_out) const {
+        const t2v_gemm_desc& dd = *d;
+        if (ch_out >= n_out) return;
+        const bool full = vec4 && ch_out + 4 <= n_out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= dd.alpha;
+        if (dd.bias) {
+            if (full) {
+                const float4 b = *(const float4*)(dd.bias + ch_in);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ch_in + e < dd.N) v[e] += dd.bias[ch_in + e];
+            }
+        }
+        if (gate) {  // GEGLU: value * gelu(gate); gate columns sit 32 packed rows after the values
+            float g[4] = {gate[0] * dd.alpha, gate[1] * dd.alpha, gate[2] * dd.alpha, gate[3] * dd.alpha};
+            if (dd.bias) {
+                const float4 b = *(const float4*)(dd.bias + ch_in + 32);
+                g[0] += b.x; g[1] += b.y; g[2] += b.z; g[3] += b.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= fast_gelu(g[e]);
+        }
+        if (dd.rowvec) {
+            const float* rv = dd.rowvec + (long long)(gm / dd.rowvec_div) * dd.ld_rowvec + ch_out;
+            if (full) {
+                const float4 r = *(const float4*)rv;
+                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ch_out + e < n_out) v[e] += rv[e];
+            }
+        }
+        if (dd.residual) {
+            const bf16_t* rp = (const bf16_t*)dd.residual + o_off + (long long)gm * dd.ldr + ch_out;
+            if (full) {
+                const uint2 r = *(const uint2*)rp;
+                v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
+                v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ch_out + e < n_out) v[e] += bf2f(rp[e]);
+            }
+        }
+        if (dd.act == T2V_ACT_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+        }
+        if (dd.out_f32) {
+            float* op = (float*)dd.out + o_off + (long long)gm * dd.ldo + ch_out;
+            if (full) {
+                *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ch_out + e < n_out) op[e] = v[e];
+            }
+        } else {
+            bf16_t* op = (bf16_t*)dd.out + o_off + (long long)gm * dd.ldo + ch_out;
+            if (full) {
+                *(uint2*)op = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (ch_out + e < n_out) op[e] = f2bf(v[e]);
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
+    constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;  // DMA wave-instructions per wave per stage
-    using S = Smem<BM, BN>;
+    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;  // DMA wave-instructions per wave per stage
+    constexpr int LOADS = A_IT + B_IT;
+    constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+    static_assert(A_IT >= 1 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
+    static_assert(LOADS * (STAGES - 2) < 64, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const t2v_gemm_desc& d = p.d;
@@ -75,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---- batch offsets --------------------------------------------------------------------------
+    // ---- batch / split offsets --------------------------------------------------------------------
     const int z = blockIdx.y;
     const int z0 = z / d.batch_inner, z1 = z % d.batch_inner;
     const bf16_t* a0 = (const bf16_t*)d.a0 + z0 * d.a_stride0 + z1 * d.a_stride1;
@@ -83,16 +173,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     const bf16_t* wbase = (const bf16_t*)d.w + z0 * d.w_stride0 + z1 * d.w_stride1;
     const long long o_off = z0 * d.o_stride0 + z1 * d.o_stride1;
     const bf16_t* zero = (const bf16_t*)p.zero;
+    const int split = blockIdx.z;
+    const int kt_begin = split * p.nk_per_split;
+    const int kt_end = min(p.nk, kt_begin + p.nk_per_split);
+    const int nk = kt_end - kt_begin;
 
     // ---- per-lane DMA row bookkeeping -----------------------------------------------------------
-    // wave-instruction i (= wave + 4*j) fills tile rows [8i, 8i+8): lane -> row 8i + (lane>>3),
+    // wave-instruction i (= wave + NW*j) fills tile rows [8i, 8i+8): lane -> row 8i + (lane>>3),
     // 16-byte slot (lane&7) of that row, which holds source chunk (lane&7) ^ swz(row).
     const int H = p.gh, W = p.gw;
     int a_n[A_IT], a_y[A_IT], a_x[A_IT];  // decomposed output coordinates (a_n < 0: row >= M)
     int a_chunk[A_IT];
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
-        const int r = (wave + 4 * j) * 8 + (lane >> 3);
+        const int r = (wave + NW * j) * 8 + (lane >> 3);
         a_chunk[j] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
         const int m = m0 + r;
         if (m >= d.M) {
@@ -109,37 +203,45 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
     int winc[B_IT];
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
-        const int r = (wave + 4 * j) * 8 + (lane >> 3);
+        const int r = (wave + NW * j) * 8 + (lane >> 3);
         const int chunk = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
         const int n = n0 + r;
-        if (n < d.N) { wptr[j] = wbase + (long long)n * d.ldw + chunk; winc[j] = 64; }
+        if (n < d.N) { wptr[j] = wbase + (long long)n * d.ldw + chunk + (long long)kt_begin * 64; winc[j] = 64; }
         else { wptr[j] = zero; winc[j] = 0; }
     }
 
-    int seg = 0, seg_left = 0;  // staging iterator: segment = (tap, source)
+    // staging iterator: segment = (tap, source); starts at K step kt_begin
+    const int steps0 = d.c0 >> 6, steps1 = d.c1 >> 6, steps_tap = steps0 + steps1;
+    int seg, seg_left, seg_skip;
+    {
+        const int tap = kt_begin / steps_tap, rem = kt_begin - tap * steps_tap;
+        const int src = rem >= steps0 ? 1 : 0;
+        seg = tap * p.nsrc + src;
+        seg_skip = src ? rem - steps0 : rem;
+    }
     auto begin_segment = [&]() {
         const int tap = seg / p.nsrc, src = seg - tap * p.nsrc;
         const bf16_t* base = src ? a1 : a0;
         const int ld = src ? d.lda1 : d.lda0;
-        seg_left = (src ? d.c1 : d.c0) >> 6;
+        seg_left = (src ? steps1 : steps0) - seg_skip;
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) {
             const int uy = a_y[j] * p.stride + ky - p.pad_y, ux = a_x[j] * p.stride + kx - p.pad_x;
             const bool ok = a_n[j] >= 0 && uy >= 0 && uy < (H << p.ups) && ux >= 0 && ux < (W << p.ups);
             const long long row = ((long long)a_n[j] * H + (uy >> p.ups)) * W + (ux >> p.ups);
-            if (ok) { aptr[j] = base + row * ld + a_chunk[j]; ainc[j] = 64; }
+            if (ok) { aptr[j] = base + row * ld + a_chunk[j] + seg_skip * 64; ainc[j] = 64; }
             else { aptr[j] = zero; ainc[j] = 0; }
         }
+        seg_skip = 0;
     };
     auto stage = [&](int buf) {
-        char* sa = smem + buf * S::STAGE;
-        char* sb = sa + S::A_BYTES;
+        char* sa = smem + buf * STAGE_BYTES;
+        char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < A_IT; ++j) dma16(aptr[j], sa + (wave + 4 * j) * 1024);
+        for (int j = 0; j < A_IT; ++j) dma16(aptr[j], sa + (wave + NW * j) * 1024);
 #pragma unroll
-        for (int j = 0; j < B_IT; ++j) dma16(wptr[j], sb + (wave + 4 * j) * 1024);
-        // advance to the next K step
+        for (int j = 0; j < B_IT; ++j) dma16(wptr[j], sb + (wave + NW * j) * 1024);
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) aptr[j] += ainc[j];
 #pragma unroll
@@ -158,144 +260,169 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     begin_segment();
-    stage(0);
-    for (int kt = 0; kt < p.nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        const int buf = kt & 1;
-        if (kt + 1 < p.nk) stage(buf ^ 1);
-        const char* sa = smem + buf * S::STAGE + (wave_m * WTM + frow) * 128;
-        const char* sb = smem + buf * S::STAGE + S::A_BYTES + (wave_n * WTN + frow) * 128;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) stage(s);
+    int buf = 0, fill = (STAGES - 1) % STAGES;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed; up to STAGES-2 younger tiles may stay in flight
+        const int younger = min(STAGES - 2, nk - 1 - kt);
+        if (STAGES >= 4 && younger == 2) wait_vmcnt<LOADS * 2>();
+        else if (STAGES >= 3 && younger == 1) wait_vmcnt<LOADS>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + STAGES - 1 < nk) stage(fill);
+        const char* sa = smem + buf * STAGE_BYTES + (wave_m * WTM + frow) * 128;
+        const char* sb = smem + buf * STAGE_BYTES + A_BYTES + (wave_n * WTN + frow) * 128;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int coff = ((kk * 2 + hi) ^ swz) << 4;
-            bf16x8_t fa[TM], fb[TN];
+            bf16x8_t fa[TM], fw[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[i] = *(const bf16x8_t*)(sa + i * 32 * 128 + coff);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *(const bf16x8_t*)(sb + j * 32 * 128 + coff);
+            for (int j = 0; j < TN; ++j) fw[j] = *(const bf16x8_t*)(sb + j * 32 * 128 + coff);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
         }
+        buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+        fill = (fill + 1 == STAGES) ? 0 : fill + 1;
     }
 
-    // ---- epilogue: stage through LDS, then coalesced 16-byte rows --------------------------------
-    __syncthreads();
-    float* st = (float*)smem + wave * (WTM * WTN);
+    // ---- epilogue straight from the accumulators: lane = token (frow), regs = 4-channel runs -------
+    const int ch_lane = n0 + wave_n * WTN + 4 * hi;
+    if (p.splits > 1) {  // raw fp32 partial slab; the reduce kernel applies the epilogue
+        float* ws = p.ws + ((long long)(z * p.splits + split) * d.M) * d.N;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            const int gm = m0 + wave_m * WTM + i * 32 + frow;
+            if (gm >= d.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = ch_lane + j * 32 + 8 * g;
+                    if (ch < d.N)
+                        *(float4*)(ws + (long long)gm * d.N + ch) =
+                            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                }
+        }
+        return;
+    }
+    Epi epi;
+    epi.d = &d; epi.o_off = o_off; epi.vec4 = p.vec4;
+    if (d.act == T2V_ACT_GEGLU) {
+        epi.n_out = d.N / 2;
+        if constexpr (TN >= 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int gm = m0 + wave_m * WTM + i * 32 + frow;
+                if (gm >= d.M) continue;
+#pragma unroll
+                for (int u = 0; u < TN / 2; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4] = {acc[i][2 * u][4 * g], acc[i][2 * u][4 * g + 1], acc[i][2 * u][4 * g + 2], acc[i][2 * u][4 * g + 3]};
+                        const float gt[4] = {acc[i][2 * u + 1][4 * g], acc[i][2 * u + 1][4 * g + 1], acc[i][2 * u + 1][4 * g + 2],
+                                             acc[i][2 * u + 1][4 * g + 3]};
+                        const int ch_in = ch_lane + u * 64 + 8 * g;
+                        epi.run(v, gt, gm, ch_in, (n0 + wave_n * WTN) / 2 + u * 32 + 8 * g + 4 * hi);
+                    }
+            }
+        }
+        return;
+    }
+    epi.n_out = d.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int gm = m0 + wave_m * WTM + i * 32 + frow;
+        if (gm >= d.M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                st[row * WTN + j * 32 + frow] = acc[i][j][r];
+            for (int g = 0; g < 4; ++g) {
+                float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                const int ch = ch_lane + j * 32 + 8 * g;
+                epi.run(v, nullptr, gm, ch, ch);
             }
-    __syncthreads();
-
-    const bool geglu = d.act == T2V_ACT_GEGLU;
-    const int lpr = geglu ? 4 : WTN / 8;  // lanes per row
-    const int rpp = 64 / lpr;             // rows per pass
-    const int c8 = (lane % lpr) * 8;
-    const int gn_in = n0 + wave_n * WTN + c8;                     // column in W-row space (bias index)
-    const int gn = geglu ? (n0 + wave_n * WTN) / 2 + c8 : gn_in;  // output column
-    const int n_out = geglu ? d.N / 2 : d.N;
-    float bias[8], bias2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        bias[e] = (d.bias && gn_in + e < d.N) ? d.bias[gn_in + e] : 0.f;
-        bias2[e] = (geglu && d.bias && gn_in + 32 + e < d.N) ? d.bias[gn_in + 32 + e] : 0.f;
-    }
-    for (int row = lane / lpr; row < WTM; row += rpp) {
-        const int gm = m0 + wave_m * WTM + row;
-        if (gm >= d.M || gn >= n_out) continue;
-        float v[8];
-        const float4 lo = *(const float4*)(st + row * WTN + c8);
-        const float4 hi4 = *(const float4*)(st + row * WTN + c8 + 4);
-        v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
-        v[4] = hi4.x; v[5] = hi4.y; v[6] = hi4.z; v[7] = hi4.w;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] * d.alpha + bias[e];
-        if (geglu) {
-            if constexpr (WTN == 64) {
-                const float4 g0 = *(const float4*)(st + row * WTN + 32 + c8);
-                const float4 g1 = *(const float4*)(st + row * WTN + 32 + c8 + 4);
-                const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] * gelu_f(g[e] * d.alpha + bias2[e]);
-            }
-        }
-        if (d.rowvec) {
-            const float* rv = d.rowvec + (long long)(gm / d.rowvec_div) * d.ld_rowvec + gn;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (gn + e < n_out) v[e] += rv[e];
-        }
-        const bool full = p.vec_store && gn + 8 <= n_out;
-        if (d.residual) {
-            const bf16_t* rp = (const bf16_t*)d.residual + o_off + (long long)gm * d.ldr + gn;
-            if (full) {
-                float rf[8];
-                unpack8(*(const uint4*)rp, rf);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += rf[e];
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (gn + e < n_out) v[e] += bf2f(rp[e]);
-            }
-        }
-        if (d.act == T2V_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = silu_f(v[e]);
-        }
-        if (d.out_f32) {
-            float* op = (float*)d.out + o_off + (long long)gm * d.ldo + gn;
-            if (full) {
-                *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
-                *(float4*)(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (gn + e < n_out) op[e] = v[e];
-            }
-        } else {
-            bf16_t* op = (bf16_t*)d.out + o_off + (long long)gm * d.ldo + gn;
-            if (full) {
-                *(uint4*)op = pack8(v);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (gn + e < n_out) op[e] = f2bf(v[e]);
-            }
-        }
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+// split-K: out = epilogue(sum_s ws[s]) in a fixed order; thread = (row, 4 channels)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+    const t2v_gemm_desc& d = p.d;
+    const int nq = d.N / 4;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)d.M * nq) return;
+    const int gm = (int)(idx / nq), ch = (int)(idx % nq) * 4;
+    const int z = blockIdx.y, z0 = z / d.batch_inner, z1 = z % d.batch_inner;
+    const float* ws = p.ws + ((long long)z * p.splits * d.M + gm) * d.N + ch;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.splits; ++s) {
+        const float4 t = *(const float4*)(ws + (long long)s * d.M * d.N);
+        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+    }
+    Epi epi;
+    epi.d = &d; epi.o_off = z0 * d.o_stride0 + z1 * d.o_stride1; epi.vec4 = p.vec4; epi.n_out = d.N;
+    epi.run(v, nullptr, gm, ch, ch);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES>
 int launch(GemmParams& p, hipStream_t s) {
     p.tiles_m = (p.d.M + BM - 1) / BM;
     p.tiles_n = (p.d.N + BN - 1) / BN;
-    dim3 grid(p.tiles_m * p.tiles_n, p.d.batch, 1);
-    constexpr int smem = Smem<BM, BN>::BYTES;
+    dim3 grid(p.tiles_m * p.tiles_n, p.d.batch, p.splits);
+    constexpr int smem = STAGES * (BM + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN>), grid, dim3(256), smem, s, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(WM * WN * 64), smem, s, p);
     T2V_CHECK_LAUNCH();
+    if (p.splits > 1) {
+        const long long work = (long long)p.d.M * (p.d.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256), p.d.batch), dim3(256), 0, s, p);
+        T2V_CHECK_LAUNCH();
+    }
     return T2V_OK;
+}
+
+struct TileCfg { int bm, bn, wtn; };
+// id -> (BM, BN, per-wave N width); waves / stages: see dispatch()
+const TileCfg kCfg[] = {{0, 0, 0},      {128, 128, 64}, {128, 64, 32},  {256, 64, 64}, {128, 128, 64},
+                        {128, 64, 32},  {256, 128, 64}, {256, 128, 64}, {64, 128, 32}, {256, 64, 32},
+                        {128, 128, 64}, {128, 256, 64}};
+constexpr int kNumCfg = 11;
+
+int dispatch(int cfg, GemmParams& p, hipStream_t s) {
+    switch (cfg) {
+        case 1: return launch<128, 128, 2, 2, 2>(p, s);
+        case 2: return launch<128, 64, 2, 2, 2>(p, s);
+        case 3: return launch<256, 64, 4, 1, 2>(p, s);
+        case 4: return launch<128, 128, 2, 2, 3>(p, s);
+        case 5: return launch<128, 64, 2, 2, 3>(p, s);
+        case 6: return launch<256, 128, 4, 2, 2>(p, s);
+        case 7: return launch<256, 128, 4, 2, 3>(p, s);
+        case 8: return launch<64, 128, 1, 4, 3>(p, s);
+        case 9: return launch<256, 64, 4, 2, 3>(p, s);
+        case 10: return launch<128, 128, 2, 2, 4>(p, s);
+        case 11: return launch<128, 256, 2, 4, 3>(p, s);
+        default: return T2V_EINVAL;
+    }
 }
 
 }  // namespace
 
-// tile-shape override for tuning / tests: 0 = heuristic, 1 = 128x128, 2 = 128x64, 3 = 256x64
-static int g_force_cfg = 0;
+// tuning / test overrides: tile config id (0 = heuristic) and split-K factor (0 = heuristic)
+static int g_force_cfg = 0, g_force_split = 0;
 extern "C" int t2v_gemm_force_config(int cfg) { g_force_cfg = cfg; return T2V_OK; }
+extern "C" int t2v_gemm_force_split(int s) { g_force_split = s; return T2V_OK; }
+extern "C" int t2v_gemm_num_configs(void) { return kNumCfg; }
 
 extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     T2V_REQUIRE(dd && dd->a0 && dd->w && dd->out, T2V_EINVAL, "t2v_gemm: null pointer");
@@ -303,7 +430,7 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     p.d = *dd;
     t2v_gemm_desc& d = p.d;
     if (!d.a1) { d.c1 = 0; d.lda1 = 0; }
-    if (d.batch <= 0) { d.batch = 1; }
+    if (d.batch <= 0) d.batch = 1;
     if (d.batch_inner <= 0) d.batch_inner = 1;
     T2V_REQUIRE(d.M > 0 && d.N > 0, T2V_EINVAL, "t2v_gemm: empty problem");
     T2V_REQUIRE(d.c0 > 0 && d.c0 % 64 == 0 && d.c1 % 64 == 0, T2V_ESHAPE, "t2v_gemm: channels must be multiples of 64");
@@ -345,21 +472,43 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     p.zero = t2v_zero_page();
     T2V_REQUIRE(p.zero, T2V_EHIP, "t2v_gemm: zero page allocation failed");
     const int n_out = d.act == T2V_ACT_GEGLU ? d.N / 2 : d.N;
-    const int esz = d.out_f32 ? 4 : 2;
-    p.vec_store = (d.ldo % 8 == 0) && (n_out % 8 == 0) && ((uintptr_t)d.out % 16 == 0) && (d.o_stride0 % 8 == 0) &&
-                  (d.o_stride1 % 8 == 0) && (!d.residual || (d.ldr % 8 == 0 && (uintptr_t)d.residual % 16 == 0));
-    (void)esz;
+    const int obytes = d.out_f32 ? 16 : 8;
+    p.vec4 = (d.ldo % 4 == 0) && (n_out % 4 == 0) && ((uintptr_t)d.out % obytes == 0) && (d.o_stride0 % 4 == 0) &&
+             (d.o_stride1 % 4 == 0) && (!d.residual || (d.ldr % 4 == 0 && (uintptr_t)d.residual % 8 == 0)) &&
+             (!d.bias || (uintptr_t)d.bias % 16 == 0) && (!d.rowvec || ((uintptr_t)d.rowvec % 16 == 0 && d.ld_rowvec % 4 == 0));
+    if (d.act == T2V_ACT_GEGLU) T2V_REQUIRE(p.vec4, T2V_ESHAPE, "t2v_gemm: GEGLU needs 8-byte aligned rows");
     hipStream_t s = (hipStream_t)stream;
-    int cfg = g_force_cfg;
-    if (d.act == T2V_ACT_GEGLU) cfg = 1;
+
+    // ---- tile configuration -------------------------------------------------------------------------
+    int cfg = g_force_cfg ? g_force_cfg : d.tile_cfg;
+    if (cfg < 0 || cfg > kNumCfg) cfg = 0;
     if (cfg == 0) {
-        if (d.N % 128 == 0) cfg = 1;
-        else if (d.M >= 8192 && d.N % 64 == 0) cfg = 3;
-        else cfg = 2;
+        if (d.N % 128 == 0 || d.N >= 1024) cfg = (d.M >= 8192 && p.nk >= 8) ? 7 : 4;
+        else if (d.M >= 8192 && d.N % 64 == 0) cfg = 9;
+        else cfg = 5;
     }
-    switch (cfg) {
-        case 1: return launch<128, 128, 2, 2>(p, s);
-        case 3: return launch<256, 64, 4, 1>(p, s);
-        default: return launch<128, 64, 2, 2>(p, s);
+    if (d.act == T2V_ACT_GEGLU && kCfg[cfg].wtn < 64) cfg = 4;  // value+gate pairs need a 64-wide wave tile in N
+    // ---- split-K: only when the grid cannot fill the chip and K is deep ----------------------------------
+    int splits = g_force_split ? g_force_split : d.split_k;
+    const long long tiles = (long long)((d.M + kCfg[cfg].bm - 1) / kCfg[cfg].bm) * ((d.N + kCfg[cfg].bn - 1) / kCfg[cfg].bn) * d.batch;
+    const bool can_split = d.ws && d.act != T2V_ACT_GEGLU && d.N % 4 == 0 && p.vec4;
+    if (splits <= 0) {
+        splits = 1;
+        if (can_split && tiles < 160 && p.nk >= 16) {
+            splits = (int)((448 + tiles - 1) / tiles);
+            if (splits > p.nk / 8) splits = p.nk / 8;
+            if (splits > 16) splits = 16;
+        }
     }
+    if (!can_split) splits = 1;
+    if (splits > 1 && (long long)splits * d.batch * d.M * d.N * 4 > d.ws_bytes) {
+        splits = (int)(d.ws_bytes / ((long long)d.batch * d.M * d.N * 4));
+        if (splits < 2) splits = 1;
+    }
+    if (splits > p.nk) splits = p.nk;
+    p.nk_per_split = (p.nk + splits - 1) / splits;
+    splits = (p.nk + p.nk_per_split - 1) / p.nk_per_split;
+    p.splits = splits;
+    p.ws = (float*)d.ws;
+    return dispatch(cfg, p, s);
 }

@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("alpha", C.c_float), ("bias", C.c_void_p), ("rowvec", C.c_void_p),
         ("rowvec_div", C.c_int), ("ld_rowvec", C.c_int), ("residual", C.c_void_p), ("ldr", C.c_int),
         ("act", C.c_int), ("out", C.c_void_p), ("ldo", C.c_int), ("out_f32", C.c_int),
+        ("tile_cfg", C.c_int), ("split_k", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_longlong),
     ]
 
 
@@ -49,6 +50,8 @@ _SIGS = {
     "t2v_last_error": (C.c_char_p, []),
     "t2v_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "t2v_gemm_force_config": (C.c_int, [C.c_int]),
+    "t2v_gemm_force_split": (C.c_int, [C.c_int]),
+    "t2v_gemm_num_configs": (C.c_int, []),
     "t2v_conv3x3_small_cin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_void_p, C.c_void_p]),
     "t2v_gn_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
@@ -118,6 +121,17 @@ def _row_stride(t):
     return t.stride(0)
 
 
+def load_tune_table(path=None):
+    """(mode, M, N, K, batch) -> (tile_cfg, split_k), produced on an MI355X by tools/tune_gemm.py."""
+    import json
+    path = path or os.path.join(_PKG, "gemm_tune.json")
+    if os.environ.get("T2V_GEMM_TUNE", "1") == "0" or not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        rows = json.load(f)
+    return {(r["mode"], r["M"], r["N"], r["K"], r["batch"]): (r["cfg"], r["split"]) for r in rows}
+
+
 class HipOps:
     """Tensor-level view of the C-ABI.  Every method launches on torch's current stream; while
     ``recording`` is a list, the raw (function, args) tuples are appended to it as well so that a
@@ -126,10 +140,21 @@ class HipOps:
     act_dtype = torch.bfloat16
     is_native = True
 
+    SPLITK_WS_BYTES = 96 << 20
+
     def __init__(self):
         self.lib = load()
         self.recording = None
         self._keep = []  # objects that must outlive recorded calls (descs, host arrays)
+        self._ws = {}
+        self.tune = load_tune_table()
+
+    def workspace(self, device):
+        """split-K partial-sum workspace shared by all GEMM launches of this backend (one stream)."""
+        key = (device.type, device.index)
+        if key not in self._ws:
+            self._ws[key] = torch.empty(self.SPLITK_WS_BYTES, dtype=torch.uint8, device=device)
+        return self._ws[key]
 
     # -- plumbing ------------------------------------------------------------------------------
     @staticmethod
@@ -157,7 +182,7 @@ class HipOps:
     # -- ops ----------------------------------------------------------------------------------------
     def gemm(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
              rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
-             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0)):
+             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0):
         d = GemmDesc()
         d.a0, d.c0, d.lda0 = _p(a0), a0.shape[1], _row_stride(a0)
         if a1 is not None:
@@ -178,6 +203,11 @@ class HipOps:
         d.act = act
         d.out, d.ldo = _p(out), _row_stride(out)
         d.out_f32 = 1 if out.dtype == torch.float32 else 0
+        taps = {GEMM_LINEAR: 1, GEMM_TCONV3: 3}.get(mode, 9)
+        tuned = self.tune.get((mode, M, N, taps * (d.c0 + d.c1), batch)) if (tile_cfg == 0 and split_k == 0) else None
+        d.tile_cfg, d.split_k = tuned if tuned else (tile_cfg, split_k)
+        ws = self.workspace(a0.device)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         self._call("t2v_gemm", C.byref(d), keep=d)
 
     def conv_small(self, x, n_img, h, w, wgt, bias, out):

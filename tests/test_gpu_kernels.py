@@ -44,7 +44,7 @@ def pair():
 
 
 def _gemm_case(pair, *, M, N, c0, c1=0, mode=0, n_img=0, h=0, w=0, frames=0, bias=True, rowvec_div=0, residual=False,
-               act=0, alpha=1.0, out_f32=False, cfg=0, rows=None, seed=0):
+               act=0, alpha=1.0, out_f32=False, cfg=0, rows=None, seed=0, split=0):
     from t2v_turbo_amd import native as nt
     taps = {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(mode, 9)
     K = taps * (c0 + c1)
@@ -61,10 +61,12 @@ def _gemm_case(pair, *, M, N, c0, c1=0, mode=0, n_img=0, h=0, w=0, frames=0, bia
     out_e = torch.zeros(M, n_out)
     kw = dict(M=M, N=N, mode=mode, n_img=n_img, h=h, wd=w, frames=frames, rowvec_div=rowvec_div, act=act, alpha=alpha)
     pair.hip.lib.t2v_gemm_force_config(cfg)
+    pair.hip.lib.t2v_gemm_force_split(split)
     try:
         pair.hip.gemm(a0[0], wt[0], out_h, a1=a1[0], bias=b[0], rowvec=rv[0], residual=res[0], **kw)
     finally:
         pair.hip.lib.t2v_gemm_force_config(0)
+        pair.hip.lib.t2v_gemm_force_split(0)
     pair.emu.gemm(a0[1], wt[1], out_e, a1=a1[1], bias=b[1], rowvec=rv[1], residual=res[1], **kw)
     torch.cuda.synchronize()
     got = out_h.float().cpu()
@@ -72,7 +74,7 @@ def _gemm_case(pair, *, M, N, c0, c1=0, mode=0, n_img=0, h=0, w=0, frames=0, bia
     return rel_l2(got, out_e)
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("cfg", list(range(1, 12)))
 def test_gemm_linear_tiles_and_masking(pair, cfg):
     assert _gemm_case(pair, M=300, N=320, c0=320, residual=True, cfg=cfg) < BF16_TOL
     assert _gemm_case(pair, M=1024, N=192, c0=128, c1=64, cfg=cfg, seed=3) < BF16_TOL  # virtual concat
@@ -89,7 +91,7 @@ def test_gemm_epilogues(pair):
     assert _gemm_case(pair, M=2, N=1280, c0=320, act=nt.ACT_SILU, seed=9) < BF16_TOL  # M = batch rows
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3])
+@pytest.mark.parametrize("cfg", list(range(1, 12)))
 def test_gemm_conv_modes(pair, cfg):
     from t2v_turbo_amd import native as nt
     n, h, w = 3, 10, 12
@@ -114,6 +116,24 @@ def test_gemm_long_k_and_full_size_shapes(pair):
     assert _gemm_case(pair, M=16 * 40 * 64, N=320, c0=320, mode=nt.GEMM_CONV3X3, n_img=16, h=40, w=64,
                       rowvec_div=16 * 40 * 64, seed=2) < BF16_TOL
     assert _gemm_case(pair, M=40960, N=2560, c0=320, act=nt.ACT_GEGLU, seed=3) < BF16_TOL
+
+
+@pytest.mark.parametrize("split", [2, 3, 5])
+def test_gemm_split_k(pair, split):
+    from t2v_turbo_amd import native as nt
+    # deep-K conv on few tokens (the 5x8 level), concat + temporal + batch-free linear, each split over K
+    assert _gemm_case(pair, M=2 * 5 * 8, N=256, c0=256, mode=nt.GEMM_CONV3X3, n_img=2, h=5, w=8, residual=True,
+                      rowvec_div=40, split=split) < BF16_TOL
+    assert _gemm_case(pair, M=2 * 5 * 8, N=128, c0=128, c1=192, mode=nt.GEMM_CONV3X3, n_img=2, h=5, w=8, split=split, seed=1) < BF16_TOL
+    assert _gemm_case(pair, M=2 * 4 * 6, N=128, c0=320, mode=nt.GEMM_TCONV3, n_img=8, h=2, w=3, frames=4, rows=48,
+                      split=split, seed=2) < BF16_TOL
+    assert _gemm_case(pair, M=100, N=64, c0=1280, act=nt.ACT_SILU, out_f32=True, split=split, seed=3) < 2e-3
+
+
+def test_gemm_geglu_all_tiles(pair):
+    from t2v_turbo_amd import native as nt
+    for cfg in range(1, 12):
+        assert _gemm_case(pair, M=300, N=256, c0=128, act=nt.ACT_GEGLU, cfg=cfg, seed=cfg) < BF16_TOL
 
 
 def test_gemm_batched_two_level_strides(pair):

@@ -1,0 +1,111 @@
+#!/usr/bin/env python
+"""Tune tile config / split-K per GEMM shape on a real MI355X.
+
+Records the launch plans of the full-size UNet forward (B=1, 16x40x64) and of the 16-frame VAE
+decode, de-duplicates the t2v_gemm descriptors by (mode, M, N, K, batch) and times every legal
+(tile_cfg, split_k) candidate on the *recorded* descriptors (real operands, real epilogues).
+Writes t2v-turbo_amd/gemm_tune.json, which native.HipOps loads at start-up.
+
+    python tools/tune_gemm.py [--vae 1] [--out t2v-turbo_amd/gemm_tune.json]
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def time_desc(lib, fn, args, stream, cfg, split, iters=8):
+    lib.t2v_gemm_force_config(cfg)
+    lib.t2v_gemm_force_split(split)
+    try:
+        for _ in range(2):
+            if fn(*args, stream) != 0:
+                return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn(*args, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / iters
+    finally:
+        lib.t2v_gemm_force_config(0)
+        lib.t2v_gemm_force_split(0)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--vae", type=int, default=1)
+    ap.add_argument("--out", default=os.path.join(ROOT, "t2v-turbo_amd", "gemm_tune.json"))
+    args = ap.parse_args()
+    os.environ["T2V_GEMM_TUNE"] = "0"  # record with the library heuristics
+    import bench
+    from t2v_turbo_amd import native as nt
+
+    dev = torch.device("cuda", 0)
+    model = bench.build_model(dev, torch.bfloat16)
+    x, ctx, tc = bench.synth_inputs(dev, torch.bfloat16)
+    with torch.no_grad():
+        model(x, torch.tensor([999], device=dev), context=ctx, fps=16, timestep_cond=tc)
+    eng = model.native_engine()
+    recs = [next(iter(eng.plans.values()))["rec"]]
+    if args.vae:
+        from t2v_turbo_amd.vae import AutoencoderKL
+        dd = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                  num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+        with torch.device(dev):
+            ae = AutoencoderKL(ddconfig=dd, embed_dim=4)
+        ae = ae.to(torch.bfloat16).eval()
+        with torch.no_grad():
+            ae.decode_video(torch.randn(1, 4, 16, 40, 64, device=dev, dtype=torch.bfloat16))
+        recs.append(next(iter(ae.native_engine().plans.values()))["rec"])
+    lib = nt.load()
+    ncfg = lib.t2v_gemm_num_configs()
+    stream = torch.cuda.current_stream().cuda_stream
+    seen, rows = {}, []
+    for rec in recs:
+        for fn, a, name in rec:
+            if name != "t2v_gemm":
+                continue
+            d = a[0]._obj
+            taps = {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(d.mode, 9)
+            K = taps * (d.c0 + d.c1)
+            key = (d.mode, d.M, d.N, K, max(d.batch, 1))
+            if key in seen:
+                seen[key] += 1
+                continue
+            seen[key] = 1
+            base = time_desc(lib, fn, a, stream, 0, 0)
+            best = (base, 0, 0)
+            nk = K // 64
+            splits = [1] + [s for s in (2, 3, 4, 6, 8, 12, 16) if nk // s >= 4 and d.act != nt.ACT_GEGLU and d.N % 4 == 0
+                            and d.M * d.N * 4 * s * max(d.batch, 1) <= d.ws_bytes and d.M <= 4096]
+            for cfg in range(1, ncfg + 1):
+                for sp in splits:
+                    t = time_desc(lib, fn, a, stream, cfg, sp)
+                    if t is not None and t < best[0]:
+                        best = (t, cfg, sp)
+            flops = 2.0 * d.M * d.N * K * max(d.batch, 1)
+            rows.append({"mode": d.mode, "M": d.M, "N": d.N, "K": K, "batch": max(d.batch, 1), "cfg": best[1],
+                         "split": best[2], "us": round(best[0], 2), "us_heuristic": round(base, 2),
+                         "tflops": round(flops / best[0] / 1e6, 1), "act": d.act, "key": list(key)})
+            print(rows[-1], flush=True)
+    for r in rows:
+        r["count"] = seen[tuple(r["key"])]
+        del r["key"]
+    tot_h = sum(r["us_heuristic"] * r["count"] for r in rows) / 1e3
+    tot_b = sum(r["us"] * r["count"] for r in rows) / 1e3
+    print(f"GEMM time per UNet step + VAE decode: heuristic {tot_h:.2f} ms -> tuned {tot_b:.2f} ms")
+    with open(args.out, "w") as f:
+        json.dump([r for r in rows if r["cfg"]], f, indent=0)
+    print("wrote", args.out)
+
+
+if __name__ == "__main__":
+    main()
