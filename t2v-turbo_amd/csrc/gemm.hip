@@ -37,6 +37,7 @@ struct GemmParams {
     int vec4;          // 4-channel runs may use vector accesses
     int splits, nk_per_split;
     float* ws;         // split-K partials [splits][M][N]
+    int debug;         // ablation bits (tools only): 1 = skip DMA in the main loop, 2 = skip MFMA, 4 = skip epilogue
 };
 
 namespace {
@@ -60,79 +61,92 @@ __device__ __forceinline__ float fast_gelu(float x) {
     return 0.5f * x * (1.0f + erf_v);
 }
 
-// epilogue on a run of 4 consecutive output channels of one token row
+// epilogue on a run of 16 consecutive output channels of one token row (one lane's share of a
+// 32x32 accumulator tile)
 struct Epi {
     const t2v_gemm_desc* d;
     long long o_off;
-    int n_out, vec4;
+    int n_out, vec;
     __device__ __forceinline__ void run(float* v, const float* gate, int gm, int ch_in, int ch_out) const {
         const t2v_gemm_desc& dd = *d;
         if (ch_out >= n_out) return;
-        const bool full = vec4 && ch_out + 4 <= n_out;
+        const bool full = vec && ch_out + 16 <= n_out;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= dd.alpha;
+        for (int e = 0; e < 16; ++e) v[e] *= dd.alpha;
         if (dd.bias) {
             if (full) {
-                const float4 b = *(const float4*)(dd.bias + ch_in);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 b = *(const float4*)(dd.bias + ch_in + 4 * q);
+                    v[4 * q] += b.x; v[4 * q + 1] += b.y; v[4 * q + 2] += b.z; v[4 * q + 3] += b.w;
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 16; ++e)
                     if (ch_in + e < dd.N) v[e] += dd.bias[ch_in + e];
             }
         }
         if (gate) {  // GEGLU: value * gelu(gate); gate columns sit 32 packed rows after the values
-            float g[4] = {gate[0] * dd.alpha, gate[1] * dd.alpha, gate[2] * dd.alpha, gate[3] * dd.alpha};
-            if (dd.bias) {
-                const float4 b = *(const float4*)(dd.bias + ch_in + 32);
-                g[0] += b.x; g[1] += b.y; g[2] += b.z; g[3] += b.w;
-            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= fast_gelu(g[e]);
+            for (int q = 0; q < 4; ++q) {
+                float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (dd.bias) b = *(const float4*)(dd.bias + ch_in + 32 + 4 * q);
+                v[4 * q] *= fast_gelu(gate[4 * q] * dd.alpha + b.x);
+                v[4 * q + 1] *= fast_gelu(gate[4 * q + 1] * dd.alpha + b.y);
+                v[4 * q + 2] *= fast_gelu(gate[4 * q + 2] * dd.alpha + b.z);
+                v[4 * q + 3] *= fast_gelu(gate[4 * q + 3] * dd.alpha + b.w);
+            }
         }
         if (dd.rowvec) {
             const float* rv = dd.rowvec + (long long)(gm / dd.rowvec_div) * dd.ld_rowvec + ch_out;
             if (full) {
-                const float4 r = *(const float4*)rv;
-                v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 r = *(const float4*)(rv + 4 * q);
+                    v[4 * q] += r.x; v[4 * q + 1] += r.y; v[4 * q + 2] += r.z; v[4 * q + 3] += r.w;
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 16; ++e)
                     if (ch_out + e < n_out) v[e] += rv[e];
             }
         }
         if (dd.residual) {
             const bf16_t* rp = (const bf16_t*)dd.residual + o_off + (long long)gm * dd.ldr + ch_out;
             if (full) {
-                const uint2 r = *(const uint2*)rp;
-                v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xffff0000u);
-                v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xffff0000u);
+                float rf[16];
+                unpack8(*(const uint4*)rp, rf);
+                unpack8(*(const uint4*)(rp + 8), rf + 8);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] += rf[e];
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 16; ++e)
                     if (ch_out + e < n_out) v[e] += bf2f(rp[e]);
             }
         }
         if (dd.act == T2V_ACT_SILU) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+            for (int e = 0; e < 16; ++e) v[e] = silu_f(v[e]);
         }
         if (dd.out_f32) {
             float* op = (float*)dd.out + o_off + (long long)gm * dd.ldo + ch_out;
             if (full) {
-                *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(float4*)(op + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 16; ++e)
                     if (ch_out + e < n_out) op[e] = v[e];
             }
         } else {
             bf16_t* op = (bf16_t*)dd.out + o_off + (long long)gm * dd.ldo + ch_out;
             if (full) {
-                *(uint2*)op = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                *(uint4*)op = pack8(v);
+                *(uint4*)(op + 8) = pack8(v + 8);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 16; ++e)
                     if (ch_out + e < n_out) op[e] = f2bf(v[e]);
             }
         }
@@ -152,7 +166,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const t2v_gemm_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform -> scalar LDS/M0 math
     const int wave_m = wave / WN, wave_n = wave % WN;
 
     // ---- XCD-aware tile assignment (bijective form) -------------------------------------------
@@ -205,7 +220,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     for (int j = 0; j < B_IT; ++j) {
         const int r = (wave + NW * j) * 8 + (lane >> 3);
         const int chunk = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
-        const int n = n0 + r;
+        // LDS row r of the weight tile holds channel perm(r): within each 32-row MFMA tile the rows a
+        // lane's 16 accumulator registers cover ((q&3) + 8*(q>>2) + 4*hi) are fed 16 CONSECUTIVE
+        // channels (16*hi + q), so the epilogue moves 32-byte runs per lane, 64 bytes per row
+        const int r32 = r & 31;
+        const int n = n0 + (r & ~31) + ((((r32 >> 2) & 1) << 4) | ((r32 >> 3) << 2) | (r32 & 3));
         if (n < d.N) { wptr[j] = wbase + (long long)n * d.ldw + chunk + (long long)kt_begin * 64; winc[j] = 64; }
         else { wptr[j] = zero; winc[j] = 0; }
     }
@@ -272,29 +291,42 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (kt + STAGES - 1 < nk) stage(fill);
         const char* sa = smem + buf * STAGE_BYTES + (wave_m * WTM + frow) * 128;
         const char* sb = smem + buf * STAGE_BYTES + A_BYTES + (wave_n * WTN + frow) * 128;
+        // fragments are double-buffered in registers: the ds_read_b128s of K-slice kk+1 are issued
+        // before the MFMAs of slice kk, and slice 0's reads before the DMA issue of the next tile
+        bf16x8_t fa[2][TM], fw[2][TN];
+        {
+            const int coff = (hi ^ swz) << 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[0][i] = *(const bf16x8_t*)(sa + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fw[0][j] = *(const bf16x8_t*)(sb + j * 32 * 128 + coff);
+        }
+        if (kt + STAGES - 1 < nk && !(p.debug & 1)) stage(fill);
+        if (!(p.debug & 2))
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const int coff = ((kk * 2 + hi) ^ swz) << 4;
-            bf16x8_t fa[TM], fw[TN];
+            if (kk < 3) {
+                const int coff = (((kk + 1) * 2 + hi) ^ swz) << 4;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *(const bf16x8_t*)(sa + i * 32 * 128 + coff);
+                for (int i = 0; i < TM; ++i) fa[(kk + 1) & 1][i] = *(const bf16x8_t*)(sa + i * 32 * 128 + coff);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fw[j] = *(const bf16x8_t*)(sb + j * 32 * 128 + coff);
+                for (int j = 0; j < TN; ++j) fw[(kk + 1) & 1][j] = *(const bf16x8_t*)(sb + j * 32 * 128 + coff);
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
         }
         buf = (buf + 1 == STAGES) ? 0 : buf + 1;
         fill = (fill + 1 == STAGES) ? 0 : fill + 1;
     }
 
     // ---- epilogue straight from the accumulators: lane = token (frow), regs = 4-channel runs -------
-    const int ch_lane = n0 + wave_n * WTN + 4 * hi;
+    if ((p.debug & 4) && acc[0][0][0] != 12345.678f) return;
+    const int ch_lane = n0 + wave_n * WTN + 16 * hi;
     if (p.splits > 1) {  // raw fp32 partial slab; the reduce kernel applies the epilogue
         float* ws = p.ws + ((long long)(z * p.splits + split) * d.M) * d.N;
 #pragma unroll
@@ -304,17 +336,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ch = ch_lane + j * 32 + 8 * g;
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = ch_lane + j * 32 + 4 * q;
                     if (ch < d.N)
                         *(float4*)(ws + (long long)gm * d.N + ch) =
-                            make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
                 }
         }
         return;
     }
     Epi epi;
-    epi.d = &d; epi.o_off = o_off; epi.vec4 = p.vec4;
+    epi.d = &d; epi.o_off = o_off; epi.vec = p.vec4;
     if (d.act == T2V_ACT_GEGLU) {
         epi.n_out = d.N / 2;
         if constexpr (TN >= 2) {
@@ -323,15 +355,12 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
                 const int gm = m0 + wave_m * WTM + i * 32 + frow;
                 if (gm >= d.M) continue;
 #pragma unroll
-                for (int u = 0; u < TN / 2; ++u)
+                for (int u = 0; u < TN / 2; ++u) {
+                    float v[16], gt[16];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float v[4] = {acc[i][2 * u][4 * g], acc[i][2 * u][4 * g + 1], acc[i][2 * u][4 * g + 2], acc[i][2 * u][4 * g + 3]};
-                        const float gt[4] = {acc[i][2 * u + 1][4 * g], acc[i][2 * u + 1][4 * g + 1], acc[i][2 * u + 1][4 * g + 2],
-                                             acc[i][2 * u + 1][4 * g + 3]};
-                        const int ch_in = ch_lane + u * 64 + 8 * g;
-                        epi.run(v, gt, gm, ch_in, (n0 + wave_n * WTN) / 2 + u * 32 + 8 * g + 4 * hi);
-                    }
+                    for (int e = 0; e < 16; ++e) { v[e] = acc[i][2 * u][e]; gt[e] = acc[i][2 * u + 1][e]; }
+                    epi.run(v, gt, gm, ch_lane + u * 64, (n0 + wave_n * WTN) / 2 + u * 32 + 16 * hi);
+                }
             }
         }
         return;
@@ -342,32 +371,38 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         const int gm = m0 + wave_m * WTM + i * 32 + frow;
         if (gm >= d.M) continue;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+            float v[16];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                const int ch = ch_lane + j * 32 + 8 * g;
-                epi.run(v, nullptr, gm, ch, ch);
-            }
+            for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
+            epi.run(v, nullptr, gm, ch_lane + j * 32, ch_lane + j * 32);
+        }
     }
 }
 
-// split-K: out = epilogue(sum_s ws[s]) in a fixed order; thread = (row, 4 channels)
+// split-K: out = epilogue(sum_s ws[s]) in a fixed order; thread = (row, 16 channels)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
     const t2v_gemm_desc& d = p.d;
-    const int nq = d.N / 4;
+    const int nq = (d.N + 15) / 16;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (long long)d.M * nq) return;
-    const int gm = (int)(idx / nq), ch = (int)(idx % nq) * 4;
+    const int gm = (int)(idx / nq), ch = (int)(idx % nq) * 16;
     const int z = blockIdx.y, z0 = z / d.batch_inner, z1 = z % d.batch_inner;
     const float* ws = p.ws + ((long long)z * p.splits * d.M + gm) * d.N + ch;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    float v[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] = 0.f;
     for (int s = 0; s < p.splits; ++s) {
-        const float4 t = *(const float4*)(ws + (long long)s * d.M * d.N);
-        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (ch + 4 * q < d.N) {
+                const float4 t = *(const float4*)(ws + (long long)s * d.M * d.N + 4 * q);
+                v[4 * q] += t.x; v[4 * q + 1] += t.y; v[4 * q + 2] += t.z; v[4 * q + 3] += t.w;
+            }
+        }
     }
     Epi epi;
-    epi.d = &d; epi.o_off = z0 * d.o_stride0 + z1 * d.o_stride1; epi.vec4 = p.vec4; epi.n_out = d.N;
+    epi.d = &d; epi.o_off = z0 * d.o_stride0 + z1 * d.o_stride1; epi.vec = p.vec4; epi.n_out = d.N;
     epi.run(v, nullptr, gm, ch, ch);
 }
 
@@ -385,7 +420,7 @@ int launch(GemmParams& p, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(WM * WN * 64), smem, s, p);
     T2V_CHECK_LAUNCH();
     if (p.splits > 1) {
-        const long long work = (long long)p.d.M * (p.d.N / 4);
+        const long long work = (long long)p.d.M * ((p.d.N + 15) / 16);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((work + 255) / 256), p.d.batch), dim3(256), 0, s, p);
         T2V_CHECK_LAUNCH();
     }
@@ -419,7 +454,8 @@ int dispatch(int cfg, GemmParams& p, hipStream_t s) {
 }  // namespace
 
 // tuning / test overrides: tile config id (0 = heuristic) and split-K factor (0 = heuristic)
-static int g_force_cfg = 0, g_force_split = 0;
+static int g_force_cfg = 0, g_force_split = 0, g_debug = 0;
+extern "C" int t2v_gemm_debug(int bits) { g_debug = bits; return T2V_OK; }
 extern "C" int t2v_gemm_force_config(int cfg) { g_force_cfg = cfg; return T2V_OK; }
 extern "C" int t2v_gemm_force_split(int s) { g_force_split = s; return T2V_OK; }
 extern "C" int t2v_gemm_num_configs(void) { return kNumCfg; }
@@ -472,9 +508,8 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     p.zero = t2v_zero_page();
     T2V_REQUIRE(p.zero, T2V_EHIP, "t2v_gemm: zero page allocation failed");
     const int n_out = d.act == T2V_ACT_GEGLU ? d.N / 2 : d.N;
-    const int obytes = d.out_f32 ? 16 : 8;
-    p.vec4 = (d.ldo % 4 == 0) && (n_out % 4 == 0) && ((uintptr_t)d.out % obytes == 0) && (d.o_stride0 % 4 == 0) &&
-             (d.o_stride1 % 4 == 0) && (!d.residual || (d.ldr % 4 == 0 && (uintptr_t)d.residual % 8 == 0)) &&
+    p.vec4 = (d.ldo % 8 == 0) && (n_out % 4 == 0) && ((uintptr_t)d.out % 16 == 0) && (d.o_stride0 % 8 == 0) &&
+             (d.o_stride1 % 8 == 0) && (!d.residual || (d.ldr % 8 == 0 && (uintptr_t)d.residual % 16 == 0)) &&
              (!d.bias || (uintptr_t)d.bias % 16 == 0) && (!d.rowvec || ((uintptr_t)d.rowvec % 16 == 0 && d.ld_rowvec % 4 == 0));
     if (d.act == T2V_ACT_GEGLU) T2V_REQUIRE(p.vec4, T2V_ESHAPE, "t2v_gemm: GEGLU needs 8-byte aligned rows");
     hipStream_t s = (hipStream_t)stream;
@@ -510,5 +545,6 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     splits = (p.nk + p.nk_per_split - 1) / p.nk_per_split;
     p.splits = splits;
     p.ws = (float*)d.ws;
+    p.debug = g_debug;
     return dispatch(cfg, p, s);
 }

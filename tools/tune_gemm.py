@@ -68,7 +68,7 @@ def main():
     lib = nt.load()
     ncfg = lib.t2v_gemm_num_configs()
     stream = torch.cuda.current_stream().cuda_stream
-    seen, rows = {}, []
+    seen, rows, all_rows = {}, [], []
     for rec in recs:
         for fn, a, name in rec:
             if name != "t2v_gemm":
@@ -86,11 +86,14 @@ def main():
             nk = K // 64
             splits = [1] + [s for s in (2, 3, 4, 6, 8, 12, 16) if nk // s >= 4 and d.act != nt.ACT_GEGLU and d.N % 4 == 0
                             and d.M * d.N * 4 * s * max(d.batch, 1) <= d.ws_bytes and d.M <= 4096]
+            allt = {}
             for cfg in range(1, ncfg + 1):
                 for sp in splits:
                     t = time_desc(lib, fn, a, stream, cfg, sp)
+                    allt[f"{cfg}/{sp}"] = None if t is None else round(t, 1)
                     if t is not None and t < best[0]:
                         best = (t, cfg, sp)
+            all_rows.append({"key": list(key), "act": d.act, "times": allt})
             flops = 2.0 * d.M * d.N * K * max(d.batch, 1)
             rows.append({"mode": d.mode, "M": d.M, "N": d.N, "K": K, "batch": max(d.batch, 1), "cfg": best[1],
                          "split": best[2], "us": round(best[0], 2), "us_heuristic": round(base, 2),
@@ -105,6 +108,9 @@ def main():
     with open(args.out, "w") as f:
         json.dump([r for r in rows if r["cfg"]], f, indent=0)
     print("wrote", args.out)
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        with open(os.path.join(ROOT, "gpurun_out", "tune_all.json"), "w") as f:
+            json.dump(all_rows, f)
 
 
 if __name__ == "__main__":
