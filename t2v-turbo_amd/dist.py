@@ -1,0 +1,80 @@
+"""Data-parallel plumbing for the distillation step: one process per GPU, full model replica,
+ONE all-reduce(mean) of the trainable (LoRA) gradients per optimizer step over a flat contiguous
+buffer (1150 tensors / 468.6 MB fp32 in v1), plus a 3-float all-gather for the
+logged losses (C3).  ``backend="nccl"`` is RCCL on ROCm (xGMI); tests run the same code on gloo.
+
+The reference gets this from accelerate -> DDP's 25 MB buckets; here the grads live in one buffer so
+the collective is a single large message (the xGMI mesh is per-link bound: fewer, larger transfers)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 or dist.is_initialized():
+        return
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        kw["device_id"] = torch.device("cuda", local)
+    dist.init_process_group(backend, **kw)
+
+
+class FlatGradSync:
+    """Views every trainable parameter's ``.grad`` into one flat buffer and averages it across ranks
+    with a single all-reduce.  ``grad`` tensors stay views of the buffer, so optimisers see the
+    averaged values without copies."""
+
+    def __init__(self, params, dtype=torch.float32):
+        self.params = [p for p in params if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        n = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(n, dtype=dtype, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.numel = n
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, async_op=False):
+        if not dist.is_initialized() or dist.get_world_size() == 1:
+            return None
+        self.flat.div_(dist.get_world_size())
+        return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+
+    def clip_grad_norm_(self, max_norm):
+        """Global L2 clip on the (already averaged) flat buffer (accelerator.clip_grad_norm_)."""
+        norm = self.flat.norm(2)
+        scale = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
+        self.flat.mul_(scale)
+        return norm
+
+
+def broadcast_parameters(module, src=0):
+    """Rank-0 weights to everyone (what the DDP constructor does, C1)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+def gather_scalars(*values):
+    """All-gather a few 0-d losses in one message (C3) -> tensor [world, len(values)]."""
+    v = torch.stack([torch.as_tensor(x, dtype=torch.float32).detach().reshape(()) for x in values])
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return v[None]
+    dev = values[0].device if isinstance(values[0], torch.Tensor) else "cpu"
+    v = v.to(dev)
+    out = [torch.empty_like(v) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, v)
+    return torch.stack(out)

@@ -271,18 +271,19 @@ class UNetEngine(_Engine):
     def __call__(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None):
         m = self.model
         assert x.dim() == 5 and context is not None
-        if m.training:
-            for mod in m.modules():
-                if isinstance(mod, nn.Dropout) and mod.p > 0:
-                    raise RuntimeError("native UNet path is inference-only (dropout active): call .eval() first")
         self._check_weights(m)
         fps_is_int = isinstance(fps, int)
         key = (tuple(x.shape), x.dtype, tuple(context.shape), context.dtype, fps_is_int,
                None if timestep_cond is None else (tuple(timestep_cond.shape), timestep_cond.dtype),
                None if motion_cond is None else (tuple(motion_cond.shape), motion_cond.dtype), x.device)
         plan = self.plans.get(key)
-        if plan is None:
+        if plan is None or plan["training"] != m.training:
+            for mod in m.modules():  # train-mode dropout (TemporalConvBlock p=0.1, LoRA p=0.1) has no native kernel
+                if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training:
+                    raise RuntimeError("native UNet path is inference-only but a Dropout(p>0) is in training mode: "
+                                       "call .eval() on the model (after any LoRA injection) first")
             plan = self._record(x, timesteps, context, fps, timestep_cond, motion_cond)
+            plan["training"] = m.training
             self.plans[key] = plan
         else:
             st = plan["static"]

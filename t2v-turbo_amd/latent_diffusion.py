@@ -1,0 +1,58 @@
+"""The slice of ``LatentDiffusion`` (reference ``lvdm/models/ddpm3d.py``) the t2v-turbo entry points
+touch: ``.model.diffusion_model`` (the UNet), ``.first_stage_model`` (KL-VAE), ``.cond_stage_model``
+(text encoder, optional/out of scope), ``scale_factor``, ``temporal_length`` and the
+``decode_first_stage_2DAE`` / ``encode_first_stage_2DAE`` helpers.  State-dict keys keep the
+checkpoint prefixes (``model.diffusion_model.*``, ``first_stage_model.*``) so VideoCrafter2's
+``model.ckpt["state_dict"]`` loads with ``strict=False`` for the text tower."""
+import torch
+import torch.nn as nn
+
+from .unet3d import UNetModel
+from .vae import AutoencoderKL
+
+
+class DiffusionWrapper(nn.Module):
+    def __init__(self, diffusion_model):
+        super().__init__()
+        self.diffusion_model = diffusion_model
+
+
+class LatentDiffusion(nn.Module):
+    def __init__(self, unet_config, first_stage_config, cond_stage_model=None, scale_factor=0.18215,
+                 linear_start=0.00085, linear_end=0.012, timesteps=1000, channels=4, image_size=(40, 64), **ignored):
+        super().__init__()
+        unet = unet_config if isinstance(unet_config, nn.Module) else UNetModel(**unet_config["params"])
+        vae = first_stage_config if isinstance(first_stage_config, nn.Module) else AutoencoderKL(**first_stage_config["params"])
+        self.model = DiffusionWrapper(unet)
+        self.first_stage_model = vae
+        self.cond_stage_model = cond_stage_model
+        self.scale_factor = scale_factor
+        self.channels = channels
+        self.image_size = image_size
+        self.temporal_length = getattr(unet, "temporal_length", 16) if hasattr(unet, "temporal_length") else 16
+        self.linear_start, self.linear_end, self.num_timesteps = linear_start, linear_end, timesteps
+        self.encoder_type = "2d"
+
+    @classmethod
+    def from_config(cls, config, cond_stage_model=None):
+        """config: the ``model`` dict of configs/inference_t2v_512_v2.0.yaml (target/params layout)."""
+        p = config["params"]
+        keys = ("scale_factor", "linear_start", "linear_end", "timesteps", "channels", "image_size")
+        return cls(p["unet_config"], p["first_stage_config"], cond_stage_model, **{k: p[k] for k in keys if k in p})
+
+    @torch.no_grad()
+    def decode_first_stage_2DAE(self, z, **kwargs):
+        """(b,4,t,h,w) -> (b,3,t,8h,8w); all frames in one batched pass (ddpm3d.py:666-679)."""
+        return self.first_stage_model.decode_video(z, self.scale_factor)
+
+    @torch.no_grad()
+    def encode_first_stage_2DAE(self, x):
+        """(b,3,t,H,W) -> scaled latents, frame by frame posterior sample (ddpm3d.py:586-600)."""
+        out = [self.scale_factor * self.first_stage_model.encode(x[:, :, i]).sample().detach().unsqueeze(2)
+               for i in range(x.shape[2])]
+        return torch.cat(out, dim=2)
+
+    def get_learned_conditioning(self, c):
+        if self.cond_stage_model is None:
+            raise RuntimeError("no text encoder attached: pass prompt_embeds (B,77,1024) instead of prompts")
+        return self.cond_stage_model(c)

@@ -194,15 +194,20 @@ class TemporalTransformer(nn.Module):
         self.proj_out = zero_module(nn.Linear(inner, in_channels) if use_linear else nn.Conv1d(inner, in_channels, 1))
         self.use_linear = use_linear
 
+    @staticmethod
+    def _pointwise(proj, y):
+        """Linear (possibly LoRA-injected) or the k=1 Conv1d of init_attn: a per-token matmul either way."""
+        if isinstance(proj, nn.Conv1d):
+            return F.linear(y, proj.weight.reshape(proj.weight.shape[0], -1), proj.bias)
+        return proj(y)
+
     def forward(self, x, context=None):
         b, c, t, h, w = x.shape
         y = self.norm(x).permute(0, 3, 4, 2, 1).reshape(b * h * w, t, c)  # (b h w) t c
-        wi = self.proj_in.weight
-        y = F.linear(y, wi.reshape(wi.shape[0], -1), self.proj_in.bias)
+        y = self._pointwise(self.proj_in, y)
         for blk in self.transformer_blocks:
             y = blk(y)
-        wo = self.proj_out.weight
-        y = F.linear(y, wo.reshape(wo.shape[0], -1), self.proj_out.bias)
+        y = self._pointwise(self.proj_out, y)
         return y.reshape(b, h, w, t, c).permute(0, 4, 3, 1, 2) + x
 
 
