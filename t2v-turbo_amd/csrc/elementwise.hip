@@ -101,8 +101,11 @@ __global__ void lcm_step_kernel(const float* x, const void* eps, int eps_dt, con
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_small_kernel(const bf16_t* x, int n_img, int H, int W, const float* wgt,
                                                          const float* bias, int cout, bf16_t* out) {
-    extern __shared__ float sw[];  // [cout][9*CIN]
-    for (int i = threadIdx.x; i < cout * 9 * CIN; i += 256) sw[i] = wgt[i];
+    extern __shared__ float sw[];  // [9*CIN][cout]: a thread reads its 8 output channels as two float4
+    for (int i = threadIdx.x; i < cout * 9 * CIN; i += 256) {
+        const int oc = i / (9 * CIN), k = i - oc * 9 * CIN;
+        sw[k * cout + oc] = wgt[i];
+    }
     __syncthreads();
     const int nch = cout / 8;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -123,13 +126,19 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16_t* x, int n_
             if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
             const bf16_t* xp = x + (nbase + (long long)iy * W + ix) * CIN;
             float xv[CIN];
+            if constexpr (CIN == 4) {
+                const uint2 u = *(const uint2*)xp;
+                xv[0] = __uint_as_float(u.x << 16); xv[1] = __uint_as_float(u.x & 0xffff0000u);
+                xv[2] = __uint_as_float(u.y << 16); xv[3] = __uint_as_float(u.y & 0xffff0000u);
+            } else {
+                unpack8(*(const uint4*)xp, xv);
+            }
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) xv[c] = bf2f(xp[c]);
-#pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const float* wp = sw + (oc0 + o) * 9 * CIN + (ky * 3 + kx) * CIN;
-#pragma unroll
-                for (int c = 0; c < CIN; ++c) acc[o] += xv[c] * wp[c];
+            for (int c = 0; c < CIN; ++c) {
+                const float* wp = sw + ((ky * 3 + kx) * CIN + c) * cout + oc0;
+                const float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
+                acc[0] += xv[c] * w0.x; acc[1] += xv[c] * w0.y; acc[2] += xv[c] * w0.z; acc[3] += xv[c] * w0.w;
+                acc[4] += xv[c] * w1.x; acc[5] += xv[c] * w1.y; acc[6] += xv[c] * w1.z; acc[7] += xv[c] * w1.w;
             }
         }
     *(uint4*)(out + m * cout + oc0) = pack8(acc);

@@ -91,13 +91,13 @@ __global__ __launch_bounds__(256) void gn_stats_partial(const bf16_t* x0, int c0
         ssum[c] = a; ssq[c] = b;
     }
     __syncthreads();
-    float* out = partial + ((long long)unit * nslab + slab) * groups * 2;
+    // partial is [unit][value = 2*group + stat][slab]: the final pass reads each value's slabs contiguously
     for (int i = tid; i < groups * 2; i += 256) {
         const int grp = i >> 1;
         const float* src = (i & 1) ? ssq : ssum;
         float a = 0.f;
         for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) a += src[c];
-        out[i] = a;
+        partial[((long long)unit * groups * 2 + i) * nslab + slab] = a;
     }
 }
 
@@ -108,10 +108,14 @@ __global__ __launch_bounds__(256) void gn_stats_final(const float* partial, int 
     const int unit = blockIdx.x, tid = threadIdx.x;
     const int width = groups * 2, parts = 256 / width;
     const int v = tid % width, part = tid / width;
-    const float* base = partial + (long long)unit * nslab * width;
+    const float* base = partial + ((long long)unit * width + v) * nslab;
+    const int chunk = (nslab + parts - 1) / parts;
     double acc = 0.0;
-    if (part < parts)
-        for (int k = part; k < nslab; k += parts) acc += (double)base[(long long)k * width + v];
+    if (part < parts) {
+        const int k1 = min(nslab, (part + 1) * chunk);
+#pragma unroll 8
+        for (int k = part * chunk; k < k1; ++k) acc += (double)base[k];
+    }
     sh[tid] = acc;
     __syncthreads();
     double t = 0.0;

@@ -1,0 +1,47 @@
+"""No-GPU check of the drop-in boundary: libt2v_hip.so loads and exports every symbol that
+include/t2v_hip.h declares, and the ctypes binding covers exactly that set."""
+import ctypes
+import os
+import re
+
+from t2v_turbo_amd import native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "t2v_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(t2v_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    names = _declared()
+    assert "t2v_gemm" in names and "t2v_attn_spatial" in names and len(names) >= 20
+    assert os.path.exists(native.LIB_PATH), "build the library first: python __graft_entry__.py"
+    lib = ctypes.CDLL(native.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/t2v_hip.h but not exported"
+    assert sorted(native.EXPORTED) == names, set(native.EXPORTED) ^ set(names)
+
+
+def test_struct_layout_matches_header():
+    # field order of t2v_gemm_desc in the header == ctypes Structure
+    text = open(os.path.join(ROOT, "include", "t2v_hip.h")).read()
+    body = text[text.index("typedef struct t2v_gemm_desc {"):text.index("} t2v_gemm_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for stmt in body.split(";")[:-1]:
+        stmt = stmt.split("{")[-1].strip()
+        if not stmt:
+            continue
+        names = re.sub(r"^(const\s+)?(void|float|int|long long)\s*\*?", "", stmt)
+        fields += [n.strip().lstrip("*") for n in names.split(",")]
+    assert fields == [f[0] for f in native.GemmDesc._fields_], fields
+
+
+def test_calls_without_gpu_fail_cleanly():
+    lib = native.load()
+    assert lib.t2v_version() >= 100
+    assert lib.t2v_gemm(None, None) == -1  # T2V_EINVAL, no crash
+    assert b"null" in lib.t2v_last_error()
