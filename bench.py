@@ -21,6 +21,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+T_START = time.time()
 UNET_TFLOP_PER_STEP = 12.581   # BASELINE.md §2 (2*MAC, matmul+conv, B=1, 16x40x64)
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (MI355X_MICROARCH.md)
 
@@ -101,22 +102,64 @@ def kernel_breakdown(engine, plan):
     return agg
 
 
-def cpu_baseline(model, x, ctx, tc, y_gpu, frames):
+def log(msg):
+    print(f"[bench +{time.time() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+class Watchdog:
+    """SIGALRM guard: an optional leg that overruns is abandoned (recorded in the JSON) instead of
+    eating the whole run."""
+
+    def __init__(self, seconds, what):
+        self.seconds, self.what = seconds, what
+
+    def __enter__(self):
+        import signal
+
+        def fire(*_):
+            raise TimeoutError(f"{self.what} exceeded {self.seconds}s")
+
+        self.old = signal.signal(signal.SIGALRM, fire)
+        signal.alarm(self.seconds)
+
+    def __exit__(self, *exc):
+        import signal
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, self.old)
+        return False
+
+
+def cpu_baseline(model, x, ctx, tc, frames_req):
     """The oracle (CPU restatement of the reference forward, pinned to reference goldens) timed on this
-    host's cores on a bounded sample: ONE UNet forward on the first `frames` frames of the same clip."""
+    host's cores on a bounded sample: ONE fp32 UNet forward on the first F frames of the same clip.
+    F is chosen from a 1-frame probe so that the sample stays within ~45 s of CPU time."""
     from oracle import unet_oracle as uo
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = min(cores, 64)  # torch CPU ops stop scaling (and can thrash) far below 256 threads
+    torch.set_num_threads(threads)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    xs = x[:, :, :frames].float().cpu()
     ts = torch.tensor([999])
-    t0 = time.time()
-    y = uo.unet_forward(sd, VC2_UNET, xs, ts, ctx.float().cpu(), fps=16, timestep_cond=tc.float().cpu())
-    dt = time.time() - t0
-    out = {"value": round((frames / 16.0) / dt, 5), "unit": "UNet steps/s (16f-equivalent)", "cores": cores,
+    cpu = dict(context=ctx.float().cpu(), fps=16, timestep_cond=tc.float().cpu())
+
+    def run(f):
+        xs = x[:, :, :f].float().cpu()
+        t0 = time.time()
+        y = uo.unet_forward(sd, VC2_UNET, xs, ts, cpu["context"], fps=16, timestep_cond=cpu["timestep_cond"])
+        return time.time() - t0, y
+
+    t1, y = run(1)
+    log(f"cpu oracle probe: 1 frame {t1:.1f}s on {threads} threads")
+    frames = frames_req or (16 if t1 * 16 < 45 else 4 if t1 * 4 < 45 else 1)
+    if frames > 1:
+        dt, y = run(frames)
+    else:
+        dt = t1
+    with torch.no_grad():
+        y_gpu = model(x[:, :, :frames].contiguous(), ts.to(x.device), context=ctx, fps=16, timestep_cond=tc)
+    out = {"value": round((frames / 16.0) / dt, 5), "unit": "UNet steps/s (16f-equivalent)", "cores": threads,
            "kind": "port",
            "sample": f"1 fp32 forward of oracle.unet_oracle (restated reference UNetModel.forward) on a "
-                     f"(1,4,{frames},40,64) latent, {dt:.1f} s wall, torch CPU {cores} threads"}
+                     f"(1,4,{frames},40,64) latent, {dt:.1f} s wall, torch CPU {threads} threads of {cores} cores"}
     if y_gpu is not None:
         num = (y_gpu.float().cpu() - y).double().norm()
         out["parity_rel_l2_vs_gpu"] = float(num / y.double().norm())
@@ -146,8 +189,10 @@ def main():
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16
 
+    log("building model")
     model = build_model(dev, dtype)
     x, ctx, tc = synth_inputs(dev, dtype)
+    log("model built")
     eng = model.native_engine()
     eng.use_graph = bool(args.graph)
     table = [999, 759, 519, 279]
@@ -158,6 +203,7 @@ def main():
 
     with torch.no_grad():
         y0 = step(0)  # recording pass (also packs weights)
+        log("plan recorded")
         for i in range(max(args.warmup, 2)):  # >= 2: the second call captures the graph
             step(i)
 
@@ -207,13 +253,21 @@ def main():
             }
             result["kernel_ms"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflop": round(v["tflop"], 3)}
                                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+        log(f"timed region done: {ms_per_step:.2f} ms/step")
         if args.clip and world == 1:
-            result["clip_4step"] = clip_wallclock(model, dev, dtype)
+            try:
+                with Watchdog(150, "4-step clip leg"):
+                    result["clip_4step"] = clip_wallclock(model, dev, dtype)
+            except Exception as e:  # noqa: BLE001 - optional leg, reported not fatal
+                result["clip_4step"] = {"error": repr(e)}
+            log(f"clip leg: {result['clip_4step']}")
         if args.cpu_baseline and world == 1:
-            frames = args.cpu_frames or (16 if (os.cpu_count() or 1) >= 32 else 4)
-            with torch.no_grad():
-                y_gpu = model(x[:, :, :frames].contiguous(), ts[0], context=ctx, fps=16, timestep_cond=tc)
-            result["cpu_baseline"] = cpu_baseline(model, x, ctx, tc, y_gpu, frames)
+            try:
+                with Watchdog(240, "cpu baseline leg"):
+                    result["cpu_baseline"] = cpu_baseline(model, x, ctx, tc, args.cpu_frames)
+            except Exception as e:  # noqa: BLE001
+                result["cpu_baseline"] = {"error": repr(e)}
+            log(f"cpu baseline leg: {result['cpu_baseline']}")
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
@@ -231,6 +285,7 @@ def clip_wallclock(model, dev, dtype):
     g = torch.Generator().manual_seed(0)
     pe = torch.randn(1, 77, 1024, generator=g).to(dev, dtype)
     times = []
+    log("clip leg: VAE built")
     for it in range(3):
         gen = torch.Generator(device=dev).manual_seed(42)
         torch.cuda.synchronize()
@@ -239,6 +294,7 @@ def clip_wallclock(model, dev, dtype):
                    lcm_origin_steps=50, prompt_embeds=pe, generator=gen, output_type="pt")
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t0) * 1e3)
+        log(f"clip leg: iteration {it} {times[-1]:.1f} ms")
     return {"ms": round(min(times), 2), "ms_all": [round(t, 2) for t in times], "video_shape": list(vid.shape),
             "finite": bool(torch.isfinite(vid.float()).all())}
 

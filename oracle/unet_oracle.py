@@ -222,7 +222,8 @@ def _run_block(sd, prefix, kids, h, emb, context, b, cfg, probs_out):
 def unet_forward(sd, cfg, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None,
                  probs_out=None):
     """UNetModel.forward (openaimodel3d.py:672-740), fp32, eval mode."""
-    sd = {k: v.float() for k, v in sd.items()}
+    if any(v.dtype != torch.float32 for v in sd.values()):
+        sd = {k: v.float() for k, v in sd.items()}
     mc = cfg["model_channels"]
     x = x.float()
     context = context.float()
