@@ -149,11 +149,18 @@ def cpu_baseline(model, x, ctx, tc, frames_req):
 
     t1, y = run(1)
     log(f"cpu oracle probe: 1 frame {t1:.1f}s on {threads} threads")
-    frames = frames_req or (16 if t1 * 16 < 45 else 4 if t1 * 4 < 45 else 1)
-    if frames > 1:
+    frames, dt = 1, t1
+    if frames_req:
+        frames = frames_req
         dt, y = run(frames)
-    else:
-        dt = t1
+    elif t1 * 4 < 60:
+        frames = 4
+        dt, y = run(4)
+        est16 = dt + 12 * max(dt - t1, 0.0) / 3  # per-frame slope from the two probes
+        log(f"cpu oracle: 4 frames {dt:.1f}s, 16-frame estimate {est16:.0f}s")
+        if est16 < 40:
+            frames = 16
+            dt, y = run(16)
     with torch.no_grad():
         y_gpu = model(x[:, :, :frames].contiguous(), ts.to(x.device), context=ctx, fps=16, timestep_cond=tc)
     out = {"value": round((frames / 16.0) / dt, 5), "unit": "UNet steps/s (16f-equivalent)", "cores": threads,
