@@ -431,8 +431,10 @@ struct TileCfg { int bm, bn, wtn; };
 // id -> (BM, BN, per-wave N width); waves / stages: see dispatch()
 const TileCfg kCfg[] = {{0, 0, 0},      {128, 128, 64}, {128, 64, 32},  {256, 64, 64}, {128, 128, 64},
                         {128, 64, 32},  {256, 128, 64}, {256, 128, 64}, {64, 128, 32}, {256, 64, 32},
-                        {128, 128, 64}, {128, 256, 64}};
-constexpr int kNumCfg = 11;
+                        {128, 128, 64}, {128, 256, 64},
+                        // 128x64 (tokens x channels) wave tiles: 25 % fewer LDS reads per MFMA than 64x64
+                        {256, 256, 64}, {256, 128, 64}, {128, 256, 64}, {256, 256, 64}};
+constexpr int kNumCfg = 15;
 
 int dispatch(int cfg, GemmParams& p, hipStream_t s) {
     switch (cfg) {
@@ -447,6 +449,10 @@ int dispatch(int cfg, GemmParams& p, hipStream_t s) {
         case 9: return launch<256, 64, 4, 2, 3>(p, s);
         case 10: return launch<128, 128, 2, 2, 4>(p, s);
         case 11: return launch<128, 256, 2, 4, 3>(p, s);
+        case 12: return launch<256, 256, 2, 4, 2>(p, s);
+        case 13: return launch<256, 128, 2, 2, 2>(p, s);
+        case 14: return launch<128, 256, 1, 4, 2>(p, s);
+        case 15: return launch<256, 256, 4, 2, 2>(p, s);
         default: return T2V_EINVAL;
     }
 }
