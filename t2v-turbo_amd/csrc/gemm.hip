@@ -289,14 +289,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         if (STAGES >= 4 && younger == 2) wait_vmcnt<LOADS * 2>();
         else if (STAGES >= 3 && younger == 1) wait_vmcnt<LOADS>();
         else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
+        if (!(p.debug & 16)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const char* sa = smem + buf * STAGE_BYTES + (wave_m * WTM + frow) * 128;
         const char* sb = smem + buf * STAGE_BYTES + A_BYTES + (wave_n * WTN + frow) * 128;
         // fragments are double-buffered in registers: the ds_read_b128s of K-slice kk+1 are issued
         // before the MFMAs of slice kk, and slice 0's reads before the DMA issue of the next tile
         bf16x8_t fa[2][TM], fw[2][TN];
-        {
+        if (p.debug & 8) {  // ablation: no LDS reads, operands = whatever (kept live through asm)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) { fa[0][i] = (bf16x8_t){0}; fa[1][i] = (bf16x8_t){0}; asm volatile("" : "+v"(fa[0][i]), "+v"(fa[1][i])); }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) { fw[0][j] = (bf16x8_t){0}; fw[1][j] = (bf16x8_t){0}; asm volatile("" : "+v"(fw[0][j]), "+v"(fw[1][j])); }
+        } else {
             const int coff = (hi ^ swz) << 4;
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[0][i] = *(const bf16x8_t*)(sa + i * 32 * 128 + coff);
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         if (!(p.debug & 2))
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3) {
+            if (kk < 3 && !(p.debug & 8)) {
                 const int coff = (((kk + 1) * 2 + hi) ^ swz) << 4;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) fa[(kk + 1) & 1][i] = *(const bf16x8_t*)(sa + i * 32 * 128 + coff);
@@ -319,6 +324,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
+            // pin the issue order: all ds_reads of slice kk+1 first, then the MFMAs of slice kk, so the LDS
+            // latency hides under a full slice of matrix work (and the two fragment sets stay distinct)
+            // (the compiler's wait before the first MFMA of a slice is lgkmcnt(0): issuing the next slice's
+            // reads right AFTER that MFMA keeps the wait exact and gives them TM*TN-1 MFMAs to land)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (kk < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 1, 0);
         }
         buf = (buf + 1 == STAGES) ? 0 : buf + 1;
         fill = (fill + 1 == STAGES) ? 0 : fill + 1;
