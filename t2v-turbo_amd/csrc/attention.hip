@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
     const int swz = (lane >> 1) & 7;
+    const float c2 = scale * 1.4426950408889634f;  // softmax in base 2
 
     load_tile(0);
     store_tile(0);
@@ -108,6 +109,8 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
             }
         }
         // ---- online softmax (this lane: one query, 32 of the 64 keys; partner lane^32 the rest) ---
+        // scores stay raw; max is taken on them and exp2(fma(s, c, -c*max)) folds scale*log2(e): 3 VALU
+        // ops per element (max, fma, exp2) instead of 5
         const int key_base = t * KT + 4 * hi;
         const bool tail = (t + 1) * KT > seq_kv;
         float mloc = -INFINITY;
@@ -115,27 +118,30 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float v = s[h2][r] * scale;
-                if (tail && key_base + h2 * 32 + (r & 3) + 8 * (r >> 2) >= seq_kv) v = -INFINITY;
-                s[h2][r] = v;
-                mloc = fmaxf(mloc, v);
+                if (tail && key_base + h2 * 32 + (r & 3) + 8 * (r >> 2) >= seq_kv) s[h2][r] = -INFINITY;
+                mloc = fmaxf(mloc, s[h2][r]);
             }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __expf(m_run - m_new);
-        m_run = m_new;
+        const float m_new = fmaxf(m_run, mloc);  // raw-score units
+        const bool grew = m_new > m_run;
+        const float mc = m_new * c2;
         float lsum = 0.f;
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __expf(s[h2][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[h2][r], c2, -mc));
                 s[h2][r] = p;
                 lsum += p;
             }
-        l_run = l_run * alpha + lsum;
+        if (__any(grew)) {  // wave-uniform: rescale only when some query's running max moved
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            m_run = m_new;
+        }
+        l_run += lsum;
         // ---- O^T += V^T P^T ------------------------------------------------------------------------
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -176,78 +182,131 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int FMAX>
+// One wave per (clip, pixel, head).  lane = (frame i = lane>>2, quarter dq = lane&3 of the 64-wide head):
+// each lane fetches ITS 32-byte slice of q_i, k_i and v_i exactly once (coalesced 128-byte rows at the
+// frame stride), K and V go to a 4 KiB per-wave LDS tile, and the 16x16 scores / PV products read them
+// back with broadcast ds_read_b128 (all lanes of a quarter read the same address).  F > 16 loops over
+// 16-frame query/key blocks with an online softmax.
 __global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __restrict__ q, int ldq,
                                                             const bf16_t* __restrict__ k, int ldk,
                                                             const bf16_t* __restrict__ v, int ldv,
                                                             bf16_t* __restrict__ out, int ldo, long long n_items, int F,
                                                             int HW, int heads, float scale, float* __restrict__ probs) {
-    const int lane = threadIdx.x & 63;
-    const long long item = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= n_items) return;
+    __shared__ __attribute__((aligned(16))) char lds[4][2][16 * 128];  // [wave][K|V][frame][64 bf16]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long long item = (long long)blockIdx.x * 4 + wv;
+    if (item >= n_items) return;  // whole wave exits together (item is wave-uniform)
     const int head = (int)(item % heads);
     const long long bp = item / heads;
     const int p = (int)(bp % HW);
     const long long b = bp / HW;
     const long long row0 = b * F * HW + p;  // row of frame f = row0 + f*HW
-    const int dq = lane & 3, col = head * 64 + dq * 16;
-    for (int qb = 0; qb * 16 < F; ++qb) {
-        const int i = qb * 16 + (lane >> 2);
+    const int fi = lane >> 2, dq = lane & 3, col = head * 64 + dq * 16;
+    char* sk = lds[wv][0];
+    char* sv = lds[wv][1];
+    const int nblk = (F + 15) / 16;
+    for (int qb = 0; qb < nblk; ++qb) {
+        const int i = qb * 16 + fi;
         const bool ok = i < F;
         float qv[16];
         {
             const bf16_t* qp = q + (row0 + (long long)(ok ? i : 0) * HW) * ldq + col;
             unpack8(*(const uint4*)qp, qv);
             unpack8(*(const uint4*)(qp + 8), qv + 8);
-        }
-        float s[FMAX];
-        float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < FMAX; ++j) {
-            s[j] = -INFINITY;
-            if (j < F) {
-                const bf16_t* kp = k + (row0 + (long long)j * HW) * ldk + col;
+            for (int e = 0; e < 16; ++e) qv[e] *= scale;
+        }
+        float m_run = -INFINITY, l_run = 0.f, o[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+        for (int kb = 0; kb < nblk; ++kb) {
+            const int j_own = kb * 16 + fi;  // the key/value frame this lane stages
+            {
+                const bool jok = j_own < F;
+                const long long r = row0 + (long long)(jok ? j_own : 0) * HW;
+                const uint4* kp = (const uint4*)(k + r * ldk + col);
+                const uint4* vp = (const uint4*)(v + r * ldv + col);
+                uint4 k0 = kp[0], k1 = kp[1], v0 = vp[0], v1 = vp[1];
+                if (!jok) { k0 = k1 = v0 = v1 = make_uint4(0, 0, 0, 0); }
+                uint4* dk = (uint4*)(sk + fi * 128 + dq * 32);
+                uint4* dv = (uint4*)(sv + fi * 128 + dq * 32);
+                dk[0] = k0; dk[1] = k1; dv[0] = v0; dv[1] = v1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            float s[16];
+            float mx = m_run;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
                 float kv[16];
-                unpack8(*(const uint4*)kp, kv);
-                unpack8(*(const uint4*)(kp + 8), kv + 8);
+                unpack8(*(const uint4*)(sk + j * 128 + dq * 32), kv);
+                unpack8(*(const uint4*)(sk + j * 128 + dq * 32 + 16), kv + 8);
                 float d = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) d += qv[e] * kv[e];
                 d += __shfl_xor(d, 1, 64);
                 d += __shfl_xor(d, 2, 64);
-                s[j] = d * scale;
+                s[j] = (kb * 16 + j < F) ? d : -INFINITY;
                 mx = fmaxf(mx, s[j]);
             }
-        }
-        float sum = 0.f;
+            const float alpha = __expf(m_run - mx);
+            m_run = mx;
+            float lsum = 0.f;
 #pragma unroll
-        for (int j = 0; j < FMAX; ++j) {
-            s[j] = (j < F) ? __expf(s[j] - mx) : 0.f;
-            sum += s[j];
-        }
-        const float inv = 1.f / sum;
-        float o[16];
+            for (int j = 0; j < 16; ++j) { s[j] = __expf(s[j] - mx); lsum += s[j]; }
+            l_run = l_run * alpha + lsum;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+            for (int e = 0; e < 16; ++e) o[e] *= alpha;
 #pragma unroll
-        for (int j = 0; j < FMAX; ++j) {
-            if (j < F) {
-                const float pj = s[j] * inv;
-                if (probs && dq == 0 && ok) probs[(item * F + i) * F + j] = pj;
-                const bf16_t* vp = v + (row0 + (long long)j * HW) * ldv + col;
+            for (int j = 0; j < 16; ++j) {
                 float vv[16];
-                unpack8(*(const uint4*)vp, vv);
-                unpack8(*(const uint4*)(vp + 8), vv + 8);
+                unpack8(*(const uint4*)(sv + j * 128 + dq * 32), vv);
+                unpack8(*(const uint4*)(sv + j * 128 + dq * 32 + 16), vv + 8);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) o[e] += pj * vv[e];
+                for (int e = 0; e < 16; ++e) o[e] += s[j] * vv[e];
             }
+            if (probs && nblk == 1 && dq == 0 && ok) {
+                const float inv1 = 1.f / l_run;
+                for (int j = 0; j < F; ++j) probs[(item * F + i) * F + j] = s[j] * inv1;
+            }
+            __builtin_amdgcn_wave_barrier();  // everyone done reading before the next block overwrites
         }
+        const float inv = 1.f / l_run;
         if (ok) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] *= inv;
             bf16_t* op = out + (row0 + (long long)i * HW) * ldo + col;
             *(uint4*)op = pack8(o);
             *(uint4*)(op + 8) = pack8(o + 8);
         }
     }
+}
+
+// attention_probs for F > 16 (rare: the reference records them at F = 16): separate exact pass
+__global__ __launch_bounds__(256) void attn_temporal_probs_kernel(const bf16_t* __restrict__ q, int ldq,
+                                                                  const bf16_t* __restrict__ k, int ldk, long long n_items,
+                                                                  int F, int HW, int heads, float scale,
+                                                                  float* __restrict__ probs) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;  // (item, i)
+    if (idx >= n_items * F) return;
+    const long long item = idx / F;
+    const int i = (int)(idx % F);
+    const int head = (int)(item % heads);
+    const long long bp = item / heads;
+    const long long row0 = (bp / HW) * F * HW + (bp % HW);
+    const bf16_t* qp = q + (row0 + (long long)i * HW) * ldq + head * 64;
+    float mx = -INFINITY;
+    float* pr = probs + idx * F;
+    for (int j = 0; j < F; ++j) {
+        const bf16_t* kp = k + (row0 + (long long)j * HW) * ldk + head * 64;
+        float d = 0.f;
+        for (int e = 0; e < 64; ++e) d += bf2f(qp[e]) * bf2f(kp[e]);
+        pr[j] = d * scale;
+        mx = fmaxf(mx, pr[j]);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < F; ++j) { pr[j] = __expf(pr[j] - mx); sum += pr[j]; }
+    for (int j = 0; j < F; ++j) pr[j] /= sum;
 }
 
 }  // namespace
@@ -272,18 +331,18 @@ extern "C" int t2v_attn_temporal(const void* q, int ldq, const void* k, int ldk,
                                  void* stream) {
     T2V_REQUIRE(q && k && v && out, T2V_EINVAL, "t2v_attn_temporal: null pointer");
     T2V_REQUIRE(n_clips > 0 && frames > 0 && hw > 0 && heads > 0, T2V_EINVAL, "t2v_attn_temporal: bad size");
-    T2V_REQUIRE(frames <= 64, T2V_ESHAPE, "t2v_attn_temporal: more than 64 frames not supported");
+    T2V_REQUIRE(frames <= 1024, T2V_ESHAPE, "t2v_attn_temporal: more than 1024 frames not supported");
     T2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0, T2V_ESHAPE, "t2v_attn_temporal: strides");
     const long long n_items = (long long)n_clips * hw * heads;
     const unsigned blocks = (unsigned)((n_items + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_T(FM)                                                                                                   \
-    hipLaunchKernelGGL(attn_temporal_kernel<FM>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)q, ldq, (const bf16_t*)k, \
-                       ldk, (const bf16_t*)v, ldv, (bf16_t*)out, ldo, n_items, frames, hw, heads, scale, probs)
-    if (frames <= 16) LAUNCH_T(16);
-    else if (frames <= 32) LAUNCH_T(32);
-    else LAUNCH_T(64);
-#undef LAUNCH_T
+hipLaunchKernelGGL(attn_temporal_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                       (const bf16_t*)v, ldv, (bf16_t*)out, ldo, n_items, frames, hw, heads, scale, probs);
+    if (probs && frames > 16) {
+        T2V_CHECK_LAUNCH();
+        hipLaunchKernelGGL(attn_temporal_probs_kernel, dim3((unsigned)((n_items * frames + 255) / 256)), dim3(256), 0, s,
+                           (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, n_items, frames, hw, heads, scale, probs);
+    }
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }

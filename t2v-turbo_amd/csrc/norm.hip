@@ -59,16 +59,26 @@ __global__ __launch_bounds__(256) void gn_stats_partial(const bf16_t* x0, int c0
     float* ssum = sred;
     float* ssq = sred + g.ty * C;
     if (ry < g.ty) {
-        for (int r = r0 + ry; r < r1; r += g.ty) {
-            const long long row = (long long)unit * rows_per_unit + r;
+        // 4 rows per trip: the 4 (x cpt) 16-byte loads are issued before any is consumed
+        for (int r = r0 + ry; r < r1; r += 4 * g.ty) {
 #pragma unroll
             for (int j = 0; j < GN_MAX_CPT; ++j) {
                 const int ci = cx + j * g.tx;
                 if (j < g.cpt && ci < g.cpr) {
-                    float f[8];
-                    unpack8(*(const uint4*)gn_src(x0, c0, ld0, x1, ld1, row, ci * 8), f);
+                    uint4 u[4];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { s[j][e] += f[e]; q[j][e] += f[e] * f[e]; }
+                    for (int t = 0; t < 4; ++t) {
+                        const int rr = r + t * g.ty;
+                        u[t] = rr < r1 ? *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, (long long)unit * rows_per_unit + rr, ci * 8)
+                                       : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float f[8];
+                        unpack8(u[t], f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { s[j][e] += f[e]; q[j][e] += f[e] * f[e]; }
+                    }
                 }
             }
         }
@@ -160,20 +170,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0,
     }
     const int r0 = slab * slab_rows;
     const int r1 = min(r0 + slab_rows, rows_per_unit);
-    for (int r = r0 + ry; r < r1; r += g.ty) {
-        const long long row = (long long)unit * rows_per_unit + r;
+    for (int r = r0 + ry; r < r1; r += 4 * g.ty) {
 #pragma unroll
         for (int j = 0; j < GN_MAX_CPT; ++j) {
             const int ci = cx + j * g.tx;
             if (j < g.cpt && ci < g.cpr) {
-                float f[8];
-                unpack8(*(const uint4*)gn_src(x0, c0, ld0, x1, ld1, row, ci * 8), f);
+                uint4 u[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float v = f[e] * sc[j][e] + sh[j][e];
-                    f[e] = silu ? silu_f(v) : v;
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = r + t * g.ty;
+                    if (rr < r1) u[t] = *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, (long long)unit * rows_per_unit + rr, ci * 8);
                 }
-                *(uint4*)(out + row * ldo + ci * 8) = pack8(f);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int rr = r + t * g.ty;
+                    if (rr < r1) {
+                        float f[8];
+                        unpack8(u[t], f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float v = f[e] * sc[j][e] + sh[j][e];
+                            f[e] = silu ? silu_f(v) : v;
+                        }
+                        *(uint4*)(out + ((long long)unit * rows_per_unit + rr) * ldo + ci * 8) = pack8(f);
+                    }
+                }
             }
         }
     }
