@@ -302,4 +302,4 @@ def test_bad_arguments_return_errors(pair):
     with pytest.raises(NativeError):
         pair.hip.gemm(a, w, out, M=64, N=64)
     with pytest.raises(NativeError):
-        pair.hip.attn_temporal(out, out, out, out, 1, 65, 1, 1, 0.125)
+        pair.hip.attn_temporal(out, out, out, out, 1, 2000, 1, 1, 0.125)
