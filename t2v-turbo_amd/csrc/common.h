@@ -19,8 +19,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+// two fp32 -> packed bf16x2, round-to-nearest-even in ONE instruction (gfx950 v_cvt_pk_bf16_f32; there is
+// no clang builtin for it, hence the asm)
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
     f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
