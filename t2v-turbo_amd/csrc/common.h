@@ -38,7 +38,8 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
     return v;
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division sequence
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 // exact (erf) GELU, as torch.nn.functional.gelu default
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 

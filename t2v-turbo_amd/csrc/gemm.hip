@@ -54,7 +54,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // A&S 7.1.26 erf (|err| < 1.5e-7): exact-GELU semantics at a fraction of erff's cost
 __device__ __forceinline__ float fast_gelu(float x) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = 1.0f / (1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * __expf(-z * z);
     const float erf_v = x < 0.f ? -erf_abs : erf_abs;
