@@ -87,7 +87,7 @@ def kernel_breakdown(engine, plan):
             sh["ms"] += ms
             sh["tflop"] += tf
         elif name == "t2v_attn_spatial":
-            n_img, seq_q, seq_kv, heads = args[8], args[9], args[10], args[11]
+            n_img, seq_q, seq_kv, heads = args[9], args[10], args[11], args[12]
             a["tflop"] += 4.0 * n_img * heads * seq_q * seq_kv * 64 / 1e12
         elif name == "t2v_attn_temporal":
             clips, frames, hw, heads = args[8], args[9], args[10], args[11]

@@ -134,13 +134,14 @@ int t2v_softmax_rows(void* s, long long rows, int n, int n_pad, int ld, void* st
 /* ---------------------------------------------------------------- attention
  * Fused spatial attention (flash style), head dim 64: softmax(Q K^T * scale) V per (image, head).
  * q: bf16 rows (img*seq_q + i), head h at columns [h*64, h*64+64); k likewise over seq_kv rows;
- * vt: V transposed per image: bf16 [img_kv][heads*64][ld_vt] (keys contiguous).
+ * vt: V transposed per image: bf16 [img_kv][heads*64][ld_vt] (keys contiguous); vt_img_stride = elements
+ * between consecutive kv images (0 = heads*64*ld_vt; larger when several layers' V^T share one buffer).
  * kv image of q image b is b / kv_div (text cross-attention shares K/V across the frames of a clip).
  * Replaces CrossAttention.forward / efficient_forward (attention.py:102-164,166-240 = xformers
  * memory_efficient_attention). */
 int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, const void* vt, int ld_vt,
-                     void* out, int ldo, int n_img, int seq_q, int seq_kv, int heads, int kv_div,
-                     float scale, void* stream);
+                     long long vt_img_stride, void* out, int ldo, int n_img, int seq_q, int seq_kv,
+                     int heads, int kv_div, float scale, void* stream);
 
 /* Temporal self-attention, head dim 64, sequence = frames: for every (clip b, pixel p, head h)
  * softmax(Q K^T * scale) V over the F frames, reading rows ((b*F+f)*HW + p) directly from the

@@ -23,7 +23,7 @@ constexpr int AT_STAGE = K_TILE_BYTES + VT_TILE_BYTES;
 
 __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restrict__ q, int ldq,
                                                            const bf16_t* __restrict__ k, int ldk,
-                                                           const bf16_t* __restrict__ vt, int ld_vt,
+                                                           const bf16_t* __restrict__ vt, int ld_vt, long long vt_img_stride,
                                                            bf16_t* __restrict__ out, int ldo, int seq_q, int seq_kv,
                                                            int heads, int kv_div, float scale) {
     __shared__ __attribute__((aligned(16))) char smem[2 * AT_STAGE];
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
         }
     }
     const bf16_t* kbase = k + (long long)img_kv * seq_kv * ldk + head * 64;
-    const bf16_t* vbase = vt + ((long long)img_kv * heads + head) * 64 * ld_vt;
+    const bf16_t* vbase = vt + (long long)img_kv * vt_img_stride + (long long)head * 64 * ld_vt;
     const int ntile = (seq_kv + KT - 1) / KT;
 
     // cooperative tile staging: 512 16-byte chunks per operand, 2 per thread
@@ -311,17 +311,20 @@ __global__ __launch_bounds__(256) void attn_temporal_probs_kernel(const bf16_t* 
 
 }  // namespace
 
-extern "C" int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, const void* vt, int ld_vt, void* out,
-                                int ldo, int n_img, int seq_q, int seq_kv, int heads, int kv_div, float scale,
-                                void* stream) {
+extern "C" int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, const void* vt, int ld_vt,
+                                long long vt_img_stride, void* out, int ldo, int n_img, int seq_q, int seq_kv, int heads,
+                                int kv_div, float scale, void* stream) {
     T2V_REQUIRE(q && k && vt && out, T2V_EINVAL, "t2v_attn_spatial: null pointer");
     T2V_REQUIRE(n_img > 0 && seq_q > 0 && seq_kv > 0 && heads > 0 && kv_div > 0, T2V_EINVAL, "t2v_attn_spatial: bad size");
     T2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ld_vt % 8 == 0 && ldo % 4 == 0, T2V_ESHAPE, "t2v_attn_spatial: strides");
     T2V_REQUIRE(ld_vt >= ((seq_kv + 63) / 64) * 64, T2V_ESHAPE, "t2v_attn_spatial: V^T rows must be padded to 64 keys");
     T2V_REQUIRE(heads <= 65535 && n_img <= 65535, T2V_ESHAPE, "t2v_attn_spatial: grid");
+    if (vt_img_stride <= 0) vt_img_stride = (long long)heads * 64 * ld_vt;
+    T2V_REQUIRE(vt_img_stride % 8 == 0, T2V_ESHAPE, "t2v_attn_spatial: vt_img_stride");
     dim3 grid((seq_q + 127) / 128, heads, n_img);
     hipLaunchKernelGGL(attn_spatial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
-                       (const bf16_t*)k, ldk, (const bf16_t*)vt, ld_vt, (bf16_t*)out, ldo, seq_q, seq_kv, heads, kv_div, scale);
+                       (const bf16_t*)k, ldk, (const bf16_t*)vt, ld_vt, vt_img_stride, (bf16_t*)out, ldo, seq_q, seq_kv, heads,
+                       kv_div, scale);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }

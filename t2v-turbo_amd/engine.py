@@ -478,6 +478,31 @@ class UNetEngine(_Engine):
             h2 = y
         return h2
 
+    def context_kv(self, attn):
+        """K and V^T of the text context for EVERY cross-attention layer in two GEMMs (once per clip, not
+        per frame and not per layer: the 16 to_k / to_v weights are stacked along N, like emb_layers)."""
+        if self.ctx_kv is None or not self.ctx_kv:
+            ops, pk, m, B, L = self.ops, self.pk, self.model, self.B, self.ctx_len
+            layers = [blk.attn2 for mod in m.modules() if isinstance(mod, SpatialTransformer)
+                      for blk in mod.transformer_blocks]
+            total = sum(a.heads * a.dim_head for a in layers)
+            wk = pk.cat_mats([a.to_k for a in layers], "ctx_k_all")
+            wv = pk.cat_mats([a.to_v for a in layers], "ctx_v_all")
+            kp = ((L + 63) // 64) * 64
+            k_all = self.buf(B * L, total)
+            ops.gemm(self.ctx, wk, k_all, M=B * L, N=total)
+            vt_all = self.buf(B * total, kp)
+            if kp != L:
+                ops.fill_zero(vt_all)
+            ops.gemm(wv, self.ctx, vt_all, M=total, N=L, batch=B, w_strides=(L * self.ctx.stride(0), 0),
+                     o_strides=(total * kp, 0))
+            off = 0
+            for a in layers:
+                inner = a.heads * a.dim_head
+                self.ctx_kv[id(a)] = (k_all[:, off:off + inner], vt_all[off:off + inner], kp, total * kp)
+                off += inner
+        return self.ctx_kv[id(attn)]
+
     def _check_heads(self, attn):
         if attn.dim_head != 64:
             raise nt.NativeError(f"native attention kernels need dim_head == 64 (got {attn.dim_head})")
@@ -523,17 +548,9 @@ class UNetEngine(_Engine):
 
         def cross_attn(attn, src):
             q = self.linear(src, attn.to_q, bias=None)
-            if id(attn) not in self.ctx_kv:  # once per clip, not per frame (K11)
-                L = self.ctx_len
-                k = self.linear(self.ctx, attn.to_k, bias=None)
-                kp = ((L + 63) // 64) * 64
-                vt = self.buf(B * inner, kp, zero=True)
-                ops.gemm(pk.mat(attn.to_v), self.ctx, vt, M=inner, N=L, batch=B, w_strides=(L * self.ctx.stride(0), 0),
-                         o_strides=(inner * kp, 0))
-                self.ctx_kv[id(attn)] = (k, vt, kp)
-            k, vt, kp = self.ctx_kv[id(attn)]
+            k, vt, kp, vt_stride = self.context_kv(attn)
             o = self.buf(M, inner)
-            ops.attn_spatial(q, k, vt, kp, o, n_img, hw, self.ctx_len, attn.heads, F, attn.scale)
+            ops.attn_spatial(q, k, vt, kp, o, n_img, hw, self.ctx_len, attn.heads, F, attn.scale, vt_stride)
             self.pool.put(q)
             return o
 

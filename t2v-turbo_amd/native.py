@@ -63,8 +63,9 @@ _SIGS = {
     "t2v_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                 C.c_void_p, C.c_int, C.c_void_p]),
     "t2v_softmax_rows": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "t2v_attn_spatial": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
-                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "t2v_attn_spatial": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong,
+                                   C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                   C.c_void_p]),
     "t2v_attn_temporal": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                     C.c_void_p]),
@@ -233,9 +234,9 @@ class HipOps:
     def softmax_rows(self, s, rows, n, n_pad, ld):
         self._call("t2v_softmax_rows", _p(s), rows, n, n_pad, ld)
 
-    def attn_spatial(self, q, k, vt, ld_vt, out, n_img, seq_q, seq_kv, heads, kv_div, scale):
-        self._call("t2v_attn_spatial", _p(q), _row_stride(q), _p(k), _row_stride(k), _p(vt), ld_vt, _p(out),
-                   _row_stride(out), n_img, seq_q, seq_kv, heads, kv_div, scale)
+    def attn_spatial(self, q, k, vt, ld_vt, out, n_img, seq_q, seq_kv, heads, kv_div, scale, vt_img_stride=0):
+        self._call("t2v_attn_spatial", _p(q), _row_stride(q), _p(k), _row_stride(k), _p(vt), ld_vt, vt_img_stride,
+                   _p(out), _row_stride(out), n_img, seq_q, seq_kv, heads, kv_div, scale)
 
     def attn_temporal(self, q, k, v, out, n_clips, frames, hw, heads, scale, probs=None):
         self._call("t2v_attn_temporal", _p(q), _row_stride(q), _p(k), _row_stride(k), _p(v), _row_stride(v), _p(out),

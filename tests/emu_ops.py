@@ -143,15 +143,16 @@ class EmuOps:
         v.copy_(p.to(s.dtype))
 
     # ------------------------------------------------------------------------------------ attention
-    def attn_spatial(self, q, k, vt, ld_vt, out, n_img, seq_q, seq_kv, heads, kv_div, scale):
+    def attn_spatial(self, q, k, vt, ld_vt, out, n_img, seq_q, seq_kv, heads, kv_div, scale, vt_img_stride=0):
         self._log("attn_spatial")
         assert ld_vt >= ((seq_kv + 63) // 64) * 64
+        vt_img_stride = vt_img_stride or heads * 64 * ld_vt
         for img in range(n_img):
             ikv = img // kv_div
             for hd in range(heads):
                 Q = q[img * seq_q:(img + 1) * seq_q, hd * 64:(hd + 1) * 64].float()
                 Kk = k[ikv * seq_kv:(ikv + 1) * seq_kv, hd * 64:(hd + 1) * 64].float()
-                Vt = _strided(vt, 64, seq_kv, ld_vt, (ikv * heads + hd) * 64 * ld_vt).float()
+                Vt = _strided(vt, 64, seq_kv, ld_vt, ikv * vt_img_stride + hd * 64 * ld_vt).float()
                 P = (Q @ Kk.t() * scale).softmax(dim=1)
                 out[img * seq_q:(img + 1) * seq_q, hd * 64:(hd + 1) * 64] = (P @ Vt.t()).to(out.dtype)
 
