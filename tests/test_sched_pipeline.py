@@ -119,3 +119,40 @@ def test_compat_install_aliases_reference_paths():
         "print('ok', len(made))\n") % (__import__("tests.util").util.GOLDEN.rsplit("/tests/", 1)[0],)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_pipeline_v2_motion_cond_16_steps_matches_manual_loop():
+    """BASELINE config C4 shape family (T2V-Turbo-v2: 16 steps on the 200-step grid, motion-guidance
+    embedding switched off below the percentage threshold, pipeline/t2v_turbo_vc2_pipeline.py:190-204):
+    the pipeline must equal a hand-written loop over the oracle UNet + oracle scheduler math."""
+    from oracle import sched_oracle as so
+    from oracle import unet_oracle as uo
+    from oracle import vae_oracle as vo
+    p = tiny_unet_params(motion_cond_proj_dim=256)
+    sd_u = synth_state_dict(manifest("unet_tiny_mg_b2"))
+    sd_v = synth_state_dict(manifest("vae_tiny"))
+    unet = UNetModel(**p).eval()
+    unet.load_state_dict(sd_u, strict=True)
+    ae = AutoencoderKL(ddconfig=VAE_TINY_DD, embed_dim=4).eval()
+    ae.load_state_dict(sd_v, strict=True)
+    pipe = T2VTurboVC2Pipeline(LatentDiffusion(unet, ae), None, {"params": {"unet_config": {"params": p}}})
+    pe = torch.randn(1, 77, 128, generator=torch.Generator().manual_seed(1))
+    vid = pipe(prompt=None, height=64, width=64, frames=2, fps=8, guidance_scale=7.5, motion_gs=0.1, use_motion_cond=True,
+               percentage=0.3, num_inference_steps=16, lcm_origin_steps=200, prompt_embeds=pe,
+               generator=torch.Generator().manual_seed(7), output_type="pt")
+    # manual loop
+    gen = torch.Generator().manual_seed(7)
+    lat = torch.randn(1, 4, 2, 8, 8, generator=gen)
+    acp = so.alphas_cumprod()
+    ts = so.lcm_timesteps(16, 200)
+    assert ts[0] == 999 and len(ts) == 16
+    w = so.w_embedding(torch.tensor([7.5]), 256)
+    den = lat
+    for i, t in enumerate(ts):
+        mg = torch.tensor([0.1 if t >= 1000 * (1 - 0.3) else 0.0])
+        eps = uo.unet_forward(sd_u, p, lat, torch.tensor([int(t)]), pe, fps=8, timestep_cond=w,
+                              motion_cond=so.w_embedding(mg, 256))
+        noise = torch.randn(lat.shape, generator=gen)
+        lat, den = so.step(acp, ts, eps, i, t, lat, noise)
+    ref = vo.decode_first_stage_2dae(sd_v, VAE_TINY_DD, den)
+    assert rel_l2(vid, ref) < 1e-4
