@@ -136,6 +136,8 @@ int t2v_softmax_rows(void* s, long long rows, int n, int n_pad, int ld, void* st
  * q: bf16 rows (img*seq_q + i), head h at columns [h*64, h*64+64); k likewise over seq_kv rows;
  * vt: V transposed per image: bf16 [img_kv][heads*64][ld_vt] (keys contiguous); vt_img_stride = elements
  * between consecutive kv images (0 = heads*64*ld_vt; larger when several layers' V^T share one buffer).
+ * ld_vt >= seq_kv rounded up to 64; the padding columns are read (their probability is exactly 0) and
+ * must hold finite values.
  * kv image of q image b is b / kv_div (text cross-attention shares K/V across the frames of a clip).
  * Replaces CrossAttention.forward / efficient_forward (attention.py:102-164,166-240 = xformers
  * memory_efficient_attention). */

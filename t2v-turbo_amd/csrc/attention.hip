@@ -17,17 +17,26 @@ namespace {
 
 constexpr int KT = 64;          // keys per tile
 constexpr int K_TILE_BYTES = KT * 128;
-constexpr int VT_STRIDE = 136;  // bytes per V^T row (64 keys * 2 B + 8 B pad: conflict-free ds_read_b64)
-constexpr int VT_TILE_BYTES = 64 * VT_STRIDE;
+constexpr int VT_TILE_BYTES = 64 * 128;
 constexpr int AT_STAGE = K_TILE_BYTES + VT_TILE_BYTES;
 
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+// K tile [64 keys][64 d] and V^T tile [64 d][64 keys], both 128-byte rows with the 16-byte chunk index
+// XOR-swizzled by (row>>1)&7, are filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
+// ds_write): 16 wave-instructions per tile pair, 4 per wave.  Keys past seq_kv: K rows come from a zero
+// page; the V^T buffer's padding columns must be finite (the engine zero-fills them) since their P is 0.
 __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restrict__ q, int ldq,
                                                            const bf16_t* __restrict__ k, int ldk,
                                                            const bf16_t* __restrict__ vt, int ld_vt, long long vt_img_stride,
                                                            bf16_t* __restrict__ out, int ldo, int seq_q, int seq_kv,
-                                                           int heads, int kv_div, float scale) {
+                                                           int heads, int kv_div, float scale, const bf16_t* zero, int debug) {
     __shared__ __attribute__((aligned(16))) char smem[2 * AT_STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
     const int head = blockIdx.y, img = blockIdx.z, img_kv = img / kv_div;
     const int q0 = blockIdx.x * 128 + wave * 32;
@@ -48,36 +57,23 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
     const bf16_t* vbase = vt + (long long)img_kv * vt_img_stride + (long long)head * 64 * ld_vt;
     const int ntile = (seq_kv + KT - 1) / KT;
 
-    // cooperative tile staging: 512 16-byte chunks per operand, 2 per thread
-    uint4 kreg[2], vreg[2];
-    auto load_tile = [&](int t) {
+    // DMA lane roles: wave-instruction i (= wave + 4*j, j = 0,1) covers tile rows [8i, 8i+8)
+    int drow[2], dchunk[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        drow[j] = (wave + 4 * j) * 8 + (lane >> 3);
+        dchunk[j] = ((lane & 7) ^ ((drow[j] >> 1) & 7)) * 8;
+    }
+    auto stage = [&](int t, int buf) {
+        char* sk = smem + buf * AT_STAGE;
+        char* sv = sk + K_TILE_BYTES;
         const int key0 = t * KT;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int id = tid + j * 256, row = id >> 3, c = id & 7;
-            const int key = key0 + row;
-            kreg[j] = key < seq_kv ? *(const uint4*)(kbase + (long long)key * ldk + c * 8) : make_uint4(0, 0, 0, 0);
-            // V^T rows are d, columns keys; the buffer is padded to a multiple of 64 keys
-            uint4 v = *(const uint4*)(vbase + (long long)row * ld_vt + key0 + c * 8);
-            if (key0 + c * 8 + 8 > seq_kv) {  // zero the keys past the end (their P is 0, but 0*garbage must stay 0)
-                bf16_t* e = (bf16_t*)&v;
-#pragma unroll
-                for (int x = 0; x < 8; ++x)
-                    if (key0 + c * 8 + x >= seq_kv) e[x] = 0;
-            }
-            vreg[j] = v;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        char* sk = smem + buf * AT_STAGE;
-        char* sv = sk + K_TILE_BYTES;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int id = tid + j * 256, row = id >> 3, c = id & 7;
-            *(uint4*)(sk + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kreg[j];
-            uint2* d = (uint2*)(sv + row * VT_STRIDE + c * 16);
-            d[0] = make_uint2(vreg[j].x, vreg[j].y);
-            d[1] = make_uint2(vreg[j].z, vreg[j].w);
+            const int key = key0 + drow[j];
+            const bf16_t* ksrc = key < seq_kv ? kbase + (long long)key * ldk + dchunk[j] : zero;
+            dma16(ksrc, sk + (wave + 4 * j) * 1024);
+            dma16(vbase + (long long)drow[j] * ld_vt + key0 + dchunk[j], sv + (wave + 4 * j) * 1024);
         }
     };
 
@@ -88,12 +84,12 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
     const int swz = (lane >> 1) & 7;
     const float c2 = scale * 1.4426950408889634f;  // softmax in base 2
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    stage(0, 0);
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
-        if (t + 1 < ntile) load_tile(t + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(debug & 16)) __syncthreads();
+        if (t + 1 < ntile && !(debug & 4)) stage(t + 1, buf ^ 1);
         const char* sk = smem + buf * AT_STAGE;
         const char* sv = sk + K_TILE_BYTES;
         // ---- S^T = K Q^T ------------------------------------------------------------------------
@@ -102,6 +98,7 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
         for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[h2][r] = 0.f;
+            if (!(debug & 8))
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8_t kf = *(const bf16x8_t*)(sk + (h2 * 32 + l31) * 128 + (((kk * 2 + hi) ^ swz) << 4));
@@ -113,36 +110,40 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
         // ops per element (max, fma, exp2) instead of 5
         const int key_base = t * KT + 4 * hi;
         const bool tail = (t + 1) * KT > seq_kv;
-        float mloc = -INFINITY;
+        if (!(debug & 1)) {
+            float mloc = -INFINITY;
 #pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
+            for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (tail && key_base + h2 * 32 + (r & 3) + 8 * (r >> 2) >= seq_kv) s[h2][r] = -INFINITY;
-                mloc = fmaxf(mloc, s[h2][r]);
+                for (int r = 0; r < 16; ++r) {
+                    if (tail && key_base + h2 * 32 + (r & 3) + 8 * (r >> 2) >= seq_kv) s[h2][r] = -INFINITY;
+                    mloc = fmaxf(mloc, s[h2][r]);
+                }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);  // raw-score units
+            const bool grew = m_new > m_run;
+            const float mc = m_new * c2;
+            float lsum = 0.f;
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[h2][r], c2, -mc));
+                    s[h2][r] = p;
+                    lsum += p;
+                }
+            if (__any(grew)) {  // wave-uniform: rescale only when some query's running max moved
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                m_run = m_new;
             }
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);  // raw-score units
-        const bool grew = m_new > m_run;
-        const float mc = m_new * c2;
-        float lsum = 0.f;
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[h2][r], c2, -mc));
-                s[h2][r] = p;
-                lsum += p;
-            }
-        if (__any(grew)) {  // wave-uniform: rescale only when some query's running max moved
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
-            m_run = m_new;
+            l_run += lsum;
         }
-        l_run += lsum;
-        // ---- O^T += V^T P^T ------------------------------------------------------------------------
+        // ---- O^T += V^T P^T: the contraction slot (hi*8 + e) of K-step ks is key
+        // h2*32 + st*16 + 4*hi + (e&3) + 8*(e>>2), exactly the order the score registers come out ------
+        if (!(debug & 2))
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int h2 = ks >> 1, st = ks & 1;
@@ -152,18 +153,19 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
             pu.z = pack2bf(s[h2][st * 8 + 4], s[h2][st * 8 + 5]);
             pu.w = pack2bf(s[h2][st * 8 + 6], s[h2][st * 8 + 7]);
             const bf16x8_t pb = *(bf16x8_t*)&pu;
-            const int kofs = (h2 * 32 + st * 16 + 4 * hi) * 2;  // byte offset of this lane's first key
+            // this lane's keys: k0 = h2*32 + st*16 + 4*hi (4 keys) and k0 + 8 (4 keys): 8-byte halves of
+            // 16-byte chunks c0 = k0>>3 and c0+1 of the V^T row
+            const int k0 = h2 * 32 + st * 16 + 4 * hi;
+            const int c0 = k0 >> 3, half = (k0 & 4) << 1;  // byte offset 0 / 8 inside the chunk
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const char* vp = sv + (db * 32 + l31) * VT_STRIDE + kofs;
-                const uint2 v0 = *(const uint2*)vp;         // keys base+0..3
-                const uint2 v1 = *(const uint2*)(vp + 16);  // keys base+8..11
+                const char* vrow = sv + (db * 32 + l31) * 128 + half;
+                const uint2 v0 = *(const uint2*)(vrow + ((c0 ^ swz) << 4));
+                const uint2 v1 = *(const uint2*)(vrow + (((c0 + 1) ^ swz) << 4));
                 uint4 vu = make_uint4(v0.x, v0.y, v1.x, v1.y);
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&vu, pb, o[db], 0, 0, 0);
             }
         }
-        if (t + 1 < ntile) store_tile(buf ^ 1);
-        __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
@@ -311,6 +313,9 @@ __global__ __launch_bounds__(256) void attn_temporal_probs_kernel(const bf16_t* 
 
 }  // namespace
 
+static int g_attn_debug = 0;
+extern "C" int t2v_attn_debug(int bits) { g_attn_debug = bits; return T2V_OK; }
+
 extern "C" int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, const void* vt, int ld_vt,
                                 long long vt_img_stride, void* out, int ldo, int n_img, int seq_q, int seq_kv, int heads,
                                 int kv_div, float scale, void* stream) {
@@ -324,7 +329,7 @@ extern "C" int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, 
     dim3 grid((seq_q + 127) / 128, heads, n_img);
     hipLaunchKernelGGL(attn_spatial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
                        (const bf16_t*)k, ldk, (const bf16_t*)vt, ld_vt, vt_img_stride, (bf16_t*)out, ldo, seq_q, seq_kv, heads,
-                       kv_div, scale);
+                       kv_div, scale, (const bf16_t*)t2v_zero_page(), g_attn_debug);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }

@@ -537,7 +537,9 @@ class UNetEngine(_Engine):
         def spatial_self_attn(attn, src):
             qk = self.linear(src, None, w=pk.cat_mats([attn.to_q, attn.to_k], "qk"), bias=None)
             kp = ((hw + 63) // 64) * 64
-            vt = self.buf(n_img * inner, kp, zero=True)
+            vt = self.buf(n_img * inner, kp)
+            if kp != hw:  # padding keys get P = 0 in the kernel; their V^T columns only have to be finite
+                ops.fill_zero(vt)
             # V^T[c, token] = Wv[c,:] . x[token,:]: weights as the row operand, tokens as the column operand
             ops.gemm(pk.mat(attn.to_v), src, vt, M=inner, N=hw, batch=n_img, w_strides=(hw * src.stride(0), 0),
                      o_strides=(inner * kp, 0))

