@@ -468,7 +468,8 @@ class UNetModel(nn.Module):
                 motion_cond=None, **kwargs):
         if motion_cond is not None:
             assert timestep_cond is not None
-        if x.is_cuda and not (torch.is_grad_enabled() and self._needs_grad(x, context, timestep_cond)):
+        native = getattr(self, "native_mode", "auto") != "off"  # "off": always the torch path (e.g. a train-mode student)
+        if native and x.is_cuda and not (torch.is_grad_enabled() and self._needs_grad(x, context, timestep_cond)):
             if features_adapter is not None:
                 raise NotImplementedError("features_adapter is not used by t2v-turbo and not supported natively")
             return self.native_engine()(x, timesteps, context, fps, timestep_cond, motion_cond)
