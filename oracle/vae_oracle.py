@@ -79,3 +79,33 @@ def decode_first_stage_2dae(sd, ddconfig, z, scale_factor=0.18215):
         zi = _conv(sd, "post_quant_conv", z[:, :, i], 0)  # autoencoder.py:110-113
         frames.append(decoder_forward(sd, ddconfig, zi).unsqueeze(2))
     return torch.cat(frames, dim=2)
+
+
+@torch.no_grad()
+def encoder_forward(sd, ddconfig, x, prefix="encoder"):
+    """Encoder.forward (ae_modules.py:470-503): conv_in, per level [ResnetBlock x n, Downsample with the
+    asymmetric (0,1,0,1) zero pad (ae_modules.py:98-102)], mid, GroupNorm, swish, conv_out."""
+    nres = len(ddconfig["ch_mult"])
+    nrb = ddconfig["num_res_blocks"]
+    p = prefix
+    h = _conv(sd, p + ".conv_in", x, 1)
+    for lvl in range(nres):
+        for ib in range(nrb):
+            h = resnet_block(sd, f"{p}.down.{lvl}.block.{ib}", h)
+        if lvl != nres - 1:
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[f"{p}.down.{lvl}.downsample.conv.weight"],
+                         sd[f"{p}.down.{lvl}.downsample.conv.bias"], stride=2)
+    h = resnet_block(sd, p + ".mid.block_1", h)
+    h = attn_block(sd, p + ".mid.attn_1", h)
+    h = resnet_block(sd, p + ".mid.block_2", h)
+    return _conv(sd, p + ".conv_out", _swish(_gn(sd, p + ".norm_out", h)), 1)
+
+
+@torch.no_grad()
+def encode_moments(sd, ddconfig, x):
+    """AutoencoderKL.encode up to the posterior parameters (autoencoder.py:103-108): quant_conv(encoder(x));
+    mean/logvar = chunk(2), logvar clamped to [-30, 20] (lvdm/distributions.py:24-31)."""
+    sd = {k: v.float() for k, v in sd.items()}
+    m = _conv(sd, "quant_conv", encoder_forward(sd, ddconfig, x.float()), 0)
+    mean, logvar = torch.chunk(m, 2, dim=1)
+    return m, mean, torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))

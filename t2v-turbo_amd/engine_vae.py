@@ -150,3 +150,101 @@ class VAEDecodeEngine(_Engine):
         out = self.linear(o, ab.proj_out, residual=x.t)
         self.pool.put(t, q, k, vt, s, o, x.t)
         return Act(out, n_img, x.h, x.w)
+
+
+class VAEEncodeEngine(VAEDecodeEngine):
+    """Native KL-VAE encode up to the posterior parameters: the step right before the
+    hot path in v1 training (train_t2v_turbo_v1_lora.py:957-971).  Same kernels as the decoder plus the
+    stride-2 conv with right/bottom padding (T2V_GEMM_CONV3X3_S2_PAD01); ``quant_conv`` (1x1) is folded into
+    ``conv_out`` exactly (a pointwise map after the conv)."""
+
+    def encode_frames(self, x):
+        """x (b, 3, t, H, W) -> moments (b, 2*embed, t, H/8, W/8), fp32."""
+        assert x.dim() == 5
+        self._check_weights(self.vae)
+        key = ("enc", tuple(x.shape), x.dtype, x.device)
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = self._record_enc(x)
+            self.plans[key] = plan
+        else:
+            plan["static"]["x"].copy_(x)
+            self._run(plan)
+        return plan["out"].clone()
+
+    def _record_enc(self, x):
+        ops = self.ops
+        self._begin(x.device)
+        enc = self.vae.encoder
+        b, c, t, H, W = x.shape
+        down = 2 ** (enc.num_resolutions - 1)
+        st = {"x": x.detach().clone().contiguous()}
+        out = torch.empty(b, self.vae.quant_conv.weight.shape[0], t, H // down, W // down, dtype=torch.float32, device=x.device)
+        plan = {"static": st, "out": out, "runs": 0}
+
+        def body():
+            self._forward_enc(st["x"], out)
+
+        if getattr(ops, "is_native", False):
+            ops.init()
+            ops.recording = []
+            try:
+                body()
+            finally:
+                plan["rec"] = ops.recording
+                ops.recording = None
+        else:
+            plan["fn"] = body
+            body()
+        plan["pool_bytes"] = self.pool.bytes
+        return plan
+
+    def _forward_enc(self, x, out):
+        ops, pk, vae = self.ops, self.pk, self.vae
+        enc = vae.encoder
+        b, c, t, H, W = x.shape
+        n_img = b * t
+        assert c <= 4
+        xt = self.buf(n_img * H * W, 4)
+        if c < 4:
+            ops.fill_zero(xt)  # the padded input channel meets zero weights, but must be finite
+        ops.ncfhw_to_tokens(x, xt)
+        h0 = self.buf(n_img * H * W, leaf_out_channels(enc.conv_in))
+        ops.conv_small(xt, n_img, H, W, pk.small_conv(enc.conv_in, cin_pad=4), pk.bias(enc.conv_in), h0)
+        self.pool.put(xt)
+        a = Act(h0, n_img, H, W)
+        for lvl in range(enc.num_resolutions):
+            for ib in range(enc.num_res_blocks):
+                a = self.resnet_block(enc.down[lvl].block[ib], a)
+                if len(enc.down[lvl].attn) > 0:
+                    a = self.attn_block(enc.down[lvl].attn[ib], a)
+            if lvl != enc.num_resolutions - 1:
+                ds = enc.down[lvl].downsample
+                assert ds.with_conv
+                w = pk.conv(ds.conv)
+                ho, wo = (a.h - 2) // 2 + 1, (a.w - 2) // 2 + 1
+                o = self.buf(n_img * ho * wo, w.shape[0])
+                ops.gemm(a.t, w, o, M=n_img * ho * wo, N=w.shape[0], mode=nt.GEMM_CONV3X3_S2_PAD01, n_img=n_img, h=a.h,
+                         wd=a.w, bias=pk.bias(ds.conv))
+                self.pool.put(a.t)
+                a = Act(o, n_img, ho, wo)
+        a = self.resnet_block(enc.mid.block_1, a)
+        if isinstance(enc.mid.attn_1, AttnBlock):
+            a = self.attn_block(enc.mid.attn_1, a)
+        a = self.resnet_block(enc.mid.block_2, a)
+        tt = self.gn(a, enc.norm_out, n_img, a.h * a.w, True)
+        self.pool.put(a.t)
+
+        def folded():  # quant_conv o conv_out
+            wq = vae.quant_conv.weight.detach().float().flatten(1)                       # [2e, 2z]
+            wc = enc.conv_out.weight.detach().float().permute(0, 2, 3, 1).flatten(1)     # [2z, 9*C] tap-major
+            wf = (wq @ wc).to(self.device, self.adt).contiguous()
+            bf = (wq @ enc.conv_out.bias.detach().float() + vae.quant_conv.bias.detach().float()).to(self.device).contiguous()
+            return wf, bf
+
+        wf, bf = pk._memo(("enc_out", id(enc.conv_out), id(vae.quant_conv)), folded)
+        mom = self.buf(n_img * a.h * a.w, wf.shape[0], torch.float32)
+        ops.gemm(tt, wf, mom, M=n_img * a.h * a.w, N=wf.shape[0], mode=nt.GEMM_CONV3X3, n_img=n_img, h=a.h, wd=a.w, bias=bf)
+        self.pool.put(tt)
+        ops.tokens_to_ncfhw(mom, out)
+        self.pool.put(mom)

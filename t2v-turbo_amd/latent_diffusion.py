@@ -47,10 +47,12 @@ class LatentDiffusion(nn.Module):
 
     @torch.no_grad()
     def encode_first_stage_2DAE(self, x):
-        """(b,3,t,H,W) -> scaled latents, frame by frame posterior sample (ddpm3d.py:586-600)."""
-        out = [self.scale_factor * self.first_stage_model.encode(x[:, :, i]).sample().detach().unsqueeze(2)
-               for i in range(x.shape[2])]
-        return torch.cat(out, dim=2)
+        """(b,3,t,H,W) -> scaled latent sample per frame (ddpm3d.py:586-600); the posterior parameters of
+        all frames come from one batched encoder pass, the reparameterised sample is drawn like the reference
+        (``DiagonalGaussianDistribution.sample``: CPU randn moved to the device)."""
+        from .vae import DiagonalGaussianDistribution
+        moments = self.first_stage_model.encode_moments_video(x)
+        return self.scale_factor * DiagonalGaussianDistribution(moments.to(x.dtype)).sample().detach()
 
     def get_learned_conditioning(self, c):
         if self.cond_stage_model is None:

@@ -11,6 +11,7 @@ class EngineBox:
 
     def __init__(self):
         self.engine = None
+        self.enc = None
 
     def __deepcopy__(self, memo):
         return EngineBox()

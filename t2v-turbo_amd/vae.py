@@ -249,8 +249,24 @@ class AutoencoderKL(nn.Module):
     def dtype(self):
         return self.post_quant_conv.weight.dtype
 
+    def _native_ok(self, t):
+        return t.is_cuda and not (torch.is_grad_enabled() and (t.requires_grad or any(p.requires_grad for p in self.parameters())))
+
     def encode(self, x, **kwargs):
+        if self._native_ok(x):
+            return DiagonalGaussianDistribution(self.encode_moments_video(x.unsqueeze(2)).squeeze(2).to(x.dtype))
         return DiagonalGaussianDistribution(self.quant_conv(self.encoder(x)))
+
+    def encode_moments_video(self, x):
+        """(b,3,t,H,W) -> posterior parameters (b, 2*embed, t, H/8, W/8) for all frames in one batched pass
+        (the reference encodes 8-frame chunks, train_t2v_turbo_v1_lora.py:959-966)."""
+        if self._native_ok(x):
+            if self._engine_box.enc is None:
+                from .engine_vae import VAEEncodeEngine
+                from .native import HipOps
+                self._engine_box.enc = VAEEncodeEngine(self, HipOps())
+            return self._engine_box.enc.encode_frames(x)
+        return torch.stack([self.quant_conv(self.encoder(x[:, :, i])) for i in range(x.shape[2])], dim=2)
 
     def decode(self, z, **kwargs):
         if z.is_cuda and not (torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self.parameters()))):

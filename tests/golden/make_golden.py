@@ -250,6 +250,11 @@ def main():
         zz = z / 0.18215
         video = torch.cat([ae.decode(zz[:, :, i]).unsqueeze(2) for i in range(z.shape[2])], dim=2)
     save("vae_tiny", z=z, video=video)
+    # encoder side (train_t2v_turbo_v1_lora.py:957-971: encode -> posterior.sample() * scale_factor)
+    xin = torch.randn(2, 3, 64, 64, generator=g).clamp(-1, 1)
+    with torch.no_grad():
+        post = ae.encode(xin)
+    save("vae_tiny_enc", x=xin, moments=post.parameters, mean=post.mean, std=post.std)
     cfgfull = yaml.safe_load(open(os.path.join(REF, "configs/inference_t2v_512_v2.0.yaml")))
     with torch.device("meta"):
         aef = AutoencoderKL(**cfgfull["model"]["params"]["first_stage_config"]["params"])

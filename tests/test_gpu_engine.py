@@ -158,3 +158,18 @@ def test_scheduler_step_fused_kernel_matches_torch():
         with torch.no_grad():
             prev, den = s.step(g["mout"].cuda(), i, t, g["sample"].cuda(), generator=gen, return_dict=False)
         assert rel_l2(prev.cpu(), g[f"prev_{i}"]) < 1e-5 and rel_l2(den.cpu(), g[f"den_{i}"]) < 1e-5
+
+
+def test_vae_encode_vs_reference_golden():
+    from t2v_turbo_amd.vae import AutoencoderKL
+    g = load("vae_tiny_enc")
+    ae = AutoencoderKL(ddconfig=VAE_TINY_DD, embed_dim=4).eval()
+    ae.load_state_dict(synth_state_dict(manifest("vae_tiny")), strict=True)
+    ae = ae.cuda()
+    with torch.no_grad():
+        post = ae.encode(g["x"].cuda())
+        mom = ae.encode_moments_video(g["x"].cuda().unsqueeze(0).transpose(1, 2).contiguous())
+    assert ae._engine_box.enc is not None
+    assert rel_l2(post.parameters.cpu(), g["moments"]) < E2E_TOL
+    assert rel_l2(post.mean.cpu(), g["mean"]) < E2E_TOL
+    assert rel_l2(mom[0].transpose(0, 1).cpu(), g["moments"]) < E2E_TOL
