@@ -180,6 +180,18 @@ int t2v_lcm_step(const float* x, const void* eps, int eps_dt, const float* noise
                  float sb_t, float c_skip, float c_out, float sa_p, float sb_p, long long n,
                  float* prev, float* denoised, void* stream);
 
+/* ---------------------------------------------------------------- optimizer / EMA over flat fp32 buffers
+ * Replace bitsandbytes AdamW8bit / torch AdamW on the LoRA tensors (train_t2v_turbo_v1_lora.py:765-803),
+ * accelerator.clip_grad_norm_ (:1193) and update_ema (utils/common_utils.py:307-319).
+ * t2v_adamw_step: decoupled weight decay, bias-corrected (torch.optim.AdamW semantics); grad_scale multiplies
+ * the gradient first (fold the clip coefficient in).  t2v_sumsq: out[0] = sum(x^2), deterministic two-pass;
+ * ws = workspace of >= 1024 floats. */
+int t2v_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                   void* stream);
+int t2v_ema_update(float* target, const float* src, float rate, long long n, void* stream);
+int t2v_sumsq(const float* x, long long n, float* ws, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,6 +228,89 @@ extern "C" int t2v_conv3x3_small_cin(const void* x, int n_img, int h, int w, int
     return T2V_OK;
 }
 
+// ---- optimizer / EMA over flat buffers ---------------------------------------------------------------
+namespace {
+__global__ void adamw_kernel(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
+                             float eps, float wd, float bc1, float bc2_sqrt, float gscale) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        float4 pp = *(float4*)(p + i), gg = *(const float4*)(g + i), mm = *(float4*)(m + i), vv = *(float4*)(v + i);
+        float* P = (float*)&pp; float* G = (float*)&gg; float* M = (float*)&mm; float* V = (float*)&vv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = G[e] * gscale;
+            P[e] *= 1.0f - lr * wd;
+            M[e] = b1 * M[e] + (1.0f - b1) * gr;
+            V[e] = b2 * V[e] + (1.0f - b2) * gr * gr;
+            P[e] -= (lr / bc1) * M[e] / (sqrtf(V[e]) / bc2_sqrt + eps);
+        }
+        *(float4*)(p + i) = pp; *(float4*)(m + i) = mm; *(float4*)(v + i) = vv;
+    } else {
+        for (long long j = i; j < n; ++j) {
+            const float gr = g[j] * gscale;
+            float pj = p[j] * (1.0f - lr * wd);
+            const float mj = b1 * m[j] + (1.0f - b1) * gr, vj = b2 * v[j] + (1.0f - b2) * gr * gr;
+            pj -= (lr / bc1) * mj / (sqrtf(vj) / bc2_sqrt + eps);
+            p[j] = pj; m[j] = mj; v[j] = vj;
+        }
+    }
+}
+__global__ void ema_kernel(float* t, const float* s, float rate, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = t[i] * rate + s[i] * (1.0f - rate);
+}
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* x, long long n, float* ws) {
+    __shared__ float sh[4];
+    float a = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) a += x[i] * x[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) ws[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* ws, int nblk, float* out) {
+    __shared__ double sh[256];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) a += (double)ws[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)sh[0];
+}
+}  // namespace
+
+extern "C" int t2v_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, long long n, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                              void* stream) {
+    T2V_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, T2V_EINVAL, "t2v_adamw_step");
+    T2V_REQUIRE(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0, T2V_ESHAPE,
+                "t2v_adamw_step: buffers must be 16-byte aligned");
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(nblk((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                       exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), grad_scale);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+extern "C" int t2v_ema_update(float* target, const float* src, float rate, long long n, void* stream) {
+    T2V_REQUIRE(target && src && n > 0, T2V_EINVAL, "t2v_ema_update");
+    hipLaunchKernelGGL(ema_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, target, src, rate, n);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+extern "C" int t2v_sumsq(const float* x, long long n, float* ws, float* out, void* stream) {
+    T2V_REQUIRE(x && ws && out && n > 0, T2V_EINVAL, "t2v_sumsq");
+    const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, ws);
+    T2V_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, blocks, out);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+
 // ---- library state ---------------------------------------------------------------------------------
 static thread_local char g_err[256] = "";
 void t2v_set_error(const char* msg) {

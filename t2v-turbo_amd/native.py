@@ -79,6 +79,10 @@ _SIGS = {
     "t2v_cast": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
     "t2v_lincomb3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                C.c_longlong, C.c_void_p, C.c_void_p]),
+    "t2v_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]),
+    "t2v_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_longlong, C.c_void_p]),
+    "t2v_sumsq": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2v_lcm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -275,6 +279,16 @@ class HipOps:
         ha, hb, hc = arr(*ca), (arr(*cb) if cb is not None else None), (arr(*cc) if cc is not None else None)
         self._call("t2v_lincomb3", _p(x), _p(y), _p(z), C.cast(ha, C.c_void_p), C.cast(hb, C.c_void_p) if hb else None,
                    C.cast(hc, C.c_void_p) if hc else None, nb, x.numel() // nb, _p(out), keep=(ha, hb, hc))
+
+    def adamw_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+        self._call("t2v_adamw_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2,
+                   eps, weight_decay, step, grad_scale)
+
+    def ema_update(self, target, src, rate):
+        self._call("t2v_ema_update", _p(target), _p(src), rate, target.numel())
+
+    def sumsq(self, x, ws, out):
+        self._call("t2v_sumsq", _p(x), x.numel(), _p(ws), _p(out))
 
     def lcm_step(self, x, eps, noise, sa_t, sb_t, c_skip, c_out, sa_p, sb_p, prev, denoised):
         self._call("t2v_lcm_step", _p(x), _p(eps), _DT[eps.dtype], _p(noise), sa_t, sb_t, c_skip, c_out, sa_p, sb_p,

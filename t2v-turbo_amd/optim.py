@@ -1,0 +1,78 @@
+"""Flat-buffer AdamW / gradient clip / EMA: the LoRA tensors, their gradients
+(``dist.FlatGradSync``) and the optimizer moments each live in ONE contiguous fp32 buffer, so an optimizer
+step is one fused HIP kernel (``t2v_adamw_step``) instead of bitsandbytes' CUDA-only 8-bit AdamW
+(train_t2v_turbo_v1_lora.py:765-803) or 1150 small torch launches; the clip coefficient of
+``clip_grad_norm_`` (:1193) is folded into the same pass.  On CPU tensors the same arithmetic runs in torch."""
+import torch
+
+
+class FlatAdamW:
+    def __init__(self, params, grad_sync, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.params = [p for p in params if p.requires_grad]
+        self.sync = grad_sync
+        assert sum(p.numel() for p in self.params) == grad_sync.numel
+        dev = self.params[0].device
+        self.flat_param = torch.empty(grad_sync.numel, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:  # parameters become views of the flat buffer
+                self.flat_param[off:off + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = self.flat_param[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        self.exp_avg = torch.zeros_like(self.flat_param)
+        self.exp_avg_sq = torch.zeros_like(self.flat_param)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.step_count = 0
+        self._ops = None
+        self._ws = None
+
+    def _hip(self):
+        if self._ops is None:
+            from .native import HipOps
+            self._ops = HipOps()
+            self._ws = torch.empty(1025, dtype=torch.float32, device=self.flat_param.device)
+        return self._ops
+
+    @torch.no_grad()
+    def grad_norm(self):
+        g = self.sync.flat
+        if g.is_cuda:
+            ops = self._hip()
+            ops.sumsq(g, self._ws[:1024], self._ws[1024:])
+            return self._ws[1024].sqrt()
+        return g.norm(2)
+
+    @torch.no_grad()
+    def step(self, max_grad_norm=None):
+        """One AdamW step on the (already all-reduced) flat gradient; returns the pre-clip gradient norm."""
+        self.step_count += 1
+        g = self.sync.flat
+        norm = self.grad_norm() if max_grad_norm is not None else None
+        scale = 1.0
+        if max_grad_norm is not None:
+            scale = float(torch.clamp(max_grad_norm / (norm + 1e-6), max=1.0))
+        b1, b2 = self.betas
+        if g.is_cuda:
+            self._hip().adamw_step(self.flat_param, g, self.exp_avg, self.exp_avg_sq, self.lr, b1, b2, self.eps,
+                                   self.weight_decay, self.step_count, scale)
+        else:
+            gr = g * scale
+            self.flat_param.mul_(1 - self.lr * self.weight_decay)
+            self.exp_avg.mul_(b1).add_(gr, alpha=1 - b1)
+            self.exp_avg_sq.mul_(b2).addcmul_(gr, gr, value=1 - b2)
+            bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
+            self.flat_param.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / bc2 ** 0.5 + self.eps, value=-self.lr / bc1)
+        return norm
+
+    def zero_grad(self):
+        self.sync.zero_()
+
+
+@torch.no_grad()
+def update_ema_flat(target_flat, source_flat, rate=0.99):
+    """EMA of a flat fp32 parameter buffer (utils/common_utils.py:307-319) in one kernel."""
+    if target_flat.is_cuda:
+        from .native import HipOps
+        HipOps().ema_update(target_flat, source_flat, rate)
+    else:
+        target_flat.mul_(rate).add_(source_flat, alpha=1 - rate)

@@ -173,3 +173,13 @@ def test_vae_encode_vs_reference_golden():
     assert rel_l2(post.parameters.cpu(), g["moments"]) < E2E_TOL
     assert rel_l2(post.mean.cpu(), g["mean"]) < E2E_TOL
     assert rel_l2(mom[0].transpose(0, 1).cpu(), g["moments"]) < E2E_TOL
+
+
+def test_flat_adamw_and_ema_kernels_match_torch():
+    from tests.test_optim import _run
+    from t2v_turbo_amd.optim import update_ema_flat
+    _run("cuda")
+    t, s = torch.randn(100003, device="cuda"), torch.randn(100003, device="cuda")
+    ref = t * 0.95 + s * 0.05
+    update_ema_flat(t, s, 0.95)
+    assert torch.allclose(t, ref, rtol=1e-6, atol=1e-7)

@@ -1,0 +1,36 @@
+"""FlatAdamW (CPU arithmetic) == torch.optim.AdamW step for step; parameters stay views of the flat buffer."""
+import torch
+
+from t2v_turbo_amd.dist import FlatGradSync
+from t2v_turbo_amd.optim import FlatAdamW, update_ema_flat
+
+
+def _run(device):
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(7, 5, device=device)), torch.nn.Parameter(torch.randn(33, device=device))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    sync = FlatGradSync(ps)
+    opt = FlatAdamW(ps, sync, lr=1e-2, weight_decay=0.05)
+    ropt = torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.05)
+    for it in range(4):
+        gs = [torch.randn_like(p) * (it + 1) for p in ps]
+        sync.zero_()
+        for p, r, g in zip(ps, ref, gs):
+            p.grad.copy_(g)
+            r.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        ropt.step()
+        norm = opt.step(max_grad_norm=1.0)
+        total = torch.sqrt(sum((g ** 2).sum() for g in gs))
+        assert abs(float(norm) - float(total)) < 1e-4 * float(total)
+    for p, r in zip(ps, ref):
+        assert torch.allclose(p.detach(), r.detach(), rtol=2e-5, atol=2e-6)
+        assert p.data_ptr() >= opt.flat_param.data_ptr()
+    return opt
+
+
+def test_flat_adamw_matches_torch_on_cpu():
+    _run("cpu")
+    t, s = torch.ones(10), torch.zeros(10)
+    update_ema_flat(t, s, 0.9)
+    assert torch.allclose(t, torch.full((10,), 0.9))
