@@ -25,6 +25,7 @@
 //  * workgroup id -> tile mapping is XCD-aware: each of the 8 XCDs (private L2s) gets a contiguous
 //    run of tiles, N-tile fastest, so the tiles that share an A panel hit the same L2.
 #include "common.h"
+#include <type_traits>
 
 struct GemmParams {
     t2v_gemm_desc d;
@@ -39,6 +40,16 @@ struct GemmParams {
     float* ws;         // split-K partials [splits][M][N]
     int debug;         // ablation bits (tools only): 1 = skip DMA in the main loop, 2 = skip MFMA, 4 = skip epilogue
 };
+
+// Ablation switches (tools only): a -DT2V_GEMM_ABLATE build honours GemmParams::debug bits inside the main loop
+// (1 = no DMA, 2 = no MFMA, 8 = no LDS fragment reads, 16 = no barrier, 4 = no epilogue).  The product build
+// compiles them out: runtime branches inside the K loop split its basic block and cost ~20 % (exact s_waitcnt
+// counts and the MFMA / ds_read interleave both need straight-line code).
+#ifdef T2V_GEMM_ABLATE
+#define ABL(bit) (p.debug & (bit))
+#else
+#define ABL(bit) false
+#endif
 
 namespace {
 
@@ -153,16 +164,22 @@ struct Epi {
     }
 };
 
-template <int BM, int BN, int WM, int WN, int STAGES>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
+// BK = K elements per pipeline step (LDS rows of BK*2 bytes); WPE = waves per SIMD the register budget is
+// sized for (2 x 4-wave workgroups or one 8-wave workgroup per CU at WPE = 2)
+template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4>
+__global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
-    constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;  // DMA wave-instructions per wave per stage
+    constexpr int ROWB = BK * 2;       // bytes per LDS row
+    constexpr int CPR = ROWB / 16;     // 16-byte chunks per row
+    constexpr int RPI = 64 / CPR;      // tile rows filled by one wave-wide 1 KiB DMA
+    constexpr int A_IT = BM / RPI / NW, B_IT = BN / RPI / NW;  // DMA wave-instructions per wave per stage
     constexpr int LOADS = A_IT + B_IT;
-    constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+    constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
+    static_assert(BK == 64 || BK == 32, "BK");
     static_assert(A_IT >= 1 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
-    static_assert(LOADS * (STAGES - 2) < 64, "vmcnt field");
+    static_assert(LOADS * (STAGES - 1) < 64, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const t2v_gemm_desc& d = p.d;
@@ -194,15 +211,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     const int nk = kt_end - kt_begin;
 
     // ---- per-lane DMA row bookkeeping -----------------------------------------------------------
-    // wave-instruction i (= wave + NW*j) fills tile rows [8i, 8i+8): lane -> row 8i + (lane>>3),
-    // 16-byte slot (lane&7) of that row, which holds source chunk (lane&7) ^ swz(row).
+    // wave-instruction i (= wave + NW*j) fills tile rows [RPI*i, RPI*(i+1)): lane -> row RPI*i + lane/CPR,
+    // 16-byte slot lane%CPR of that row, which holds source chunk slot ^ swz(row)
+    // (swz(row) = (row>>1)&7 for 128-byte rows, (row>>2)&3 for 64-byte rows: conflict-free ds_read_b128).
+    auto swz_of = [](int r) { return BK == 64 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
     const int H = p.gh, W = p.gw;
     int a_n[A_IT], a_y[A_IT], a_x[A_IT];  // decomposed output coordinates (a_n < 0: row >= M)
     int a_chunk[A_IT];
 #pragma unroll
     for (int j = 0; j < A_IT; ++j) {
-        const int r = (wave + NW * j) * 8 + (lane >> 3);
-        a_chunk[j] = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        const int r = (wave + NW * j) * RPI + lane / CPR;
+        a_chunk[j] = ((lane % CPR) ^ swz_of(r)) * 8;
         const int m = m0 + r;
         if (m >= d.M) {
             a_n[j] = -1; a_y[j] = 0; a_x[j] = 0;
@@ -218,19 +237,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     int winc[B_IT];
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
-        const int r = (wave + NW * j) * 8 + (lane >> 3);
-        const int chunk = ((lane & 7) ^ ((r >> 1) & 7)) * 8;
+        const int r = (wave + NW * j) * RPI + lane / CPR;
+        const int chunk = ((lane % CPR) ^ swz_of(r)) * 8;
         // LDS row r of the weight tile holds channel perm(r): within each 32-row MFMA tile the rows a
         // lane's 16 accumulator registers cover ((q&3) + 8*(q>>2) + 4*hi) are fed 16 CONSECUTIVE
         // channels (16*hi + q), so the epilogue moves 32-byte runs per lane, 64 bytes per row
         const int r32 = r & 31;
         const int n = n0 + (r & ~31) + ((((r32 >> 2) & 1) << 4) | ((r32 >> 3) << 2) | (r32 & 3));
-        if (n < d.N) { wptr[j] = wbase + (long long)n * d.ldw + chunk + (long long)kt_begin * 64; winc[j] = 64; }
+        if (n < d.N) { wptr[j] = wbase + (long long)n * d.ldw + chunk + (long long)kt_begin * BK; winc[j] = BK; }
         else { wptr[j] = zero; winc[j] = 0; }
     }
 
     // staging iterator: segment = (tap, source); starts at K step kt_begin
-    const int steps0 = d.c0 >> 6, steps1 = d.c1 >> 6, steps_tap = steps0 + steps1;
+    const int steps0 = d.c0 / BK, steps1 = d.c1 / BK, steps_tap = steps0 + steps1;
     int seg, seg_left, seg_skip;
     {
         const int tap = kt_begin / steps_tap, rem = kt_begin - tap * steps_tap;
@@ -249,13 +268,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
             const int uy = a_y[j] * p.stride + ky - p.pad_y, ux = a_x[j] * p.stride + kx - p.pad_x;
             const bool ok = a_n[j] >= 0 && uy >= 0 && uy < (H << p.ups) && ux >= 0 && ux < (W << p.ups);
             const long long row = ((long long)a_n[j] * H + (uy >> p.ups)) * W + (ux >> p.ups);
-            if (ok) { aptr[j] = base + row * ld + a_chunk[j] + seg_skip * 64; ainc[j] = 64; }
+            if (ok) { aptr[j] = base + row * ld + a_chunk[j] + seg_skip * BK; ainc[j] = BK; }
             else { aptr[j] = zero; ainc[j] = 0; }
         }
         seg_skip = 0;
     };
-    auto stage = [&](int buf) {
-        char* sa = smem + buf * STAGE_BYTES;
+    // DMAs of one K step into ring slot `slot` + pointer advance (segment bookkeeping stays OUTSIDE the hot loop)
+    auto issue = [&](int slot) {
+        char* sa = smem + slot * STAGE_BYTES;
         char* sb = sa + A_BYTES;
 #pragma unroll
         for (int j = 0; j < A_IT; ++j) dma16(aptr[j], sa + (wave + NW * j) * 1024);
@@ -265,11 +285,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
         for (int j = 0; j < A_IT; ++j) aptr[j] += ainc[j];
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) wptr[j] += winc[j];
-        if (--seg_left == 0) { ++seg; if (seg < p.taps * p.nsrc) begin_segment(); }
+    };
+    auto next_segment_if_done = [&]() {
+        if (seg_left == 0) { ++seg; if (seg < p.taps * p.nsrc) begin_segment(); }
     };
 
     // ---- fragment read addressing ---------------------------------------------------------------
-    const int frow = lane & 31, hi = lane >> 5, swz = (lane >> 1) & 7;
+    const int frow = lane & 31, hi = lane >> 5, swz = swz_of(frow);
     f32x16_t acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -278,66 +300,121 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    begin_segment();
+    // ---- software-pipelined K loop ------------------------------------------------------------------
+    // Ring of STAGES slots, all filled by the prologue.  Fragments are double-buffered in registers (fa/fw[2]):
+    // the ds_read_b128s of K-slice kk+1 are issued BEFORE the MFMAs of slice kk and land under them.  The
+    // hand-over to the next K step happens before the LAST slice's MFMAs: wait for my own DMAs of step kt+1
+    // (counted vmcnt: YOUNGER later slots stay in flight), s_barrier (now step kt+1 is visible from every wave
+    // and slot kt is drained by every wave), slice-0 fragments of step kt+1 are read, the DMAs of step kt+STAGES
+    // go out into the freed slot interleaved with the last slice's MFMAs.  So neither LDS latency nor DMA issue
+    // is ever exposed inside the loop.  Each step body is ONE basic block (segment bookkeeping sits outside):
+    // exact counted s_waitcnt and a fixed issue order (sched_barrier fences) depend on that.
+    int buf = 0;
+    bf16x8_t fa[2][TM], fw[2][TN];
+    auto read_frags = [&](int slot, int kk, int which) {
+        const char* sa = smem + slot * STAGE_BYTES + (wave_m * WTM + frow) * ROWB;
+        const char* sb = smem + slot * STAGE_BYTES + A_BYTES + (wave_n * WTN + frow) * ROWB;
+        const int coff = ((kk * 2 + hi) ^ swz) << 4;
+        if (ABL(8)) {
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nk) stage(s);
-    int buf = 0, fill = (STAGES - 1) % STAGES;
-    for (int kt = 0; kt < nk; ++kt) {
-        // tile kt must have landed; up to STAGES-2 younger tiles may stay in flight
-        const int younger = min(STAGES - 2, nk - 1 - kt);
-        if (STAGES >= 4 && younger == 2) wait_vmcnt<LOADS * 2>();
-        else if (STAGES >= 3 && younger == 1) wait_vmcnt<LOADS>();
-        else wait_vmcnt<0>();
-        if (!(p.debug & 16)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char* sa = smem + buf * STAGE_BYTES + (wave_m * WTM + frow) * 128;
-        const char* sb = smem + buf * STAGE_BYTES + A_BYTES + (wave_n * WTN + frow) * 128;
-        // fragments are double-buffered in registers: the ds_read_b128s of K-slice kk+1 are issued
-        // before the MFMAs of slice kk, and slice 0's reads before the DMA issue of the next tile
-        bf16x8_t fa[2][TM], fw[2][TN];
-        if (p.debug & 8) {  // ablation: no LDS reads, operands = whatever (kept live through asm)
+            for (int i = 0; i < TM; ++i) { fa[which][i] = (bf16x8_t){0}; asm volatile("" : "+v"(fa[which][i])); }
 #pragma unroll
-            for (int i = 0; i < TM; ++i) { fa[0][i] = (bf16x8_t){0}; fa[1][i] = (bf16x8_t){0}; asm volatile("" : "+v"(fa[0][i]), "+v"(fa[1][i])); }
+            for (int j = 0; j < TN; ++j) { fw[which][j] = (bf16x8_t){0}; asm volatile("" : "+v"(fw[which][j])); }
+            return;
+        }
 #pragma unroll
-            for (int j = 0; j < TN; ++j) { fw[0][j] = (bf16x8_t){0}; fw[1][j] = (bf16x8_t){0}; asm volatile("" : "+v"(fw[0][j]), "+v"(fw[1][j])); }
+        for (int i = 0; i < TM; ++i) fa[which][i] = *(const bf16x8_t*)(sa + i * 32 * ROWB + coff);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fw[which][j] = *(const bf16x8_t*)(sb + j * 32 * ROWB + coff);
+    };
+    // MFMAs [first, last) of one K slice in (i, j) order
+    auto mfmas = [&](int which, int first, int last) {
+        if (ABL(2)) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                if (i * TN + j >= first && i * TN + j < last)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[which][j], fa[which][i], acc[i][j], 0, 0, 0);
+    };
+    constexpr int NS = BK / 16;  // K slices (one MFMA deep) per step
+    constexpr int NM = TM * TN;  // MFMAs per slice
+    // ISSUE: stage step kt+STAGES into the slot this step frees.  NEXT: there is a step kt+1 (hand-over).
+    // Issue order per slice: first MFMA (the compiler's wait for this slice's fragments is lgkmcnt(0), exact here
+    // because nothing younger is outstanding), THEN the next slice's ds_reads, then the other NM-1 MFMAs which
+    // cover the LDS latency.
+    auto kstep = [&](auto issue_tag, auto next_tag, auto younger) {
+        constexpr bool ISSUE = decltype(issue_tag)::value, NEXT = decltype(next_tag)::value;
+#pragma unroll
+        for (int kk = 0; kk < NS - 1; ++kk) {
+            mfmas(kk & 1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(buf, kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(kk & 1, 1, NM);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int nxt = (buf + 1 == STAGES) ? 0 : buf + 1;
+        if constexpr (NEXT) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of this slot have landed
+            wait_vmcnt<LOADS * decltype(younger)::value>();       // my DMAs of step kt+1 have landed
+            if (!ABL(16)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            mfmas((NS - 1) & 1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(nxt, 0, 0);  // NS is even: slice 0 always lives in fragment set 0
+            __builtin_amdgcn_sched_barrier(0);
         } else {
-            const int coff = (hi ^ swz) << 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[0][i] = *(const bf16x8_t*)(sa + i * 32 * 128 + coff);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fw[0][j] = *(const bf16x8_t*)(sb + j * 32 * 128 + coff);
+            mfmas((NS - 1) & 1, 0, 1);
         }
-        if (kt + STAGES - 1 < nk && !(p.debug & 1)) stage(fill);
-        if (!(p.debug & 2))
+        if constexpr (ISSUE) {
+            if (!ABL(1)) issue(buf);
+        }
+        mfmas((NS - 1) & 1, 1, NM);
+        if constexpr (ISSUE) {  // spread the DMA issue over the last slice's MFMAs
+            constexpr int PER = (LOADS + NM - 2) / (NM - 1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk < 3 && !(p.debug & 8)) {
-                const int coff = (((kk + 1) * 2 + hi) ^ swz) << 4;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[(kk + 1) & 1][i] = *(const bf16x8_t*)(sa + i * 32 * 128 + coff);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fw[(kk + 1) & 1][j] = *(const bf16x8_t*)(sb + j * 32 * 128 + coff);
+            for (int q = 0; q < NM - 1; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, PER, 0);
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[kk & 1][j], fa[kk & 1][i], acc[i][j], 0, 0, 0);
-            // pin the issue order: all ds_reads of slice kk+1 first, then the MFMAs of slice kk, so the LDS
-            // latency hides under a full slice of matrix work (and the two fragment sets stay distinct)
-            // (the compiler's wait before the first MFMA of a slice is lgkmcnt(0): issuing the next slice's
-            // reads right AFTER that MFMA keeps the wait exact and gives them TM*TN-1 MFMAs to land)
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (kk < 3) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - 1, 0);
         }
-        buf = (buf + 1 == STAGES) ? 0 : buf + 1;
-        fill = (fill + 1 == STAGES) ? 0 : fill + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        buf = nxt;
+    };
+    using std::integral_constant;
+    constexpr integral_constant<bool, true> kYes{};
+    constexpr integral_constant<bool, false> kNo{};
+
+    // prologue: fill the whole ring (steps 0 .. STAGES-1)
+    begin_segment();
+    int staged = 0;
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s)
+        if (s < nk) { issue(s); --seg_left; ++staged; if (staged < nk) next_segment_if_done(); }
+    if (nk >= STAGES) wait_vmcnt<LOADS*(STAGES - 1)>();
+    else wait_vmcnt<0>();
+    if (!ABL(16)) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(0, 0, 0);
+    // steady state: per (tap, source) segment a branch-free run of steps, each computing step kt and staging kt+STAGES
+    int remaining = nk - staged;
+    while (remaining > 0) {
+        const int n = min(seg_left, remaining);
+        for (int i = 0; i < n; ++i) kstep(kYes, kYes, integral_constant<int, STAGES - 2>{});
+        remaining -= n;
+        seg_left -= n;
+        if (remaining > 0) next_segment_if_done();
     }
+    // drain: the last min(nk, STAGES) steps have nothing left to stage; step t of them leaves tail-2-t slots in flight
+    const int tail = min(nk, STAGES);
+    if constexpr (STAGES >= 4) { if (tail >= 4) kstep(kNo, kYes, integral_constant<int, 2>{}); }
+    if constexpr (STAGES >= 3) { if (tail >= 3) kstep(kNo, kYes, integral_constant<int, 1>{}); }
+    if (tail >= 2) kstep(kNo, kYes, integral_constant<int, 0>{});
+    kstep(kNo, kNo, integral_constant<int, 0>{});
 
     // ---- epilogue straight from the accumulators: lane = token (frow), regs = 4-channel runs -------
-    if ((p.debug & 4) && acc[0][0][0] != 12345.678f) return;
+    if (ABL(4) && acc[0][0][0] != 12345.678f) return;
     const int ch_lane = n0 + wave_n * WTN + 16 * hi;
     if (p.splits > 1) {  // raw fp32 partial slab; the reduce kernel applies the epilogue
         float* ws = p.ws + ((long long)(z * p.splits + split) * d.M) * d.N;
@@ -418,18 +495,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     epi.run(v, nullptr, gm, ch, ch);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4>
 int launch(GemmParams& p, hipStream_t s) {
     p.tiles_m = (p.d.M + BM - 1) / BM;
     p.tiles_n = (p.d.N + BN - 1) / BN;
     dim3 grid(p.tiles_m * p.tiles_n, p.d.batch, p.splits);
-    constexpr int smem = STAGES * (BM + BN) * 128;
+    constexpr int smem = STAGES * (BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES>), grid, dim3(WM * WN * 64), smem, s, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE>), grid, dim3(WM * WN * 64), smem, s, p);
     T2V_CHECK_LAUNCH();
     if (p.splits > 1) {
         const long long work = (long long)p.d.M * ((p.d.N + 15) / 16);
@@ -439,14 +516,17 @@ int launch(GemmParams& p, hipStream_t s) {
     return T2V_OK;
 }
 
-struct TileCfg { int bm, bn, wtn; };
+struct TileCfg { int bm, bn, wtn, bk = 64; };
 // id -> (BM, BN, per-wave N width); waves / stages: see dispatch()
 const TileCfg kCfg[] = {{0, 0, 0},      {128, 128, 64}, {128, 64, 32},  {256, 64, 64}, {128, 128, 64},
                         {128, 64, 32},  {256, 128, 64}, {256, 128, 64}, {64, 128, 32}, {256, 64, 32},
                         {128, 128, 64}, {128, 256, 64},
                         // 128x64 (tokens x channels) wave tiles: 25 % fewer LDS reads per MFMA than 64x64
-                        {256, 256, 64}, {256, 128, 64}, {128, 256, 64}, {256, 256, 64}};
-constexpr int kNumCfg = 15;  // (a 4-wave 128x128-wave-tile variant spills: 3 KB/lane scratch, 72 TF/s - dropped)
+                        {256, 256, 64}, {256, 128, 64}, {128, 256, 64}, {256, 256, 64},
+                        // 32-deep K steps (64-byte LDS rows): <= 80 KiB of LDS and <= 256 VGPRs per 4-wave workgroup, so TWO
+                        // workgroups share a CU and one's prologue / barriers / epilogue hide under the other's MFMAs
+                        {256, 128, 64, 32}, {128, 256, 64, 32}, {128, 128, 64, 32}, {256, 128, 64, 32}};
+constexpr int kNumCfg = 19;  // (a 4-wave 128x128-wave-tile variant spills: 3 KB/lane scratch, 72 TF/s - dropped)
 
 int dispatch(int cfg, GemmParams& p, hipStream_t s) {
     switch (cfg) {
@@ -465,6 +545,10 @@ int dispatch(int cfg, GemmParams& p, hipStream_t s) {
         case 13: return launch<256, 128, 2, 2, 2>(p, s);
         case 14: return launch<128, 256, 1, 4, 2>(p, s);
         case 15: return launch<256, 256, 4, 2, 2>(p, s);
+        case 16: return launch<256, 128, 2, 2, 3, 32, 2>(p, s);
+        case 17: return launch<128, 256, 1, 4, 3, 32, 2>(p, s);
+        case 18: return launch<128, 128, 2, 2, 4, 32, 2>(p, s);
+        case 19: return launch<256, 128, 4, 2, 3, 32, 4>(p, s);
         default: return T2V_EINVAL;
     }
 }
@@ -519,7 +603,7 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     }
     T2V_REQUIRE((long long)d.M == (long long)n_grid * p.h_out * p.w_out, T2V_EINVAL, "t2v_gemm: M does not match the geometry");
     p.K = p.taps * (d.c0 + d.c1);
-    p.nk = p.K / 64;
+    p.nk = p.K / 64;  // refined below once the tile config (BK) is known
     T2V_REQUIRE(d.ldw >= p.K, T2V_EINVAL, "t2v_gemm: ldw < K");
     if (d.act == T2V_ACT_GEGLU) T2V_REQUIRE(d.N % 128 == 0, T2V_ESHAPE, "t2v_gemm: GEGLU needs N % 128 == 0");
     if (d.rowvec) T2V_REQUIRE(d.rowvec_div > 0, T2V_EINVAL, "t2v_gemm: rowvec_div");
@@ -541,15 +625,16 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
         else cfg = 5;
     }
     if (d.act == T2V_ACT_GEGLU && kCfg[cfg].wtn < 64) cfg = 4;  // value+gate pairs need a 64-wide wave tile in N
+    p.nk = p.K / kCfg[cfg].bk;
     // ---- split-K: only when the grid cannot fill the chip and K is deep ----------------------------------
     int splits = g_force_split ? g_force_split : d.split_k;
     const long long tiles = (long long)((d.M + kCfg[cfg].bm - 1) / kCfg[cfg].bm) * ((d.N + kCfg[cfg].bn - 1) / kCfg[cfg].bn) * d.batch;
     const bool can_split = d.ws && d.act != T2V_ACT_GEGLU && d.N % 4 == 0 && p.vec4;
     if (splits <= 0) {
         splits = 1;
-        if (can_split && tiles < 160 && p.nk >= 16) {
+        if (can_split && tiles < 160 && p.K / 64 >= 16) {
             splits = (int)((448 + tiles - 1) / tiles);
-            if (splits > p.nk / 8) splits = p.nk / 8;
+            if (splits > p.K / 512) splits = p.K / 512;
             if (splits > 16) splits = 16;
         }
     }

@@ -1,0 +1,108 @@
+#!/usr/bin/env python
+"""Per-shape device time of every t2v_gemm launch of the UNet step, measured inside a hipGraph (R back-to-back
+launches of the recorded descriptor, so no host launch overhead), next to a plain hipBLASLt GEMM of the same
+(M, N, K) via torch.mm and the two roofline floors (MFMA 2.5 PF/s dense bf16, HBM 8 TB/s on algorithmic bytes).
+
+    python tools/gemm_profile_graph.py [--blas 1] [--out gpurun_out/gemm_profile.csv]
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def graph_time(fn, reps=20, replays=4):
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(replays):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blas", type=int, default=1)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "gemm_profile.csv"))
+    args = ap.parse_args()
+    import bench
+    from t2v_turbo_amd import native as nt
+
+    dev = torch.device("cuda", 0)
+    model = bench.build_model(dev, torch.bfloat16)
+    x, ctx, tc = bench.synth_inputs(dev, torch.bfloat16)
+    with torch.no_grad():
+        model(x, torch.tensor([999], device=dev), context=ctx, fps=16, timestep_cond=tc)
+    rec = next(iter(model.native_engine().plans.values()))["rec"]
+    seen = {}
+    for fn, a, name in rec:
+        if name != "t2v_gemm":
+            continue
+        d = a[0]._obj
+        taps = {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(d.mode, 9)
+        K = taps * (d.c0 + d.c1)
+        key = (d.mode, d.M, d.N, K, max(d.batch, 1), d.act, bool(d.residual), bool(d.rowvec))
+        if key in seen:
+            seen[key][0] += 1
+        else:
+            seen[key] = [1, fn, a, d]
+    rows = []
+    for key, (count, fn, a, d) in seen.items():
+        mode, M, N, K, batch, act, has_res, has_rv = key
+        s = torch.cuda.current_stream().cuda_stream
+        us = graph_time(lambda: fn(*a, torch.cuda.current_stream().cuda_stream))
+        n_out = N // 2 if act == nt.ACT_GEGLU else N
+        flops = 2.0 * M * N * K * batch
+        src_rows = M if mode in (nt.GEMM_LINEAR, nt.GEMM_CONV3X3, nt.GEMM_TCONV3) else (M * 4 if "S2" in str(mode) else M)
+        if mode in (nt.GEMM_CONV3X3_S2, nt.GEMM_CONV3X3_S2_PAD01):
+            src_rows = M * 4
+        elif mode == nt.GEMM_CONV3X3_UP2:
+            src_rows = M // 4
+        cin = d.c0 + d.c1
+        byts = batch * (src_rows * cin * 2 + N * K * 2 + M * n_out * 2 * (2 if has_res else 1))
+        us_blas = None
+        if args.blas and batch == 1:
+            A = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
+            B = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
+            Cc = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+            try:
+                us_blas = graph_time(lambda: torch.mm(A, B.t(), out=Cc), reps=10, replays=3)
+            except Exception as e:  # noqa
+                us_blas = None
+            del A, B, Cc
+        rows.append(dict(mode=mode, M=M, N=N, K=K, batch=batch, act=act, res=int(has_res), rv=int(has_rv), count=count,
+                         us=round(us, 2), total_ms=round(us * count / 1e3, 3), tflops=round(flops / us / 1e6, 1),
+                         us_blas=None if us_blas is None else round(us_blas, 2),
+                         us_mfma_floor=round(flops / 2.5e15 * 1e6, 2), us_hbm_floor=round(byts / 8e12 * 1e6, 2)))
+        print(rows[-1], flush=True)
+    rows.sort(key=lambda r: -r["total_ms"])
+    tot = sum(r["total_ms"] for r in rows)
+    floor = sum(max(r["us_mfma_floor"], r["us_hbm_floor"]) * r["count"] for r in rows) / 1e3
+    blas = sum((r["us_blas"] or r["us"]) * r["count"] for r in rows) / 1e3
+    print(f"GEMM per UNet step: {tot:.2f} ms in-graph; roofline floor {floor:.2f} ms; plain hipBLASLt GEMMs of the same MNK {blas:.2f} ms")
+    os.makedirs(os.path.dirname(args.out), exist_ok=True)
+    with open(args.out, "w") as f:
+        f.write(f"# GEMM per UNet step: {tot:.2f} ms in-graph; roofline floor {floor:.2f} ms; hipBLASLt same-MNK {blas:.2f} ms\n")
+        cols = list(rows[0].keys())
+        f.write(",".join(cols) + "\n")
+        for r in rows:
+            f.write(",".join("" if r[c] is None else str(r[c]) for c in cols) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -20,20 +20,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def time_desc(lib, fn, args, stream, cfg, split, iters=8):
+def time_desc(lib, fn, args, stream, cfg, split, iters=10):
+    """Device time per launch, measured inside a hipGraph (no host launch overhead in the number)."""
     lib.t2v_gemm_force_config(cfg)
     lib.t2v_gemm_force_split(split)
     try:
-        for _ in range(2):
-            if fn(*args, stream) != 0:
-                return None
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn(*args, stream)
-        e1.record()
+        if fn(*args, torch.cuda.current_stream().cuda_stream) != 0:
+            return None
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / iters
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                fn(*args, torch.cuda.current_stream().cuda_stream)
+        g.replay()
+        torch.cuda.synchronize()
+        best = 1e30
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+        return best
     finally:
         lib.t2v_gemm_force_config(0)
         lib.t2v_gemm_force_split(0)
