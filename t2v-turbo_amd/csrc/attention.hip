@@ -7,11 +7,20 @@
 //   the online-softmax max/sum are lane-local plus one 32-lane exchange, and the probabilities are
 //   already in B-operand position for O^T += V^T P^T — the MFMA contraction index is simply
 //   enumerated in the order the score registers come out, and V^T is read from LDS in that order,
-//   so P never goes through LDS or cross-lane shuffles.
+//   so P never goes through LDS or cross-lane shuffles (K rows sit in LDS with bits 2/3 of the key index
+//   swapped, which makes each lane's 8 contraction keys one contiguous 16-byte chunk of V^T).
 // attn_temporal_kernel: the sequence is the F (=16) frames of one pixel; one wave per
 //   (clip, pixel, head), rows fetched with the frame stride straight from the token-major
 //   buffers (no rearrange copies); tiny FLOPs, bandwidth bound.
 #include "common.h"
+
+// ablation bits (tools/attn_one.py --debug) only exist in a -DT2V_ATTN_ABLATE build: runtime branches inside the
+// KV loop split its basic block (inexact s_waitcnt, no MFMA / VALU interleave)
+#ifdef T2V_ATTN_ABLATE
+#define ATT_ABL(bit) (debug & (bit))
+#else
+#define ATT_ABL(bit) false
+#endif
 
 namespace {
 
@@ -29,7 +38,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base)
 // XOR-swizzled by (row>>1)&7, are filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
 // ds_write): 16 wave-instructions per tile pair, 4 per wave.  Keys past seq_kv: K rows come from a zero
 // page; the V^T buffer's padding columns must be finite (the engine zero-fills them) since their P is 0.
-__global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restrict__ q, int ldq,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_spatial_kernel(const bf16_t* __restrict__ q, int ldq,
                                                            const bf16_t* __restrict__ k, int ldk,
                                                            const bf16_t* __restrict__ vt, int ld_vt, long long vt_img_stride,
                                                            bf16_t* __restrict__ out, int ldo, int seq_q, int seq_kv,
@@ -70,7 +79,10 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
         const int key0 = t * KT;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int key = key0 + drow[j];
+            // LDS row r of the K tile holds key perm(r) = r with bits 2 and 3 swapped: the 8 score registers a lane
+            // feeds into one PV K-step (rows {4hi + 0..3, 8 + 4hi + 0..3} of a 16-row group) are then 8 CONSECUTIVE
+            // keys, i.e. one aligned 16-byte chunk of the V^T row (a single ds_read_b128 per fragment)
+            const int key = key0 + ((drow[j] & ~12) | ((drow[j] & 4) << 1) | ((drow[j] & 8) >> 1));
             const bf16_t* ksrc = key < seq_kv ? kbase + (long long)key * ldk + dchunk[j] : zero;
             dma16(ksrc, sk + (wave + 4 * j) * 1024);
             dma16(vbase + (long long)drow[j] * ld_vt + key0 + dchunk[j], sv + (wave + 4 * j) * 1024);
@@ -88,35 +100,50 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
     for (int t = 0; t < ntile; ++t) {
         const int buf = t & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(debug & 16)) __syncthreads();
-        if (t + 1 < ntile && !(debug & 4)) stage(t + 1, buf ^ 1);
+        if (!ATT_ABL(16)) __syncthreads();
+        if (t + 1 < ntile && !ATT_ABL(4)) stage(t + 1, buf ^ 1);
         const char* sk = smem + buf * AT_STAGE;
         const char* sv = sk + K_TILE_BYTES;
-        // ---- S^T = K Q^T ------------------------------------------------------------------------
+        // ---- S^T = K Q^T: all 8 K fragments are read up front (one batch of ds_read_b128, counted waits) so the
+        // MFMAs run back to back instead of read -> wait -> MFMA eight times -------------------------------
         f32x16_t s[2];
+        bf16x8_t kf[2][4];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                kf[h2][kk] = *(const bf16x8_t*)(sk + (h2 * 32 + l31) * 128 + (((kk * 2 + hi) ^ swz) << 4));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[h2][r] = 0.f;
-            if (!(debug & 8))
+            if (!ATT_ABL(8))
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8_t kf = *(const bf16x8_t*)(sk + (h2 * 32 + l31) * 128 + (((kk * 2 + hi) ^ swz) << 4));
-                s[h2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[h2], 0, 0, 0);
-            }
+            for (int kk = 0; kk < 4; ++kk) s[h2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[h2][kk], qf[kk], s[h2], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // V^T fragments for the PV product: issued now, they land under the softmax VALU work.  K-step ks = 2*h2 + st
+        // contracts keys h2*32 + st*16 + 8*hi + 0..7 = chunk 4*h2 + 2*st + hi of the V^T row.
+        bf16x8_t vfr[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                vfr[ks][db] = *(const bf16x8_t*)(sv + (db * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
+        __builtin_amdgcn_sched_barrier(0);
         // ---- online softmax (this lane: one query, 32 of the 64 keys; partner lane^32 the rest) ---
         // scores stay raw; max is taken on them and exp2(fma(s, c, -c*max)) folds scale*log2(e): 3 VALU
         // ops per element (max, fma, exp2) instead of 5
-        const int key_base = t * KT + 4 * hi;
+        const int key_base = t * KT + 8 * hi;  // register r of half h2 is key key_base + h2*32 + (r>>3)*16 + (r&7)
         const bool tail = (t + 1) * KT > seq_kv;
-        if (!(debug & 1)) {
+        if (!ATT_ABL(1)) {
             float mloc = -INFINITY;
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (tail && key_base + h2 * 32 + (r & 3) + 8 * (r >> 2) >= seq_kv) s[h2][r] = -INFINITY;
+                    if (tail && key_base + h2 * 32 + (r >> 3) * 16 + (r & 7) >= seq_kv) s[h2][r] = -INFINITY;
                     mloc = fmaxf(mloc, s[h2][r]);
                 }
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
@@ -141,9 +168,8 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
             }
             l_run += lsum;
         }
-        // ---- O^T += V^T P^T: the contraction slot (hi*8 + e) of K-step ks is key
-        // h2*32 + st*16 + 4*hi + (e&3) + 8*(e>>2), exactly the order the score registers come out ------
-        if (!(debug & 2))
+        // ---- O^T += V^T P^T: the score registers already come out in contraction order ----------------------
+        if (!ATT_ABL(2))
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int h2 = ks >> 1, st = ks & 1;
@@ -153,18 +179,8 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const bf16_t* __restr
             pu.z = pack2bf(s[h2][st * 8 + 4], s[h2][st * 8 + 5]);
             pu.w = pack2bf(s[h2][st * 8 + 6], s[h2][st * 8 + 7]);
             const bf16x8_t pb = *(bf16x8_t*)&pu;
-            // this lane's keys: k0 = h2*32 + st*16 + 4*hi (4 keys) and k0 + 8 (4 keys): 8-byte halves of
-            // 16-byte chunks c0 = k0>>3 and c0+1 of the V^T row
-            const int k0 = h2 * 32 + st * 16 + 4 * hi;
-            const int c0 = k0 >> 3, half = (k0 & 4) << 1;  // byte offset 0 / 8 inside the chunk
 #pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const char* vrow = sv + (db * 32 + l31) * 128 + half;
-                const uint2 v0 = *(const uint2*)(vrow + ((c0 ^ swz) << 4));
-                const uint2 v1 = *(const uint2*)(vrow + (((c0 + 1) ^ swz) << 4));
-                uint4 vu = make_uint4(v0.x, v0.y, v1.x, v1.y);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&vu, pb, o[db], 0, 0, 0);
-            }
+            for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks][db], pb, o[db], 0, 0, 0);
         }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
