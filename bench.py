@@ -73,7 +73,7 @@ def kernel_breakdown(engine, plan):
     agg, shapes = {}, {}
     for i, (fn, args, name) in enumerate(rec):
         ms = evs[i].elapsed_time(evs[i + 1])
-        a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "tflop": 0.0})
+        a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "tflop": 0.0, "gbyte": 0.0})
         a["launches"] += 1
         a["ms"] += ms
         if name == "t2v_gemm":
@@ -92,6 +92,12 @@ def kernel_breakdown(engine, plan):
         elif name == "t2v_attn_temporal":
             clips, frames, hw, heads = args[8], args[9], args[10], args[11]
             a["tflop"] += 4.0 * clips * hw * heads * frames * frames * 64 / 1e12
+            a["gbyte"] += 4 * 2.0 * clips * frames * hw * heads * 64 / 1e9  # q, k, v in + out, bf16
+        elif name in ("t2v_gn_stats", "t2v_gn_apply"):  # algorithmic HBM bytes: stats read x once, apply reads + writes
+            rows, ch = args[6] * args[7], args[1] + args[4]
+            a["gbyte"] += (1 if name == "t2v_gn_stats" else 2) * 2.0 * rows * ch / 1e9
+        elif name == "t2v_layernorm":
+            a["gbyte"] += 2 * 2.0 * args[2] * args[3] / 1e9
     report = os.environ.get("T2V_SHAPE_REPORT")
     if report:
         rows = [{"mode": k[0], "M": k[1], "N": k[2], "K": k[3], "batch": k[4], "act": k[5], "concat": k[6], "n": v["n"],
@@ -258,7 +264,9 @@ def main():
                 "launches": gm["launches"], "tflop_per_step": round(gm["tflop"], 3), "ms_per_step": round(gm["ms"], 3),
                 "whole_step_frac": round(UNET_TFLOP_PER_STEP / (ms_per_step / 1e3) / MFMA_PEAK_TFLOPS, 4),
             }
-            result["kernel_ms"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflop": round(v["tflop"], 3)}
+            result["kernel_ms"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflop": round(v["tflop"], 3),
+                                       **({"gbyte": round(v["gbyte"], 3), "gb_per_s": round(v["gbyte"] / (v["ms"] / 1e3), 1)}
+                                          if v.get("gbyte") else {})}
                                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
         log(f"timed region done: {ms_per_step:.2f} ms/step")
         if args.clip and world == 1:

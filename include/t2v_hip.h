@@ -122,6 +122,12 @@ int t2v_gn_stats(const void* x0, int c0, int ld0, const void* x1, int c1, int ld
 int t2v_gn_apply(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units,
                  int rows_per_unit, int groups, const float* stats, const float* gamma,
                  const float* beta, int silu, void* out, int ldo, void* stream);
+/* GroupNorm(+SiLU) in one call (what the engines use): statistics + normalise, 2 launches for tensors with few row slabs,
+ * 3 otherwise.  ws: t2v_group_norm_ws_floats(n_units, rows_per_unit, groups, c0 + c1) floats. */
+long long t2v_group_norm_ws_floats(int n_units, int rows_per_unit, int groups, int channels);
+int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units, int rows_per_unit,
+                   int groups, float eps, const float* gamma, const float* beta, int silu, float* ws, void* out, int ldo,
+                   void* stream);
 
 /* LayerNorm over the channel dim, eps, affine; bf16 in/out (attention.py:279-281). */
 int t2v_layernorm(const void* x, int ldx, int M, int C, const float* gamma, const float* beta,

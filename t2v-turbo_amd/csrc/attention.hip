@@ -200,17 +200,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // ------------------------------------------------------------------------------------------------
-// One wave per (clip, pixel, head).  lane = (frame i = lane>>2, quarter dq = lane&3 of the 64-wide head):
-// each lane fetches ITS 32-byte slice of q_i, k_i and v_i exactly once (coalesced 128-byte rows at the
-// frame stride), K and V go to a 4 KiB per-wave LDS tile, and the 16x16 scores / PV products read them
-// back with broadcast ds_read_b128 (all lanes of a quarter read the same address).  F > 16 loops over
-// 16-frame query/key blocks with an online softmax.
+// Temporal attention: the sequence is the F frames of one pixel.  One wave per (clip, pixel, head), matrix cores for
+// both products (the VALU form of this kernel was instruction-bound at a third of the HBM rate):
+//   S^T = K Q^T   v_mfma_f32_16x16x32_bf16, A = K rows (key j = lane&15), B = Q rows (query i = lane&15); every lane
+//                 fetches ITS 16-byte slices of q_i / k_j / v_j straight from the token-major buffers at the frame
+//                 stride (rows of 128 contiguous bytes per head), no staging for Q and K.
+//   softmax       a lane owns query column i and keys j = 4g + r (g = lane>>4): lane-local + 2 shuffles (xor 16, 32).
+//   O^T = V^T P^T v_mfma_f32_16x16x16_bf16: P^T is already in B-operand position (k = 4g + r); V^T (contraction index =
+//                 frame, the strided one) goes through a 2.5 KiB per-wave LDS transpose (16-bit writes, ds_read_b64).
+// F > 16 loops over 16-frame query / key blocks with an online softmax.
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short bf16x4s_t;
+constexpr int VT_LD = 20;  // V^T row stride in elements (40 B: keeps the 8-byte fragment reads aligned, spreads banks)
 __global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __restrict__ q, int ldq,
                                                             const bf16_t* __restrict__ k, int ldk,
                                                             const bf16_t* __restrict__ v, int ldv,
                                                             bf16_t* __restrict__ out, int ldo, long long n_items, int F,
                                                             int HW, int heads, float scale, float* __restrict__ probs) {
-    __shared__ __attribute__((aligned(16))) char lds[4][2][16 * 128];  // [wave][K|V][frame][64 bf16]
+    __shared__ __attribute__((aligned(16))) bf16_t lds[4][64 * VT_LD];  // [wave] V^T [d][frame]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const long long item = (long long)blockIdx.x * 4 + wv;
     if (item >= n_items) return;  // whole wave exits together (item is wave-uniform)
@@ -219,83 +225,97 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const bf16_t* __rest
     const int p = (int)(bp % HW);
     const long long b = bp / HW;
     const long long row0 = b * F * HW + p;  // row of frame f = row0 + f*HW
-    const int fi = lane >> 2, dq = lane & 3, col = head * 64 + dq * 16;
-    char* sk = lds[wv][0];
-    char* sv = lds[wv][1];
+    const int l15 = lane & 15, g = lane >> 4;
+    const int col = head * 64 + g * 8;     // this lane's 8-channel slice of K-step 0 (K-step 1: +32)
+    bf16_t* vt = lds[wv];
     const int nblk = (F + 15) / 16;
+    const float c2 = scale * 1.4426950408889634f;  // softmax in base 2 on raw scores
     for (int qb = 0; qb < nblk; ++qb) {
-        const int i = qb * 16 + fi;
-        const bool ok = i < F;
-        float qv[16];
+        const int qi = qb * 16 + l15;
+        const bool q_ok = qi < F;
+        bf16x8_t qf[2];
         {
-            const bf16_t* qp = q + (row0 + (long long)(ok ? i : 0) * HW) * ldq + col;
-            unpack8(*(const uint4*)qp, qv);
-            unpack8(*(const uint4*)(qp + 8), qv + 8);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) qv[e] *= scale;
+            const bf16_t* qp = q + (row0 + (long long)(q_ok ? qi : 0) * HW) * ldq + col;
+            uint4 u0 = *(const uint4*)qp, u1 = *(const uint4*)(qp + 32);
+            qf[0] = *(bf16x8_t*)&u0; qf[1] = *(bf16x8_t*)&u1;
         }
-        float m_run = -INFINITY, l_run = 0.f, o[16];
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x4_t o[4];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+        for (int m = 0; m < 4; ++m) o[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         for (int kb = 0; kb < nblk; ++kb) {
-            const int j_own = kb * 16 + fi;  // the key/value frame this lane stages
+            const int kj = kb * 16 + l15;
+            const bool k_ok = kj < F;
+            const long long r = row0 + (long long)(k_ok ? kj : 0) * HW;
+            uint4 k0 = *(const uint4*)(k + r * ldk + col), k1 = *(const uint4*)(k + r * ldk + col + 32);
+            uint4 v0 = *(const uint4*)(v + r * ldv + col), v1 = *(const uint4*)(v + r * ldv + col + 32);
+            if (!k_ok) { k0 = k1 = v0 = v1 = make_uint4(0, 0, 0, 0); }  // padding frames: V must be finite (P is 0 there)
+            // ---- S^T[j][i] = sum_d K[j][d] Q[i][d]: lane holds column i = l15, rows j = 4g + r
+            f32x4_t st = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8_t*)&k0, qf[0], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8_t*)&k1, qf[1], st, 0, 0, 0);
+            // ---- V^T through LDS (frame index becomes the contiguous one)
+            __builtin_amdgcn_wave_barrier();  // previous block's fragment reads are done
             {
-                const bool jok = j_own < F;
-                const long long r = row0 + (long long)(jok ? j_own : 0) * HW;
-                const uint4* kp = (const uint4*)(k + r * ldk + col);
-                const uint4* vp = (const uint4*)(v + r * ldv + col);
-                uint4 k0 = kp[0], k1 = kp[1], v0 = vp[0], v1 = vp[1];
-                if (!jok) { k0 = k1 = v0 = v1 = make_uint4(0, 0, 0, 0); }
-                uint4* dk = (uint4*)(sk + fi * 128 + dq * 32);
-                uint4* dv = (uint4*)(sv + fi * 128 + dq * 32);
-                dk[0] = k0; dk[1] = k1; dv[0] = v0; dv[1] = v1;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            float s[16];
-            float mx = m_run;
+                const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                float kv[16];
-                unpack8(*(const uint4*)(sk + j * 128 + dq * 32), kv);
-                unpack8(*(const uint4*)(sk + j * 128 + dq * 32 + 16), kv + 8);
-                float d = 0.f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) d += qv[e] * kv[e];
-                d += __shfl_xor(d, 1, 64);
-                d += __shfl_xor(d, 2, 64);
-                s[j] = (kb * 16 + j < F) ? d : -INFINITY;
-                mx = fmaxf(mx, s[j]);
+                for (int e = 0; e < 8; ++e) {
+                    const int d = g * 8 + (e >> 2) * 32 + (e & 3) * 2;
+                    vt[d * VT_LD + l15] = (bf16_t)(w[e] & 0xffffu);
+                    vt[(d + 1) * VT_LD + l15] = (bf16_t)(w[e] >> 16);
+                }
             }
-            const float alpha = __expf(m_run - mx);
-            m_run = mx;
+            // ---- online softmax down column i
+            float sc[4];
+            float mloc = -INFINITY;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                sc[rr] = (kb * 16 + 4 * g + rr < F) ? st[rr] : -INFINITY;
+                mloc = fmaxf(mloc, sc[rr]);
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
             float lsum = 0.f;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { s[j] = __expf(s[j] - mx); lsum += s[j]; }
+            for (int rr = 0; rr < 4; ++rr) { sc[rr] = __builtin_amdgcn_exp2f((sc[rr] - m_new) * c2); lsum += sc[rr]; }
+            lsum += __shfl_xor(lsum, 16, 64);
+            lsum += __shfl_xor(lsum, 32, 64);
             l_run = l_run * alpha + lsum;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[e] *= alpha;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                float vv[16];
-                unpack8(*(const uint4*)(sv + j * 128 + dq * 32), vv);
-                unpack8(*(const uint4*)(sv + j * 128 + dq * 32 + 16), vv + 8);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[e] += s[j] * vv[e];
-            }
-            if (probs && nblk == 1 && dq == 0 && ok) {
+            m_run = m_new;
+            if (probs && nblk == 1 && q_ok) {  // attention_probs [item][i][j], complete after the only key block
                 const float inv1 = 1.f / l_run;
-                for (int j = 0; j < F; ++j) probs[(item * F + i) * F + j] = s[j] * inv1;
-            }
-            __builtin_amdgcn_wave_barrier();  // everyone done reading before the next block overwrites
-        }
-        const float inv = 1.f / l_run;
-        if (ok) {
+                float* pr = probs + (item * F + qi) * F + 4 * g;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) o[e] *= inv;
-            bf16_t* op = out + (row0 + (long long)i * HW) * ldo + col;
-            *(uint4*)op = pack8(o);
-            *(uint4*)(op + 8) = pack8(o + 8);
+                for (int rr = 0; rr < 4; ++rr)
+                    if (4 * g + rr < F) pr[rr] = sc[rr] * inv1;
+            }
+            uint2 pu;
+            pu.x = pack2bf(sc[0], sc[1]);
+            pu.y = pack2bf(sc[2], sc[3]);
+            const bf16x4s_t pb = *(bf16x4s_t*)&pu;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- O^T[d][i] += sum_j V^T[d][j] P^T[j][i]: 4 d-blocks of 16
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint2 a = *(const uint2*)(vt + (m * 16 + l15) * VT_LD + 4 * g);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) o[m][rr] *= alpha;
+                o[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(*(const bf16x4s_t*)&a, pb, o[m], 0, 0, 0);
+            }
+        }
+        if (q_ok) {
+            const float inv = 1.f / l_run;
+            bf16_t* op = out + (row0 + (long long)qi * HW) * ldo + head * 64 + 4 * g;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {  // O^T rows d = 16m + 4g + r of column i: 4 consecutive channels = 8 bytes
+                uint2 w;
+                w.x = pack2bf(o[m][0] * inv, o[m][1] * inv);
+                w.y = pack2bf(o[m][2] * inv, o[m][3] * inv);
+                *(uint2*)(op + m * 16) = w;
+            }
         }
     }
 }

@@ -5,10 +5,13 @@
 
 namespace {
 
-// Thread decomposition shared by gn_stats / gn_apply: a block owns a slab of rows of ONE
+// Thread decomposition shared by the GroupNorm kernels: a block owns a slab of rows of ONE
 // statistics unit; thread (cx, ry) owns channel chunks cx + j*tx (8 channels each) for rows
 // ry + i*ty.  Each thread therefore sees the same channels on every row it touches, so the
-// per-channel scale/shift (apply) or partial sums (stats) stay in registers.
+// per-channel scale/shift (apply) or partial sums (stats) stay in registers.  A thread keeps
+// GN_RPT rows (16-byte loads) in flight; a slab is ty*GN_RPT rows, so small tensors still
+// spread over many blocks (these kernels are latency-bound below a few MB) and a call never
+// has more than 1024 slabs per unit.
 struct GnGeom {
     int cpr;  // 16-byte chunks per row = C/8
     int cpt;  // chunks per thread
@@ -24,14 +27,19 @@ __host__ __device__ inline GnGeom gn_geom(int C) {
     return g;
 }
 constexpr int GN_MAX_CPT = 2;      // C <= 4096
-// rows per block: sized so that a call launches ~1024 blocks (>= 32, <= 256 rows)
-inline int gn_slab_rows(int n_units, int rows_per_unit) {
-    long long total = (long long)n_units * rows_per_unit;
-    long long s = (total + 1023) / 1024;
-    s = (s + 7) / 8 * 8;
-    if (s < 32) s = 32;
-    if (s > 256) s = 256;
-    return (int)s;
+constexpr int GN_RPT = 8;          // rows in flight per thread
+constexpr int GN_MAX_SLABS = 1024;
+constexpr int GN_FUSE_SLABS = 128;  // up to this many slabs the apply kernel finishes the statistics itself
+// slab limits: a finishing thread holds at most 64 partials (gn_finish_unit), with NT / (2*groups) threads per value
+inline int gn_max_slabs(int groups) { const int m = 64 * (1024 / (2 * groups)); return m < GN_MAX_SLABS ? m : GN_MAX_SLABS; }
+inline int gn_fuse_slabs(int groups) { const int m = 64 * (256 / (2 * groups)); return m < GN_FUSE_SLABS ? m : GN_FUSE_SLABS; }
+inline int gn_slab_rows(int C, int rows_per_unit, int groups) {
+    const GnGeom g = gn_geom(C);
+    int s = g.ty * GN_RPT;
+    const int cap = gn_max_slabs(groups);
+    const int need = (rows_per_unit + cap - 1) / cap;
+    if (s < need) s = (need + g.ty - 1) / g.ty * g.ty;
+    return s;
 }
 
 __device__ __forceinline__ const bf16_t* gn_src(const bf16_t* x0, int c0, int ld0, const bf16_t* x1, int ld1,
@@ -39,11 +47,11 @@ __device__ __forceinline__ const bf16_t* gn_src(const bf16_t* x0, int c0, int ld
     return c < c0 ? x0 + row * ld0 + c : x1 + row * ld1 + (c - c0);
 }
 
-// partial[unit][slab][group][2] = (sum, sumsq).  Deterministic: per-thread register sums -> LDS
-// [row-lane][channel] -> fixed-order reduction over row-lanes, then over the channels of a group.
-__global__ __launch_bounds__(256) void gn_stats_partial(const bf16_t* x0, int c0, int ld0, const bf16_t* x1, int c1,
-                                                        int ld1, int rows_per_unit, int groups, int slab_rows, float* partial) {
-    extern __shared__ float sred[];  // [2][ty][C] then reused as [2][C]
+// partial[unit][slab][value = 2*group + stat] = (sum, sumsq) of the slab's rows.  Deterministic: per-thread
+// register sums -> LDS [row-lane][channel] -> one thread per value adds its group's entries in a fixed order.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x0, int c0, int ld0, const bf16_t* x1, int c1,
+                                                         int ld1, int rows_per_unit, int groups, int slab_rows, float* partial) {
+    extern __shared__ float sred[];  // [2][ty][C]
     const int C = c0 + c1, cpg = C / groups;
     const GnGeom g = gn_geom(C);
     const int unit = blockIdx.y, slab = blockIdx.x, nslab = gridDim.x;
@@ -51,80 +59,77 @@ __global__ __launch_bounds__(256) void gn_stats_partial(const bf16_t* x0, int c0
     const int cx = tid % g.tx, ry = tid / g.tx;
     const int r0 = slab * slab_rows;
     const int r1 = min(r0 + slab_rows, rows_per_unit);
-    float s[GN_MAX_CPT][8], q[GN_MAX_CPT][8];
-#pragma unroll
-    for (int j = 0; j < GN_MAX_CPT; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s[j][e] = 0.f; q[j][e] = 0.f; }
     float* ssum = sred;
     float* ssq = sred + g.ty * C;
     if (ry < g.ty) {
-        // 4 rows per trip: the 4 (x cpt) 16-byte loads are issued before any is consumed
-        for (int r = r0 + ry; r < r1; r += 4 * g.ty) {
 #pragma unroll
-            for (int j = 0; j < GN_MAX_CPT; ++j) {
-                const int ci = cx + j * g.tx;
-                if (j < g.cpt && ci < g.cpr) {
-                    uint4 u[4];
+        for (int j = 0; j < GN_MAX_CPT; ++j) {
+            const int ci = cx + j * g.tx;
+            if (j < g.cpt && ci < g.cpr) {
+                float s[8], q[8];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+                for (int r = r0 + ry; r < r1; r += GN_RPT * g.ty) {
+                    uint4 u[GN_RPT];
+#pragma unroll
+                    for (int t = 0; t < GN_RPT; ++t) {
                         const int rr = r + t * g.ty;
                         u[t] = rr < r1 ? *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, (long long)unit * rows_per_unit + rr, ci * 8)
                                        : make_uint4(0, 0, 0, 0);
                     }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
+                    for (int t = 0; t < GN_RPT; ++t) {
                         float f[8];
                         unpack8(u[t], f);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) { s[j][e] += f[e]; q[j][e] += f[e] * f[e]; }
+                        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
                     }
                 }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < GN_MAX_CPT; ++j) {
-            const int ci = cx + j * g.tx;
-            if (j < g.cpt && ci < g.cpr) {
-                *(float4*)(ssum + ry * C + ci * 8) = make_float4(s[j][0], s[j][1], s[j][2], s[j][3]);
-                *(float4*)(ssum + ry * C + ci * 8 + 4) = make_float4(s[j][4], s[j][5], s[j][6], s[j][7]);
-                *(float4*)(ssq + ry * C + ci * 8) = make_float4(q[j][0], q[j][1], q[j][2], q[j][3]);
-                *(float4*)(ssq + ry * C + ci * 8 + 4) = make_float4(q[j][4], q[j][5], q[j][6], q[j][7]);
+                *(float4*)(ssum + ry * C + ci * 8) = make_float4(s[0], s[1], s[2], s[3]);
+                *(float4*)(ssum + ry * C + ci * 8 + 4) = make_float4(s[4], s[5], s[6], s[7]);
+                *(float4*)(ssq + ry * C + ci * 8) = make_float4(q[0], q[1], q[2], q[3]);
+                *(float4*)(ssq + ry * C + ci * 8 + 4) = make_float4(q[4], q[5], q[6], q[7]);
             }
         }
     }
     __syncthreads();
-    // reduce over row-lanes: thread -> channel(s); result parked in row-lane 0's slots
-    for (int c = tid; c < C; c += 256) {
-        float a = ssum[c], b = ssq[c];
-        for (int y = 1; y < g.ty; ++y) { a += ssum[y * C + c]; b += ssq[y * C + c]; }
-        ssum[c] = a; ssq[c] = b;
-    }
-    __syncthreads();
-    // partial is [unit][value = 2*group + stat][slab]: the final pass reads each value's slabs contiguously
+    // partial is [unit][slab][value]: the finishing pass reads a slab's values with one coalesced load per wave
     for (int i = tid; i < groups * 2; i += 256) {
         const int grp = i >> 1;
-        const float* src = (i & 1) ? ssq : ssum;
-        float a = 0.f;
-        for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) a += src[c];
-        partial[((long long)unit * groups * 2 + i) * nslab + slab] = a;
+        const float* src = ((i & 1) ? ssq : ssum) + grp * cpg;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four independent chains: the LDS reads pipeline
+        for (int y = 0; y < g.ty; ++y) {
+            const float* row = src + y * C;
+            int c = 0;
+            for (; c + 4 <= cpg; c += 4) { a0 += row[c]; a1 += row[c + 1]; a2 += row[c + 2]; a3 += row[c + 3]; }
+            for (; c < cpg; ++c) a0 += row[c];
+        }
+        partial[((long long)unit * nslab + slab) * groups * 2 + i] = (a0 + a1) + (a2 + a3);
     }
 }
 
-// one block per unit: thread = (part, value) walks slabs part, part+parts, ... in a fixed order;
-// values = (sum, sumsq) of each group (groups*2 <= 256)
-__global__ __launch_bounds__(256) void gn_stats_final(const float* partial, int nslab, int groups, float inv_count, float eps, float* stats) {
-    __shared__ double sh[256];
-    const int unit = blockIdx.x, tid = threadIdx.x;
-    const int width = groups * 2, parts = 256 / width;
+// Statistics of one unit from its slab partials, in a fixed order (block-wide helper, NT threads): thread = (part, value)
+// walks slabs [part*chunk, ...), then the parts are added in order.  Leaves (mean, rstd) of group g in sm[g], sr[g].
+template <int NT, int MAXCH>
+__device__ __forceinline__ void gn_finish_unit(const float* partial, int unit, int nslab, int groups, float inv_count, float eps,
+                                               double* sh /*[NT]*/, float* sm, float* sr) {
+    const int tid = threadIdx.x;
+    const int width = groups * 2, parts = NT / width;
     const int v = tid % width, part = tid / width;
-    const float* base = partial + ((long long)unit * width + v) * nslab;
+    const float* base = partial + (long long)unit * nslab * width + v;
     const int chunk = (nslab + parts - 1) / parts;
     double acc = 0.0;
     if (part < parts) {
         const int k1 = min(nslab, (part + 1) * chunk);
-#pragma unroll 8
-        for (int k = part * chunk; k < k1; ++k) acc += (double)base[k];
+        int k = part * chunk;
+        for (; k + 8 <= k1; k += 8) {  // 8 coalesced loads in flight, then a fixed-order add
+            float t[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = base[(long long)(k + e) * width];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += (double)t[e];
+        }
+        for (; k < k1; ++k) acc += (double)base[(long long)k * width];
     }
     sh[tid] = acc;
     __syncthreads();
@@ -138,58 +143,108 @@ __global__ __launch_bounds__(256) void gn_stats_final(const float* partial, int 
         const double mean = sh[2 * tid] * inv_count;
         double var = sh[2 * tid + 1] * inv_count - mean * mean;
         if (var < 0.0) var = 0.0;
-        stats[((long long)unit * groups + tid) * 2] = (float)mean;
-        stats[((long long)unit * groups + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        sm[tid] = (float)mean;
+        sr[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+}
+
+// one block per unit: stats[unit][group] = (mean, rstd) and, when coef != null, the per-channel affine
+// coef[unit][0][c] = rstd*gamma[c], coef[unit][1][c] = beta[c] - mean*rstd*gamma[c] the apply pass streams with
+__global__ __launch_bounds__(1024) void gn_final_kernel(const float* partial, int nslab, int groups, int C, float inv_count, float eps,
+                                                        const float* gamma, const float* beta, float* stats, float* coef) {
+    __shared__ double sh[1024];
+    __shared__ float sm[128], sr[128];
+    const int unit = blockIdx.x, tid = threadIdx.x;
+    gn_finish_unit<1024, 64>(partial, unit, nslab, groups, inv_count, eps, sh, sm, sr);
+    if (stats && tid < groups) {
+        stats[((long long)unit * groups + tid) * 2] = sm[tid];
+        stats[((long long)unit * groups + tid) * 2 + 1] = sr[tid];
+    }
+    if (coef) {
+        const int cpg = C / groups;
+        for (int c = tid; c < C; c += 1024) {
+            const int grp = c / cpg;
+            const float a = sr[grp] * gamma[c];
+            coef[(long long)unit * 2 * C + c] = a;
+            coef[(long long)unit * 2 * C + C + c] = beta[c] - sm[grp] * a;
+        }
     }
 }
 
+// MODE 0: (mean, rstd) per group in `stats`.  MODE 1: per-channel affine in `coef` (gn_final_kernel ran).
+// MODE 2: slab partials in `partial` (nslab <= GN_FUSE_SLABS): every block finishes the statistics of its unit itself,
+// which saves the final launch where launch latency, not bandwidth, is what a small tensor pays for.
+template <int MODE>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0, int ld0, const bf16_t* x1, int c1,
                                                        int ld1, int rows_per_unit, int groups, int slab_rows, const float* stats,
-                                                       const float* gamma, const float* beta, int silu, bf16_t* out,
+                                                       const float* coef, const float* partial, int nslab_stats, float inv_count,
+                                                       float eps, const float* gamma, const float* beta, int silu, bf16_t* out,
                                                        int ldo) {
     const int C = c0 + c1, cpg = C / groups;
     const GnGeom g = gn_geom(C);
     const int unit = blockIdx.y, slab = blockIdx.x;
     const int tid = threadIdx.x;
     const int cx = tid % g.tx, ry = tid / g.tx;
+    __shared__ double sh[MODE == 2 ? 256 : 1];
+    __shared__ float sm[MODE == 2 ? 128 : 1], sr[MODE == 2 ? 128 : 1];
+    if (MODE == 2) gn_finish_unit<256, 64>(partial, unit, nslab_stats, groups, inv_count, eps, sh, sm, sr);
     if (ry >= g.ty) return;
-    float sc[GN_MAX_CPT][8], sh[GN_MAX_CPT][8];
+    float sc[GN_MAX_CPT][8], sf[GN_MAX_CPT][8];
 #pragma unroll
     for (int j = 0; j < GN_MAX_CPT; ++j) {
         const int ci = cx + j * g.tx;
         if (j < g.cpt && ci < g.cpr) {
+            if (MODE == 1) {
+                const float* cf = coef + (long long)unit * 2 * C + ci * 8;
+                const float4 a0 = *(const float4*)cf, a1 = *(const float4*)(cf + 4);
+                const float4 b0 = *(const float4*)(cf + C), b1 = *(const float4*)(cf + C + 4);
+                sc[j][0] = a0.x; sc[j][1] = a0.y; sc[j][2] = a0.z; sc[j][3] = a0.w;
+                sc[j][4] = a1.x; sc[j][5] = a1.y; sc[j][6] = a1.z; sc[j][7] = a1.w;
+                sf[j][0] = b0.x; sf[j][1] = b0.y; sf[j][2] = b0.z; sf[j][3] = b0.w;
+                sf[j][4] = b1.x; sf[j][5] = b1.y; sf[j][6] = b1.z; sf[j][7] = b1.w;
+            } else {
+                const float4 g0 = *(const float4*)(gamma + ci * 8), g1 = *(const float4*)(gamma + ci * 8 + 4);
+                const float4 b0 = *(const float4*)(beta + ci * 8), b1 = *(const float4*)(beta + ci * 8 + 4);
+                const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+                const int grp0 = (ci * 8) / cpg;
+                int grp = grp0, next = (grp0 + 1) * cpg - ci * 8;  // channels left in the current group
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int c = ci * 8 + e;
-                const float* st = stats + ((long long)unit * groups + c / cpg) * 2;
-                const float a = st[1] * gamma[c];
-                sc[j][e] = a;
-                sh[j][e] = beta[c] - st[0] * a;
+                for (int e = 0; e < 8; ++e) {
+                    if (e == next) { ++grp; next += cpg; }
+                    float mean, rstd;
+                    if (MODE == 2) { mean = sm[grp]; rstd = sr[grp]; }
+                    else { const float* st = stats + ((long long)unit * groups + grp) * 2; mean = st[0]; rstd = st[1]; }
+                    const float a = rstd * gm[e];
+                    sc[j][e] = a;
+                    sf[j][e] = bt[e] - mean * a;
+                }
             }
         }
     }
     const int r0 = slab * slab_rows;
     const int r1 = min(r0 + slab_rows, rows_per_unit);
-    for (int r = r0 + ry; r < r1; r += 4 * g.ty) {
+    for (int r = r0 + ry; r < r1; r += GN_RPT * g.ty) {
 #pragma unroll
         for (int j = 0; j < GN_MAX_CPT; ++j) {
             const int ci = cx + j * g.tx;
             if (j < g.cpt && ci < g.cpr) {
-                uint4 u[4];
+                uint4 u[GN_RPT];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < GN_RPT; ++t) {
                     const int rr = r + t * g.ty;
                     if (rr < r1) u[t] = *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, (long long)unit * rows_per_unit + rr, ci * 8);
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < GN_RPT; ++t) {
                     const int rr = r + t * g.ty;
                     if (rr < r1) {
                         float f[8];
                         unpack8(u[t], f);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
-                            const float v = f[e] * sc[j][e] + sh[j][e];
+                            const float v = f[e] * sc[j][e] + sf[j][e];
                             f[e] = silu ? silu_f(v) : v;
                         }
                         *(uint4*)(out + ((long long)unit * rows_per_unit + rr) * ldo + ci * 8) = pack8(f);
@@ -200,48 +255,65 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0,
     }
 }
 
-// ---- LayerNorm: one wave per row, row held in registers (C <= 64*8*LN_MAX = 4096) -------------
+// ---- LayerNorm: a wave owns ROWS rows, each held in registers (NJ 16-byte chunks per lane, C <= 64*8*NJ);
+// all ROWS*NJ loads are issued before the first reduction so a wave keeps several rows in flight ----------
 constexpr int LN_MAX = 8;
+template <int NJ, int ROWS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, int ldx, int M, int C, const float* gamma,
                                                         const float* beta, float eps, bf16_t* out, int ldo) {
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
+    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= M) return;
     const int cpr = C / 8;
-    float v[LN_MAX][8];
-    float s = 0.f;
+    uint4 u[ROWS][NJ];
 #pragma unroll
-    for (int j = 0; j < LN_MAX; ++j) {
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int ci = lane + j * 64;
+            u[r][j] = (ci < cpr && row0 + r < M) ? *(const uint4*)(x + (row0 + r) * ldx + ci * 8) : make_uint4(0, 0, 0, 0);
+        }
+    float gg[NJ][8], bb[NJ][8];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
         const int ci = lane + j * 64;
         if (ci < cpr) {
-            unpack8(*(const uint4*)(x + row * ldx + ci * 8), v[j]);
+            const float4 g0 = *(const float4*)(gamma + ci * 8), g1 = *(const float4*)(gamma + ci * 8 + 4);
+            const float4 b0 = *(const float4*)(beta + ci * 8), b1 = *(const float4*)(beta + ci * 8 + 4);
+            gg[j][0] = g0.x; gg[j][1] = g0.y; gg[j][2] = g0.z; gg[j][3] = g0.w; gg[j][4] = g1.x; gg[j][5] = g1.y; gg[j][6] = g1.z; gg[j][7] = g1.w;
+            bb[j][0] = b0.x; bb[j][1] = b0.y; bb[j][2] = b0.z; bb[j][3] = b0.w; bb[j][4] = b1.x; bb[j][5] = b1.y; bb[j][6] = b1.z; bb[j][7] = b1.w;
+        }
+    }
+    const float inv_c = 1.0f / (float)C;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        if (row0 + r >= M) break;
+        float v[NJ][8];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            unpack8(u[r][j], v[j]);  // chunks past the row end are zero and add nothing
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += v[j][e];
         }
-    }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
+        const float mean = wave_sum(s) * inv_c;
+        float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAX; ++j) {
-        const int ci = lane + j * 64;
-        if (ci < cpr) {
+        for (int j = 0; j < NJ; ++j)
+            if (lane + j * 64 < cpr) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float dlt = v[j][e] - mean; q += dlt * dlt; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+                for (int e = 0; e < 8; ++e) { const float dlt = v[j][e] - mean; q += dlt * dlt; }
+            }
+        const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
 #pragma unroll
-    for (int j = 0; j < LN_MAX; ++j) {
-        const int ci = lane + j * 64;
-        if (ci < cpr) {
-            float o[8];
-            const float4 g0 = *(const float4*)(gamma + ci * 8), g1 = *(const float4*)(gamma + ci * 8 + 4);
-            const float4 b0 = *(const float4*)(beta + ci * 8), b1 = *(const float4*)(beta + ci * 8 + 4);
-            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        for (int j = 0; j < NJ; ++j) {
+            const int ci = lane + j * 64;
+            if (ci < cpr) {
+                float o[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (v[j][e] - mean) * rstd * gg[e] + bb[e];
-            *(uint4*)(out + row * ldo + ci * 8) = pack8(o);
+                for (int e = 0; e < 8; ++e) o[e] = (v[j][e] - mean) * rstd * gg[j][e] + bb[j][e];
+                *(uint4*)(out + (row0 + r) * ldo + ci * 8) = pack8(o);
+            }
         }
     }
 }
@@ -297,19 +369,35 @@ int gn_check(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, i
     T2V_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0 && ld0 % 8 == 0 && (c1 == 0 || ld1 % 8 == 0), T2V_ESHAPE,
                 "groupnorm: channels / strides must be multiples of 8");
     T2V_REQUIRE(C % groups == 0 && C / 8 <= 256 * GN_MAX_CPT, T2V_ESHAPE, "groupnorm: unsupported channel count");
-    T2V_REQUIRE(groups * 2 <= 256, T2V_ESHAPE, "groupnorm: too many groups");
+    T2V_REQUIRE(groups <= 128, T2V_ESHAPE, "groupnorm: too many groups");
     return T2V_OK;
 }
 
 }  // namespace
 
-static int gn_nslab(int n_units, int rows_per_unit) {
-    const int sr = gn_slab_rows(n_units, rows_per_unit);
+static int gn_nslab(int C, int rows_per_unit, int groups) {
+    const int sr = gn_slab_rows(C, rows_per_unit, groups);
     return (rows_per_unit + sr - 1) / sr;
 }
 
+// upper bound over every channel count (a slab is >= GN_RPT rows and a unit has <= GN_MAX_SLABS slabs)
 extern "C" long long t2v_gn_ws_floats(int n_units, int rows_per_unit, int groups) {
-    return (long long)n_units * gn_nslab(n_units, rows_per_unit) * groups * 2;
+    long long nslab = (rows_per_unit + GN_RPT - 1) / GN_RPT;
+    if (nslab > GN_MAX_SLABS) nslab = GN_MAX_SLABS;
+    return (long long)n_units * nslab * groups * 2;
+}
+extern "C" long long t2v_group_norm_ws_floats(int n_units, int rows_per_unit, int groups, int channels) {
+    return t2v_gn_ws_floats(n_units, rows_per_unit, groups) + 2LL * n_units * channels;
+}
+
+static int gn_launch_partial(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units, int rows_per_unit,
+                             int groups, float* ws, hipStream_t s) {
+    const int C = c0 + c1;
+    const GnGeom gg = gn_geom(C);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(gn_nslab(C, rows_per_unit, groups), n_units), dim3(256), (size_t)2 * gg.ty * C * sizeof(float), s,
+                       (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, rows_per_unit, groups, gn_slab_rows(C, rows_per_unit, groups), ws);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
 }
 
 extern "C" int t2v_gn_stats(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units,
@@ -319,14 +407,12 @@ extern "C" int t2v_gn_stats(const void* x0, int c0, int ld0, const void* x1, int
     T2V_REQUIRE(ws && stats, T2V_EINVAL, "t2v_gn_stats: null workspace");
     if (!x1) { c1 = 0; ld1 = 0; }
     hipStream_t s = (hipStream_t)stream;
-    const int nslab = gn_nslab(n_units, rows_per_unit);
-    const int slab_rows = gn_slab_rows(n_units, rows_per_unit);
-    const GnGeom gg = gn_geom(c0 + c1);
-    hipLaunchKernelGGL(gn_stats_partial, dim3(nslab, n_units), dim3(256), (size_t)2 * gg.ty * (c0 + c1) * sizeof(float), s,
-                       (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, rows_per_unit, groups, slab_rows, ws);
-    T2V_CHECK_LAUNCH();
-    const float inv_count = 1.0f / ((float)rows_per_unit * (float)((c0 + c1) / groups));
-    hipLaunchKernelGGL(gn_stats_final, dim3(n_units), dim3(256), 0, s, (const float*)ws, nslab, groups, inv_count, eps, stats);
+    rc = gn_launch_partial(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups, ws, s);
+    if (rc) return rc;
+    const int C = c0 + c1;
+    const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / groups));
+    hipLaunchKernelGGL(gn_final_kernel, dim3(n_units), dim3(1024), 0, s, (const float*)ws, gn_nslab(C, rows_per_unit, groups), groups, C,
+                       inv_count, eps, (const float*)nullptr, (const float*)nullptr, stats, (float*)nullptr);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
@@ -338,10 +424,42 @@ extern "C" int t2v_gn_apply(const void* x0, int c0, int ld0, const void* x1, int
     if (rc) return rc;
     T2V_REQUIRE(stats && gamma && beta && out && ldo % 8 == 0, T2V_EINVAL, "t2v_gn_apply: bad argument");
     if (!x1) { c1 = 0; ld1 = 0; }
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(gn_nslab(n_units, rows_per_unit), n_units), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, rows_per_unit, groups,
-                       gn_slab_rows(n_units, rows_per_unit), stats, gamma, beta,
-                       silu, (bf16_t*)out, ldo);
+    const int C = c0 + c1;
+    hipLaunchKernelGGL(gn_apply_kernel<0>, dim3(gn_nslab(C, rows_per_unit, groups), n_units), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, rows_per_unit, groups, gn_slab_rows(C, rows_per_unit, groups),
+                       stats, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0.f, gamma, beta, silu, (bf16_t*)out, ldo);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+
+// GroupNorm(+SiLU) in one call: slab partial sums, then either [finish + per-channel affine, streaming apply] or, for
+// tensors with few slabs, an apply pass whose blocks finish the statistics themselves (2 launches instead of 3).
+extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units,
+                              int rows_per_unit, int groups, float eps, const float* gamma, const float* beta, int silu,
+                              float* ws, void* out, int ldo, void* stream) {
+    int rc = gn_check(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups);
+    if (rc) return rc;
+    T2V_REQUIRE(ws && gamma && beta && out && ldo % 8 == 0, T2V_EINVAL, "t2v_group_norm: bad argument");
+    if (!x1) { c1 = 0; ld1 = 0; }
+    hipStream_t s = (hipStream_t)stream;
+    rc = gn_launch_partial(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups, ws, s);
+    if (rc) return rc;
+    const int C = c0 + c1, nslab = gn_nslab(C, rows_per_unit, groups), slab_rows = gn_slab_rows(C, rows_per_unit, groups);
+    const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / groups));
+    if (nslab <= gn_fuse_slabs(groups)) {
+        hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
+                           ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, nslab,
+                           inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo);
+        T2V_CHECK_LAUNCH();
+        return T2V_OK;
+    }
+    float* coef = ws + t2v_gn_ws_floats(n_units, rows_per_unit, groups);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(n_units), dim3(1024), 0, s, (const float*)ws, nslab, groups, C, inv_count, eps, gamma, beta,
+                       (float*)nullptr, coef);
+    T2V_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1,
+                       rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)coef, (const float*)nullptr, 0, 0.f, 0.f,
+                       gamma, beta, silu, (bf16_t*)out, ldo);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
@@ -350,8 +468,16 @@ extern "C" int t2v_layernorm(const void* x, int ldx, int M, int C, const float* 
                              void* out, int ldo, void* stream) {
     T2V_REQUIRE(x && gamma && beta && out && M > 0, T2V_EINVAL, "t2v_layernorm: bad argument");
     T2V_REQUIRE(C % 8 == 0 && C <= 64 * 8 * LN_MAX && ldx % 8 == 0 && ldo % 8 == 0, T2V_ESHAPE, "t2v_layernorm: unsupported C");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, C,
-                       gamma, beta, eps, (bf16_t*)out, ldo);
+    const int nj = (C / 8 + 63) / 64;
+#define T2V_LN_LAUNCH(NJ, ROWS)                                                                                              \
+    hipLaunchKernelGGL((layernorm_kernel<NJ, ROWS>), dim3((M + 4 * ROWS - 1) / (4 * ROWS)), dim3(256), 0, (hipStream_t)stream, \
+                       (const bf16_t*)x, ldx, M, C, gamma, beta, eps, (bf16_t*)out, ldo)
+    if (nj == 1) T2V_LN_LAUNCH(1, 4);
+    else if (nj == 2) T2V_LN_LAUNCH(2, 4);
+    else if (nj == 3) T2V_LN_LAUNCH(3, 2);
+    else if (nj == 4) T2V_LN_LAUNCH(4, 2);
+    else T2V_LN_LAUNCH(8, 1);
+#undef T2V_LN_LAUNCH
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }

@@ -196,14 +196,12 @@ class _Engine:
         """GroupNorm(+SiLU) of an Act (possibly a virtual concat) -> new single-part tensor."""
         ops = self.ops
         G = norm.num_groups
-        ws = self.buf(1, max(ops.gn_ws_floats(units, rows_per_unit, G), 1), torch.float32)
-        stats = self.buf(units, G * 2, torch.float32)
+        ws = self.buf(1, max(ops.group_norm_ws_floats(units, rows_per_unit, G, x.C), 1), torch.float32)
         eps = norm.eps if eps is None else eps
-        ops.gn_stats(x.parts[0], x.p1, units, rows_per_unit, eps, ws, stats, G)
         out = self.buf(x.M, x.C)
-        ops.gn_apply(x.parts[0], x.p1, units, rows_per_unit, stats, self.pk.f32(norm.weight), self.pk.f32(norm.bias),
-                     silu, out, G)
-        self.pool.put(ws, stats)
+        ops.group_norm(x.parts[0], x.p1, units, rows_per_unit, eps, self.pk.f32(norm.weight), self.pk.f32(norm.bias),
+                       silu, ws, out, G)
+        self.pool.put(ws)
         return out
 
     def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None):

@@ -60,6 +60,9 @@ _SIGS = {
     "t2v_gn_apply": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                C.c_void_p]),
+    "t2v_group_norm_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "t2v_group_norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "t2v_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                 C.c_void_p, C.c_int, C.c_void_p]),
     "t2v_softmax_rows": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -230,6 +233,14 @@ class HipOps:
         self._call("t2v_gn_apply", _p(x0), x0.shape[1], _row_stride(x0), _p(x1),
                    0 if x1 is None else x1.shape[1], 0 if x1 is None else _row_stride(x1),
                    n_units, rows_per_unit, groups, _p(stats), _p(gamma), _p(beta), int(silu), _p(out), _row_stride(out))
+
+    def group_norm_ws_floats(self, n_units, rows_per_unit, groups, channels):
+        return int(self.lib.t2v_group_norm_ws_floats(n_units, rows_per_unit, groups, channels))
+
+    def group_norm(self, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32):
+        self._call("t2v_group_norm", _p(x0), x0.shape[1], _row_stride(x0), _p(x1),
+                   0 if x1 is None else x1.shape[1], 0 if x1 is None else _row_stride(x1),
+                   n_units, rows_per_unit, groups, eps, _p(gamma), _p(beta), int(silu), _p(ws), _p(out), _row_stride(out))
 
     def layernorm(self, x, gamma, beta, eps, out):
         self._call("t2v_layernorm", _p(x), _row_stride(x), x.shape[0], x.shape[1], _p(gamma), _p(beta), eps, _p(out),

@@ -131,6 +131,15 @@ class EmuOps:
             y = F.silu(y)
         out.copy_(y.reshape(-1, C).to(out.dtype))
 
+    def group_norm_ws_floats(self, n_units, rows_per_unit, groups, channels):
+        return 8
+
+    def group_norm(self, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32):
+        self._log("group_norm")
+        stats = torch.empty(n_units, groups * 2)
+        self.gn_stats(x0, x1, n_units, rows_per_unit, eps, ws, stats, groups)
+        self.gn_apply(x0, x1, n_units, rows_per_unit, stats, gamma, beta, silu, out, groups)
+
     def layernorm(self, x, gamma, beta, eps, out):
         self._log("layernorm")
         out.copy_(F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps).to(out.dtype))

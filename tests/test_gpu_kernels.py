@@ -188,7 +188,27 @@ def test_groupnorm(pair, C, c1, units, rows):
         assert rel_l2(out_h.float().cpu(), out_e) < BF16_TOL
 
 
-@pytest.mark.parametrize("M,C", [(1000, 320), (37, 1280), (256, 64), (5, 512)])
+@pytest.mark.parametrize("C,c1,units,rows", [(320, 0, 2, 77), (640, 320, 3, 40), (1280, 0, 1, 700), (2560, 1280, 2, 40),
+                                              (320, 0, 1, 4000), (128, 0, 2, 9000), (960, 320, 1, 1500)])
+def test_group_norm_one_call(pair, C, c1, units, rows):
+    """t2v_group_norm: the fused-finish path (few slabs) and the 3-launch path (many slabs), vs the torch emulation."""
+    c0 = C - c1
+    x0 = pair.act((_rt(units * rows, c0, seed=1) * 2.0 + 0.5).bfloat16().float())
+    x1 = pair.act((_rt(units * rows, c1, seed=2) - 1.0).bfloat16().float()) if c1 else (None, None)
+    gamma, beta = pair.f32(_rt(C, seed=3) * 0.1 + 1.0), pair.f32(_rt(C, seed=4) * 0.1)
+    ws = torch.zeros(pair.hip.group_norm_ws_floats(units, rows, 32, C), device="cuda")
+    for silu in (True, False):
+        out_h = torch.zeros(units * rows, C, dtype=torch.bfloat16, device="cuda")
+        out_e = torch.zeros(units * rows, C)
+        pair.run("group_norm", (x0[0], x1[0], units, rows, 1e-5, gamma[0], beta[0], silu, ws, out_h),
+                 (x0[1], x1[1], units, rows, 1e-5, gamma[1], beta[1], silu, None, out_e))
+        assert rel_l2(out_h.float().cpu(), out_e) < BF16_TOL
+    again = torch.zeros_like(out_h)
+    pair.hip.group_norm(x0[0], x1[0], units, rows, 1e-5, gamma[0], beta[0], False, ws, again)
+    assert torch.equal(again, out_h)  # fixed reduction order: bit-identical on re-run
+
+
+@pytest.mark.parametrize("M,C", [(1000, 320), (37, 1280), (256, 64), (5, 512), (33, 640), (9, 2048), (7, 4096)])
 def test_layernorm(pair, M, C):
     x = pair.act((_rt(M, C, seed=1) * 3.0 + 1.0).bfloat16().float())
     gamma, beta = pair.f32(_rt(C, seed=3) * 0.1 + 1.0), pair.f32(_rt(C, seed=4) * 0.1)
@@ -243,7 +263,7 @@ def test_attn_spatial_online_softmax_rescale(pair):
     assert rel_l2(out_h.float().cpu(), out_e) < 8e-3
 
 
-@pytest.mark.parametrize("clips,frames,hw,heads", [(1, 16, 100, 5), (2, 4, 64, 2), (1, 8, 33, 1), (1, 24, 16, 2)])
+@pytest.mark.parametrize("clips,frames,hw,heads", [(1, 16, 100, 5), (2, 4, 64, 2), (1, 8, 33, 1), (1, 24, 16, 2), (2, 40, 9, 3), (1, 1, 50, 2)])
 def test_attn_temporal(pair, clips, frames, hw, heads):
     inner = heads * 64
     M = clips * frames * hw
