@@ -78,7 +78,10 @@ struct Epi {
     const t2v_gemm_desc* d;
     long long o_off;
     int n_out, vec;
-    __device__ __forceinline__ void run(float* v, const float* gate, int gm, int ch_in, int ch_out) const {
+    // pre_res: the run's 16 residual values already in registers (issued for the whole wave tile before the first
+    // store, so their latency is paid once instead of once per run behind the previous run's stores)
+    __device__ __forceinline__ void run(float* v, const float* gate, int gm, int ch_in, int ch_out, bool has_pre = false,
+                                        uint4 pre0 = uint4{0, 0, 0, 0}, uint4 pre1 = uint4{0, 0, 0, 0}) const {
         const t2v_gemm_desc& dd = *d;
         if (ch_out >= n_out) return;
         const bool full = vec && ch_out + 16 <= n_out;
@@ -126,8 +129,9 @@ struct Epi {
             const bf16_t* rp = (const bf16_t*)dd.residual + o_off + (long long)gm * dd.ldr + ch_out;
             if (full) {
                 float rf[16];
-                unpack8(*(const uint4*)rp, rf);
-                unpack8(*(const uint4*)(rp + 8), rf + 8);
+                if (!has_pre) { pre0 = *(const uint4*)rp; pre1 = *(const uint4*)(rp + 8); }
+                unpack8(pre0, rf);
+                unpack8(pre1, rf + 8);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] += rf[e];
             } else {
@@ -455,16 +459,42 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
         return;
     }
     epi.n_out = d.N;
+    // residual tiles are fetched PF rows of MFMA tiles at a time, before any store of that batch: their latency is
+    // paid once per batch instead of once per 16-channel run (the compiler cannot hoist a load over the previous run's
+    // stores: residual and out may alias).  Register-starved variants (4 waves per SIMD) batch one tile row.
+    constexpr int PF = (WPE >= 4) ? 1 : TM;
+    const bool pre = d.residual && p.vec4;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int gm = m0 + wave_m * WTM + i * 32 + frow;
-        if (gm >= d.M) continue;
+    for (int i0 = 0; i0 < TM; i0 += PF) {
+        uint4 rres[PF][TN][2];
+        if (pre) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            float v[16];
+            for (int ii = 0; ii < PF; ++ii) {
+                const int gm = m0 + wave_m * WTM + (i0 + ii) * 32 + frow;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
-            epi.run(v, nullptr, gm, ch_lane + j * 32, ch_lane + j * 32);
+                for (int j = 0; j < TN; ++j) {
+                    const int ch = ch_lane + j * 32;
+                    rres[ii][j][0] = rres[ii][j][1] = uint4{0, 0, 0, 0};
+                    if (gm < d.M && ch + 16 <= d.N) {
+                        const bf16_t* rp = (const bf16_t*)d.residual + o_off + (long long)gm * d.ldr + ch;
+                        rres[ii][j][0] = *(const uint4*)rp;
+                        rres[ii][j][1] = *(const uint4*)(rp + 8);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < PF; ++ii) {
+            const int i = i0 + ii;
+            const int gm = m0 + wave_m * WTM + i * 32 + frow;
+            if (gm >= d.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
+                epi.run(v, nullptr, gm, ch_lane + j * 32, ch_lane + j * 32, pre, rres[ii][j][0], rres[ii][j][1]);
+            }
         }
     }
 }

@@ -94,10 +94,11 @@ def main():
     tot = sum(r["total_ms"] for r in rows)
     floor = sum(max(r["us_mfma_floor"], r["us_hbm_floor"]) * r["count"] for r in rows) / 1e3
     blas = sum((r["us_blas"] or r["us"]) * r["count"] for r in rows) / 1e3
-    print(f"GEMM per UNet step: {tot:.2f} ms in-graph; roofline floor {floor:.2f} ms; plain hipBLASLt GEMMs of the same MNK {blas:.2f} ms")
+    blas_txt = f"; plain hipBLASLt GEMMs of the same MNK {blas:.2f} ms" if args.blas else ""
+    print(f"GEMM per UNet step: {tot:.2f} ms in-graph; roofline floor {floor:.2f} ms{blas_txt}")
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
-        f.write(f"# GEMM per UNet step: {tot:.2f} ms in-graph; roofline floor {floor:.2f} ms; hipBLASLt same-MNK {blas:.2f} ms\n")
+        f.write(f"# GEMM per UNet step: {tot:.2f} ms in-graph; roofline floor {floor:.2f} ms{blas_txt}\n")
         cols = list(rows[0].keys())
         f.write(",".join(cols) + "\n")
         for r in rows:
