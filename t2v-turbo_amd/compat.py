@@ -23,6 +23,9 @@ _ALIASES = {
     "pipeline.t2v_turbo_vc2_pipeline": ("pipeline", ["T2VTurboVC2Pipeline"]),
     "ode_solver.ddim_solver": ("cd_math", ["DDIMSolver"]),
     "ode_solver": ("cd_math", ["DDIMSolver"]),
+    "model_scope.unet_3d_condition": ("ms_unet3d", ["UNet3DConditionModel", "UNet3DConditionOutput"]),
+    "model_scope.unet_3d_blocks": ("ms_unet3d", ["CrossAttnDownBlock3D", "DownBlock3D", "UNetMidBlock3DCrossAttn",
+                                                 "CrossAttnUpBlock3D", "UpBlock3D"]),
     "utils.lora": ("lora", ["LoraInjectedLinear", "LoraInjectedConv2d", "LoraInjectedConv3d",
                             "inject_trainable_lora_extended", "extract_lora_ups_down", "save_lora_weight",
                             "collapse_lora", "monkeypatch_remove_lora"]),

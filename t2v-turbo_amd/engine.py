@@ -462,19 +462,24 @@ class UNetEngine(_Engine):
         if own_skip:
             self.pool.put(skip)
         if rb.use_temporal_conv:
-            tc = rb.temopral_conv
-            y = h2
-            for i, stage in enumerate((tc.conv1, tc.conv2, tc.conv3, tc.conv4)):
-                tt = self.gn(y, stage[0], B, F * hw, True)
-                ny = self.conv(Act(tt, x.n_img, x.h, x.w), stage[-1], nt.GEMM_TCONV3, frames=F,
-                               residual=h2.t if i == 3 else None)
-                self.pool.put(tt)
-                if y is not h2:
-                    self.pool.put(y.t)
-                y = ny
-            self.pool.put(h2.t)
-            h2 = y
+            h2 = self.temporal_conv_block(rb.temopral_conv, h2)
         return h2
+
+    def temporal_conv_block(self, tc, h2):
+        """4 x [GroupNorm over all frames -> SiLU -> (3,1,1) conv] + identity (openaimodel3d.py:257-309); consumes h2."""
+        B, F = self.B, self.F
+        hw = h2.h * h2.w
+        y = h2
+        for i, stage in enumerate((tc.conv1, tc.conv2, tc.conv3, tc.conv4)):
+            tt = self.gn(y, stage[0], B, F * hw, True)
+            ny = self.conv(Act(tt, h2.n_img, h2.h, h2.w), stage[-1], nt.GEMM_TCONV3, frames=F,
+                           residual=h2.t if i == 3 else None)
+            self.pool.put(tt)
+            if y is not h2:
+                self.pool.put(y.t)
+            y = ny
+        self.pool.put(h2.t)
+        return y
 
     def context_kv(self, attn):
         """K and V^T of the text context for EVERY cross-attention layer in two GEMMs (once per clip, not
