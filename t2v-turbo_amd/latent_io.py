@@ -1,0 +1,83 @@
+"""Pre-computed latent records of the v2 training path.
+
+On-disk format = what ``preprocess_scripts/preprocess_with_motion_prior.py:392-408`` writes per clip: a pickle of a
+dict of fp16 CPU tensors ``{index, z_t, cond_teacher_out, uncond_teacher_out, score, z_example, z_example_prev,
+prompt_emb}`` (optionally ``text``).  The reader mirrors ``data/mp4_dataset.py:87-154`` (``MP4LatentDataset``): a CSV with
+columns ``relpath,text[,latent_root][,use_motion_guide][,short_text]``; the reference fetches ``<latent_root>/<relpath>``
+from S3 with boto3 — here the same keys are resolved against a local directory (any mounted object store)."""
+import csv
+import os
+import pickle
+import random
+
+import torch
+from torch.utils.data import Dataset
+
+RECORD_KEYS = ("index", "z_t", "cond_teacher_out", "uncond_teacher_out", "score", "z_example", "z_example_prev", "prompt_emb")
+
+
+def pack_latent_record(index, z_t, cond_teacher_out, uncond_teacher_out, score, z_example, z_example_prev, prompt_emb,
+                       text=None):
+    """bytes of one record (preprocess_with_motion_prior.py:392-403): every tensor fp16, detached, on CPU."""
+    rec = {"index": index}
+    for k, v in (("z_t", z_t), ("cond_teacher_out", cond_teacher_out), ("uncond_teacher_out", uncond_teacher_out),
+                 ("score", score), ("z_example", z_example), ("z_example_prev", z_example_prev), ("prompt_emb", prompt_emb)):
+        rec[k] = v.to(torch.float16)
+    rec = {k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in rec.items()}
+    if text is not None:
+        rec["text"] = text
+    return pickle.dumps(rec)
+
+
+def unpack_latent_record(blob):
+    rec = pickle.loads(blob)
+    missing = [k for k in RECORD_KEYS if k not in rec]
+    if missing:
+        raise KeyError(f"latent record lacks {missing}")
+    return rec
+
+
+class LatentRecordDataset(Dataset):
+    """``MP4LatentDataset`` (data/mp4_dataset.py:87-154) over a local root instead of an S3 bucket."""
+
+    def __init__(self, path_to_csv, latent_root="latent_root", root_dir="."):
+        self.latent_root, self.root_dir = latent_root, root_dir
+        with open(path_to_csv, newline="") as f:
+            self.rows = list(csv.DictReader(f))
+        self.length = len(self.rows)
+
+    def __len__(self):
+        return self.length
+
+    def get_latent_text_pair(self, idx):
+        row = self.rows[idx]
+        relpath, text = row["relpath"], row["text"]
+        root = row.get("latent_root") or self.latent_root
+        latent_dir = f"{root}/{relpath}"
+        use_motion_guide = bool(int(row["use_motion_guide"])) if row.get("use_motion_guide") not in (None, "") else True
+        short_text = row.get("short_text") or ""
+        if str(short_text) == "nan":
+            short_text = ""
+        with open(os.path.join(self.root_dir, latent_dir), "rb") as f:
+            latent_dict = pickle.loads(f.read())
+        if "webvid" in latent_dir:
+            text = latent_dict.pop("text")
+            short_text = text
+        elif "text" in latent_dict:
+            assert text == latent_dict.pop("text")
+        return latent_dict, text, short_text, use_motion_guide
+
+    def __getitem__(self, idx):
+        while True:  # a broken record is replaced by a random other one, as the reference does
+            try:
+                latent_dict, text, short_text, use_motion_guide = self.get_latent_text_pair(idx)
+                for k in latent_dict:
+                    if isinstance(latent_dict[k], torch.Tensor):
+                        latent_dict[k] = latent_dict[k].detach().cpu()
+                sample = dict(txt=text, short_txt=short_text, use_motion_guide=use_motion_guide)
+                sample.update(latent_dict)
+                return sample
+            except Exception:
+                if self.length <= 1:
+                    raise
+                idx = random.randint(0, self.length - 1)
