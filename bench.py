@@ -108,6 +108,21 @@ def kernel_breakdown(engine, plan):
     return agg
 
 
+def gemm_traffic():
+    """HBM-side bytes per t2v_gemm launch from the committed PMC passes (profiles/r01_gemm_traffic.json: rocprofv3
+    --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this same step, gfx950 FETCH_SIZE x2 correction;
+    tools/pmc_traffic.py).  Counters cannot be read from inside the timed process, so this is the profile's number,
+    labelled as such; null when the profile is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
+    try:
+        with open(path) as f:
+            g = json.load(f)["gemm"]
+        return {"traffic": round(g["hbm_bytes_per_launch"]), "traffic_unit": "bytes per launch (L2-miss side, incl. Infinity-Cache hits)",
+                "traffic_source": "profiles/r01_gemm_traffic.json"}
+    except Exception:
+        return {"traffic": None}
+
+
 def log(msg):
     print(f"[bench +{time.time() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
@@ -260,7 +275,7 @@ def main():
             result["roofline"] = {
                 "kernel": "gemm_kernel (implicit-GEMM conv / linear, v_mfma_f32_32x32x16_bf16)",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), **gemm_traffic(),
                 "launches": gm["launches"], "tflop_per_step": round(gm["tflop"], 3), "ms_per_step": round(gm["ms"], 3),
                 "whole_step_frac": round(UNET_TFLOP_PER_STEP / (ms_per_step / 1e3) / MFMA_PEAK_TFLOPS, 4),
             }

@@ -25,6 +25,7 @@
 //  * workgroup id -> tile mapping is XCD-aware: each of the 8 XCDs (private L2s) gets a contiguous
 //    run of tiles, N-tile fastest, so the tiles that share an A panel hit the same L2.
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 struct GemmParams {
@@ -35,6 +36,7 @@ struct GemmParams {
     int kh, kw, stride, pad_y, pad_x, ups;
     int h_out, w_out;
     int tiles_m, tiles_n;
+    int xcd_m, xcd_n;  // the 8 XCDs as an xcd_m x xcd_n grid over the tile grid (product 8)
     int vec4;          // 4-channel runs may use vector accesses
     int splits, nk_per_split;
     float* ws;         // split-K partials [splits][M][N]
@@ -198,7 +200,27 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
         const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int tile_n = tile % p.tiles_n, tile_m = tile / p.tiles_n;
+    // `tile` walks the tile grid block by block (xcd_m x xcd_n rectangular blocks, n fastest inside a block), so the
+    // contiguous run an XCD owns is (about) one block: its private L2 then fetches 1/xcd_m of the activations and
+    // 1/xcd_n of the weights instead of all of one operand.  The host picks the split that minimises the bytes the
+    // eight L2s pull in total (xcd_n * A_bytes + xcd_m * W_bytes).
+    int tile_m, tile_n;
+    {
+        int t = tile, r0 = 0, r1 = p.tiles_m, c0 = 0, c1 = p.tiles_n;
+        bool found = false;
+        for (int bi = 0; bi < p.xcd_m && !found; ++bi) {
+            r0 = bi * p.tiles_m / p.xcd_m; r1 = (bi + 1) * p.tiles_m / p.xcd_m;
+            for (int bj = 0; bj < p.xcd_n; ++bj) {
+                c0 = bj * p.tiles_n / p.xcd_n; c1 = (bj + 1) * p.tiles_n / p.xcd_n;
+                const int sz = (r1 - r0) * (c1 - c0);
+                if (t < sz) { found = true; break; }
+                t -= sz;
+            }
+        }
+        const int bw = c1 - c0;
+        tile_m = r0 + t / bw;
+        tile_n = c0 + t - (t / bw) * bw;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- batch / split offsets --------------------------------------------------------------------
@@ -529,6 +551,20 @@ template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM
 int launch(GemmParams& p, hipStream_t s) {
     p.tiles_m = (p.d.M + BM - 1) / BM;
     p.tiles_n = (p.d.N + BN - 1) / BN;
+    {   // XCD grid: minimise xcd_n * A_bytes + xcd_m * W_bytes over the factorizations of 8 that the tile grid allows
+        const double a_bytes = (double)p.d.M * (p.d.c0 + p.d.c1), w_bytes = (double)p.d.N * p.K;
+        double best = 1e300;
+        p.xcd_m = 8; p.xcd_n = 1;
+        static const int xcd_policy = getenv("T2V_GEMM_XCD_GRID") ? atoi(getenv("T2V_GEMM_XCD_GRID")) : 2;
+        const bool model = xcd_policy == 1 || (xcd_policy == 2 && p.taps != 9);
+        for (int xm = 8; xm >= (model ? 1 : 8); xm >>= 1) {
+            const int xn = 8 / xm;
+            if (xm > p.tiles_m || xn > p.tiles_n) continue;
+            const double cost = xn * a_bytes + xm * w_bytes;
+            if (cost < best) { best = cost; p.xcd_m = xm; p.xcd_n = xn; }
+        }
+        if (p.xcd_m > p.tiles_m || p.xcd_n > p.tiles_n) { p.xcd_m = 1; p.xcd_n = 1; }
+    }
     dim3 grid(p.tiles_m * p.tiles_n, p.d.batch, p.splits);
     constexpr int smem = STAGES * (BM + BN) * BK * 2;
     static bool attr_set = false;
@@ -555,8 +591,11 @@ const TileCfg kCfg[] = {{0, 0, 0},      {128, 128, 64}, {128, 64, 32},  {256, 64
                         {256, 256, 64}, {256, 128, 64}, {128, 256, 64}, {256, 256, 64},
                         // 32-deep K steps (64-byte LDS rows): <= 80 KiB of LDS and <= 256 VGPRs per 4-wave workgroup, so TWO
                         // workgroups share a CU and one's prologue / barriers / epilogue hide under the other's MFMAs
-                        {256, 128, 64, 32}, {128, 256, 64, 32}, {128, 128, 64, 32}, {256, 128, 64, 32}};
-constexpr int kNumCfg = 19;  // (a 4-wave 128x128-wave-tile variant spills: 3 KB/lane scratch, 72 TF/s - dropped)
+                        {256, 128, 64, 32}, {128, 256, 64, 32}, {128, 128, 64, 32}, {256, 128, 64, 32},
+                        // 256x256 with a 4-slot ring of 32-deep steps (128 KiB): 1.5 K-steps of DMA lookahead instead of 1,
+                        // for weight panels that stream from HBM (cold) rather than from L2
+                        {256, 256, 64, 32}, {256, 256, 64, 32}};
+constexpr int kNumCfg = 21;  // (a 4-wave 128x128-wave-tile variant spills: 3 KB/lane scratch, 72 TF/s - dropped)
 
 int dispatch(int cfg, GemmParams& p, hipStream_t s) {
     switch (cfg) {
@@ -579,6 +618,8 @@ int dispatch(int cfg, GemmParams& p, hipStream_t s) {
         case 17: return launch<128, 256, 1, 4, 3, 32, 2>(p, s);
         case 18: return launch<128, 128, 2, 2, 4, 32, 2>(p, s);
         case 19: return launch<256, 128, 4, 2, 3, 32, 4>(p, s);
+        case 20: return launch<256, 256, 2, 4, 4, 32, 2>(p, s);
+        case 21: return launch<256, 256, 4, 2, 4, 32, 2>(p, s);
         default: return T2V_EINVAL;
     }
 }

@@ -20,29 +20,55 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def time_desc(lib, fn, args, stream, cfg, split, iters=10):
-    """Device time per launch, measured inside a hipGraph (no host launch overhead in the number)."""
+_THRASH = {}
+
+
+def _thrash_buf():
+    """384 MiB scratch whose rewrite evicts the L2s (32 MiB) and the 256 MiB Infinity Cache: in the real UNet step every
+    GEMM meets its weights cold in HBM, while back-to-back replays of one launch would find them in cache."""
+    if "buf" not in _THRASH:
+        _THRASH["buf"] = torch.empty(384 << 20, dtype=torch.uint8, device="cuda")
+    return _THRASH["buf"]
+
+
+def _graph_us(body, iters):
+    body()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            body()
+    g.replay()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
+    return best
+
+
+def time_desc(lib, fn, args, stream, cfg, split, iters=10, cold=True):
+    """Device time per launch inside a hipGraph (no host overhead); cold=True rewrites a 384 MiB buffer before every
+    launch (its own time, measured the same way, is subtracted)."""
     lib.t2v_gemm_force_config(cfg)
     lib.t2v_gemm_force_split(split)
     try:
         if fn(*args, torch.cuda.current_stream().cuda_stream) != 0:
             return None
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(iters):
-                fn(*args, torch.cuda.current_stream().cuda_stream)
-        g.replay()
-        torch.cuda.synchronize()
-        best = 1e30
-        for _ in range(3):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            g.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            best = min(best, e0.elapsed_time(e1) * 1e3 / iters)
-        return best
+        if not cold:
+            return _graph_us(lambda: fn(*args, torch.cuda.current_stream().cuda_stream), iters)
+        buf = _thrash_buf()
+        if "us" not in _THRASH:
+            _THRASH["us"] = _graph_us(lambda: buf.zero_(), 6)
+
+        def body():
+            buf.zero_()
+            fn(*args, torch.cuda.current_stream().cuda_stream)
+        return max(_graph_us(body, 6) - _THRASH["us"], 0.1)
     finally:
         lib.t2v_gemm_force_config(0)
         lib.t2v_gemm_force_split(0)
@@ -52,6 +78,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--vae", type=int, default=1)
     ap.add_argument("--out", default=os.path.join(ROOT, "t2v-turbo_amd", "gemm_tune.json"))
+    ap.add_argument("--cold", type=int, default=1, help="evict caches before every timed launch (what the UNet step sees)")
     args = ap.parse_args()
     os.environ["T2V_GEMM_TUNE"] = "0"  # record with the library heuristics
     import bench
@@ -90,7 +117,7 @@ def main():
                 seen[key] += 1
                 continue
             seen[key] = 1
-            base = time_desc(lib, fn, a, stream, 0, 0)
+            base = time_desc(lib, fn, a, stream, 0, 0, cold=bool(args.cold))
             best = (base, 0, 0)
             nk = K // 64
             splits = [1] + [s for s in (2, 3, 4, 6, 8, 12, 16) if nk // s >= 4 and d.act != nt.ACT_GEGLU and d.N % 4 == 0
@@ -98,7 +125,7 @@ def main():
             allt = {}
             for cfg in range(1, ncfg + 1):
                 for sp in splits:
-                    t = time_desc(lib, fn, a, stream, cfg, sp)
+                    t = time_desc(lib, fn, a, stream, cfg, sp, cold=bool(args.cold))
                     allt[f"{cfg}/{sp}"] = None if t is None else round(t, 1)
                     if t is not None and t < best[0]:
                         best = (t, cfg, sp)
