@@ -78,7 +78,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--vae", type=int, default=1)
     ap.add_argument("--out", default=os.path.join(ROOT, "t2v-turbo_amd", "gemm_tune.json"))
-    ap.add_argument("--cold", type=int, default=1, help="evict caches before every timed launch (what the UNet step sees)")
+    ap.add_argument("--cold", type=int, default=0, help="evict caches before every timed launch (what the UNet step sees)")
     args = ap.parse_args()
     os.environ["T2V_GEMM_TUNE"] = "0"  # record with the library heuristics
     import bench
