@@ -186,6 +186,22 @@ int t2v_lcm_step(const float* x, const void* eps, int eps_dt, const float* noise
                  float sb_t, float c_skip, float c_out, float sa_p, float sb_p, long long n,
                  float* prev, float* denoised, void* stream);
 
+/* ---------------------------------------------------------------- backward (dX) pieces of the VAE decoder
+ * Reward-gradient branch (train_t2v_turbo_v1_lora.py:1047-1098: autograd through vae.decode, ae_modules.py:602-641).
+ * Conv / linear data gradients are t2v_gemm launches on re-packed weights; these are the non-GEMM parts.
+ * t2v_gn_bwd: dx = d/dx [act(GroupNorm(x))] . dy (+ resid), act = SiLU or identity; stats = (mean, rstd) per
+ *   (unit, group) from t2v_gn_stats of the forward; ws: t2v_gn_bwd_ws_floats() floats.  x, dy, resid, dx bf16.
+ * t2v_softmax_bwd_rows: dp <- p * (dp - sum_j p_j dp_j) per row (columns >= n set to 0).
+ * t2v_transpose_bf16: out[b][c][r] = in[b][r][c].   t2v_sumpool2x2: adjoint of nearest-x2 upsampling (token-major). */
+long long t2v_gn_bwd_ws_floats(int n_units, int rows_per_unit, int groups);
+int t2v_gn_bwd(const void* x, int ldx, int C, int n_units, int rows_per_unit, int groups, const float* stats,
+               const float* gamma, const float* beta, int silu, const void* dy, int ldy, const void* resid, int ldr,
+               float* ws, void* dx, int ldo, void* stream);
+int t2v_softmax_bwd_rows(const void* p, void* dp, long long rows, int n, int n_pad, int ld, void* stream);
+int t2v_transpose_bf16(const void* in, int ld_in, int rows, int cols, void* out, int ld_out, int batch,
+                       long long in_stride, long long out_stride, void* stream);
+int t2v_sumpool2x2(const void* in, int n_img, int h, int w, int C, void* out, void* stream);
+
 /* ---------------------------------------------------------------- optimizer / EMA over flat fp32 buffers
  * Replace bitsandbytes AdamW8bit / torch AdamW on the LoRA tensors (train_t2v_turbo_v1_lora.py:765-803),
  * accelerator.clip_grad_norm_ (:1193) and update_ema (utils/common_utils.py:307-319).

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip"]
 LIB = os.path.join(PKG, "libt2v_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-I", os.path.join(ROOT, "include"), "-I", HERE]

@@ -140,6 +140,34 @@ class Packer:
             return w.reshape(w.shape[0], -1).to(self.device, self.wdtype).contiguous()
         return self._memo(("conv", id(mod)), make)
 
+    def mat_t(self, mod):
+        """[K, N]^T pack of a Linear / 1x1 conv: the weight of its data gradient (dx = dy @ W)."""
+        def make():
+            w = effective_weight_bias(mod)[0]
+            return w.reshape(w.shape[0], -1).t().to(self.device, self.wdtype).contiguous()
+        return self._memo(("mat_t", id(mod)), make)
+
+    def conv_dgrad(self, mod):
+        """3x3 conv data gradient as a 3x3 conv over dy: w'[ci][(ky',kx'), co] = w[co][ci][2-ky'][2-kx']."""
+        def make():
+            w = effective_weight_bias(mod)[0]          # [co, ci, 3, 3]
+            wd = w.flip(2, 3).permute(1, 2, 3, 0)      # [ci, ky', kx', co]
+            return wd.reshape(wd.shape[0], -1).to(self.device, self.wdtype).contiguous()
+        return self._memo(("conv_dgrad", id(mod)), make)
+
+    def small_conv_dgrad(self, mod, cin_pad, cout_pad=None):
+        """fp32 [cout'][9][cin'] pack for the direct small-channel conv computing the data gradient of ``mod``:
+        cout' = mod's input channels (optionally zero-padded rows), cin' = mod's output channels padded to cin_pad."""
+        def make():
+            w = effective_weight_bias(mod)[0].float()  # [co, ci, 3, 3]
+            wd = w.flip(2, 3).permute(1, 2, 3, 0)      # [ci, ky', kx', co]
+            if cin_pad > wd.shape[-1]:
+                wd = torch.nn.functional.pad(wd, (0, cin_pad - wd.shape[-1]))
+            if cout_pad and cout_pad > wd.shape[0]:
+                wd = torch.nn.functional.pad(wd, (0, 0, 0, 0, 0, 0, 0, cout_pad - wd.shape[0]))
+            return wd.reshape(wd.shape[0], -1).to(self.device).contiguous()
+        return self._memo(("small_dgrad", id(mod), cin_pad, cout_pad), make)
+
     def cat_mats(self, mods, tag):
         return self._memo((tag,) + tuple(id(m) for m in mods),
                           lambda: torch.cat([self.mat(m) for m in mods], dim=0).contiguous())
@@ -212,9 +240,11 @@ class _Engine:
         self.ops.gemm(a, w, out, M=a.shape[0], N=N, bias=bias, residual=residual, act=act)
         return out
 
-    def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None):
-        """3x3 / strided / upsampled / temporal conv of an Act (virtual concat allowed)."""
-        w = self.pk.conv(mod)
+    def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto"):
+        """3x3 / strided / upsampled / temporal conv of an Act (virtual concat allowed); ``w`` / ``bias`` override the
+        module's packed forward weights (data-gradient convs pass the flipped / transposed pack and no bias)."""
+        w = self.pk.conv(mod) if w is None else w
+        bias = self.pk.bias(mod) if isinstance(bias, str) else bias
         N = w.shape[0]
         if mode == nt.GEMM_CONV3X3_S2:
             ho, wo = (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1
@@ -225,7 +255,7 @@ class _Engine:
         M = x.n_img * ho * wo
         out = self.buf(M, N, out_dtype)
         self.ops.gemm(x.parts[0], w, out, M=M, N=N, a1=x.p1, mode=mode, n_img=x.n_img, h=x.h, wd=x.w, frames=frames,
-                      bias=self.pk.bias(mod), rowvec=rowvec, rowvec_div=rowvec_div, residual=residual)
+                      bias=bias, rowvec=rowvec, rowvec_div=rowvec_div, residual=residual)
         return Act(out, x.n_img, ho, wo)
 
     # ---- plan management --------------------------------------------------------------------------------

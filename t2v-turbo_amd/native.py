@@ -82,6 +82,13 @@ _SIGS = {
     "t2v_cast": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p]),
     "t2v_lincomb3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                C.c_longlong, C.c_void_p, C.c_void_p]),
+    "t2v_gn_bwd_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "t2v_gn_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "t2v_softmax_bwd_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "t2v_transpose_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
+                                     C.c_longlong, C.c_void_p]),
+    "t2v_sumpool2x2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "t2v_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "t2v_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_longlong, C.c_void_p]),
@@ -290,6 +297,26 @@ class HipOps:
         ha, hb, hc = arr(*ca), (arr(*cb) if cb is not None else None), (arr(*cc) if cc is not None else None)
         self._call("t2v_lincomb3", _p(x), _p(y), _p(z), C.cast(ha, C.c_void_p), C.cast(hb, C.c_void_p) if hb else None,
                    C.cast(hc, C.c_void_p) if hc else None, nb, x.numel() // nb, _p(out), keep=(ha, hb, hc))
+
+    # -- backward pieces (VAE decoder dX) ---------------------------------------------------------------------
+    def gn_bwd_ws_floats(self, n_units, rows_per_unit, groups=32):
+        return int(self.lib.t2v_gn_bwd_ws_floats(n_units, rows_per_unit, groups))
+
+    def gn_bwd(self, x, n_units, rows_per_unit, stats, gamma, beta, silu, dy, resid, ws, dx, groups=32):
+        self._call("t2v_gn_bwd", _p(x), _row_stride(x), x.shape[1], n_units, rows_per_unit, groups, _p(stats), _p(gamma),
+                   _p(beta), int(silu), _p(dy), _row_stride(dy), _p(resid), 0 if resid is None else _row_stride(resid),
+                   _p(ws), _p(dx), _row_stride(dx))
+
+    def softmax_bwd_rows(self, p, dp, rows, n, n_pad, ld):
+        self._call("t2v_softmax_bwd_rows", _p(p), _p(dp), rows, n, n_pad, ld)
+
+    def transpose(self, src, rows, cols, out, batch=1, in_stride=0, out_stride=0):
+        """out[b][c][r] = src[b][r][c]; row strides taken from the tensors, batch strides in elements."""
+        self._call("t2v_transpose_bf16", _p(src), _row_stride(src), rows, cols, _p(out), _row_stride(out), batch, in_stride,
+                   out_stride)
+
+    def sumpool2x2(self, src, n_img, h, w, out):
+        self._call("t2v_sumpool2x2", _p(src), n_img, h, w, src.shape[1], _p(out))
 
     def adamw_step(self, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
         self._call("t2v_adamw_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), lr, beta1, beta2,

@@ -12,6 +12,7 @@ class EngineBox:
     def __init__(self):
         self.engine = None
         self.enc = None
+        self.grad = None
 
     def __deepcopy__(self, memo):
         return EngineBox()

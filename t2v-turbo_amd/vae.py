@@ -228,6 +228,26 @@ class DiagonalGaussianDistribution:
         return self.mean
 
 
+class _NativeDecodeGrad(torch.autograd.Function):
+    """decode(z) with a native backward: forward and dX both run on the HIP engine (engine_vae_bwd.py)."""
+
+    @staticmethod
+    def forward(ctx, z, vae):
+        ctx.vae = vae
+        ctx.z_dtype = z.dtype
+        eng = vae.native_grad_engine()
+        out = eng.decode_frames_tape(z.detach().unsqueeze(2), scale=1.0).squeeze(2)
+        ctx.plan = eng._last
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        eng = ctx.vae.native_grad_engine()
+        eng._last = ctx.plan
+        dz = eng.backward(grad_out.unsqueeze(2)).squeeze(2)
+        return dz.to(ctx.z_dtype), None
+
+
 class AutoencoderKL(nn.Module):
     """encode(x) -> posterior; decode(z) -> image (lvdm/models/autoencoder.py:13-113)."""
 
@@ -271,7 +291,18 @@ class AutoencoderKL(nn.Module):
     def decode(self, z, **kwargs):
         if z.is_cuda and not (torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self.parameters()))):
             return self.native_engine().decode_frames(z.unsqueeze(2), scale=1.0).squeeze(2)
+        if (z.is_cuda and torch.is_grad_enabled() and z.requires_grad and not any(p.requires_grad for p in self.parameters())
+                and not self.training and getattr(self, "native_mode", "auto") != "off"):
+            # reward-gradient branch (train_t2v_turbo_v1_lora.py:1047-1098): frozen VAE, gradient w.r.t. the latents only
+            return _NativeDecodeGrad.apply(z, self)
         return self.decoder(self.post_quant_conv(z))
+
+    def native_grad_engine(self):
+        if self._engine_box.grad is None:
+            from .engine_vae_bwd import VAEDecodeGradEngine
+            from .native import HipOps
+            self._engine_box.grad = VAEDecodeGradEngine(self, HipOps())
+        return self._engine_box.grad
 
     def native_engine(self):
         if self._engine_box.engine is None:

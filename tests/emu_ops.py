@@ -140,6 +140,55 @@ class EmuOps:
         self.gn_stats(x0, x1, n_units, rows_per_unit, eps, ws, stats, groups)
         self.gn_apply(x0, x1, n_units, rows_per_unit, stats, gamma, beta, silu, out, groups)
 
+    # ------------------------------------------------------------------------------------ backward pieces
+    def gn_bwd_ws_floats(self, n_units, rows_per_unit, groups=32):
+        return 8
+
+    def gn_bwd(self, x, n_units, rows_per_unit, stats, gamma, beta, silu, dy, resid, ws, dx, groups=32):
+        self._log("gn_bwd")
+        C = x.shape[1]
+        cpg = C // groups
+        st = stats.reshape(n_units, groups, 2).float()
+        mean = st[:, :, 0].repeat_interleave(cpg, dim=1)[:, None, :]
+        rstd = st[:, :, 1].repeat_interleave(cpg, dim=1)[:, None, :]
+        xh = (x.float().reshape(n_units, rows_per_unit, C) - mean) * rstd
+        g = dy.float().reshape(n_units, rows_per_unit, C)
+        if silu:
+            u = xh * gamma.float() + beta.float()
+            sig = torch.sigmoid(u)
+            g = g * sig * (1 + u * (1 - sig))
+        g = g * gamma.float()
+        gg = g.reshape(n_units, rows_per_unit, groups, cpg)
+        xg = xh.reshape(n_units, rows_per_unit, groups, cpg)
+        m1 = gg.mean(dim=(1, 3), keepdim=True)
+        m2 = (gg * xg).mean(dim=(1, 3), keepdim=True)
+        d = (rstd.reshape(n_units, 1, groups, cpg) * (gg - m1 - xg * m2)).reshape(-1, C)
+        if resid is not None:
+            d = d + resid.float()
+        dx.copy_(d.to(dx.dtype))
+
+    def softmax_bwd_rows(self, p, dp, rows, n, n_pad, ld):
+        self._log("softmax_bwd_rows")
+        pv = _strided(p, rows, n_pad, ld, 0).float()
+        dv = _strided(dp, rows, n_pad, ld, 0)
+        d = dv.float()
+        out = torch.zeros(rows, n_pad)
+        dot = (pv[:, :n] * d[:, :n]).sum(dim=1, keepdim=True)
+        out[:, :n] = pv[:, :n] * (d[:, :n] - dot)
+        dv.copy_(out.to(dp.dtype))
+
+    def transpose(self, src, rows, cols, out, batch=1, in_stride=0, out_stride=0):
+        self._log("transpose")
+        for b in range(batch):
+            a = _strided(src, rows, cols, src.stride(0), b * in_stride)
+            _strided(out, cols, rows, out.stride(0), b * out_stride).copy_(a.t())
+
+    def sumpool2x2(self, src, n_img, h, w, out):
+        self._log("sumpool2x2")
+        C = src.shape[1]
+        v = src.float().reshape(n_img, h, 2, w, 2, C).sum(dim=(2, 4))
+        out.copy_(v.reshape(-1, C).to(out.dtype))
+
     def layernorm(self, x, gamma, beta, eps, out):
         self._log("layernorm")
         out.copy_(F.layer_norm(x.float(), (x.shape[1],), gamma.float(), beta.float(), eps).to(out.dtype))

@@ -327,3 +327,56 @@ def test_bad_arguments_return_errors(pair):
         pair.hip.gemm(a, w, out, M=64, N=64)
     with pytest.raises(NativeError):
         pair.hip.attn_temporal(out, out, out, out, 1, 2000, 1, 1, 0.125)
+
+
+# ------------------------------------------------------------------------------------ backward pieces (VAE decoder dX)
+@pytest.mark.parametrize("C,units,rows,silu,with_resid", [(128, 2, 300, True, False), (512, 1, 257, True, True),
+                                                          (256, 3, 64, False, True), (64, 2, 5000, True, False)])
+def test_gn_bwd(pair, C, units, rows, silu, with_resid):
+    M = units * rows
+    x = pair.act((_rt(M, C, seed=1) * 1.5 + 0.3).bfloat16().float())
+    dy = pair.act((_rt(M, C, seed=2)).bfloat16().float())
+    rs = pair.act((_rt(M, C, seed=5)).bfloat16().float()) if with_resid else (None, None)
+    gamma, beta = pair.f32(_rt(C, seed=3) * 0.1 + 1.0), pair.f32(_rt(C, seed=4) * 0.1)
+    st_h, st_e = torch.zeros(units, 64, device="cuda"), torch.zeros(units, 64)
+    ws = torch.zeros(max(pair.hip.gn_ws_floats(units, rows), 1), device="cuda")
+    pair.run("gn_stats", (x[0], None, units, rows, 1e-6, ws, st_h), (x[1], None, units, rows, 1e-6, None, st_e))
+    wsb = torch.zeros(pair.hip.gn_bwd_ws_floats(units, rows), device="cuda")
+    dx_h = torch.zeros(M, C, dtype=torch.bfloat16, device="cuda")
+    dx_e = torch.zeros(M, C)
+    pair.run("gn_bwd", (x[0], units, rows, st_h, gamma[0], beta[0], silu, dy[0], rs[0], wsb, dx_h),
+             (x[1], units, rows, st_e, gamma[1], beta[1], silu, dy[1], rs[1], None, dx_e))
+    assert rel_l2(dx_h.float().cpu(), dx_e) < BF16_TOL
+    # and the emulation itself against torch autograd of group_norm (+ silu)
+    xa = x[1].clone().requires_grad_(True)
+    y = torch.nn.functional.group_norm(xa.reshape(units, rows, C).transpose(1, 2), 32, gamma[1], beta[1], 1e-6)
+    y = torch.nn.functional.silu(y) if silu else y
+    (y.transpose(1, 2).reshape(M, C) * dy[1]).sum().backward()
+    ref = xa.grad + (rs[1] if with_resid else 0)
+    assert rel_l2(dx_e, ref) < 1e-4
+
+
+@pytest.mark.parametrize("rows,n,n_pad", [(300, 2560, 2560), (64, 77, 128), (10, 40, 64)])
+def test_softmax_bwd_rows(pair, rows, n, n_pad):
+    logits = _rt(rows, n_pad, seed=1) * 3.0
+    p = torch.zeros(rows, n_pad)
+    p[:, :n] = logits[:, :n].softmax(dim=1)
+    pp = pair.act(p.bfloat16().float())
+    dp = pair.act(_rt(rows, n_pad, seed=2).bfloat16().float())
+    pair.run("softmax_bwd_rows", (pp[0], dp[0], rows, n, n_pad, n_pad), (pp[1], dp[1], rows, n, n_pad, n_pad))
+    assert rel_l2(dp[0].float().cpu(), dp[1]) < BF16_TOL
+    assert float(dp[0][:, n:].float().abs().max()) == 0.0 if n_pad > n else True
+
+
+def test_transpose_and_sumpool(pair):
+    src = pair.act(_rt(3 * 70, 200, seed=1).bfloat16().float())
+    out_h = torch.zeros(3 * 200, 72, dtype=torch.bfloat16, device="cuda")
+    out_e = torch.zeros(3 * 200, 72)
+    pair.run("transpose", (src[0], 70, 200, out_h), (src[1], 70, 200, out_e), dict(batch=3, in_stride=70 * 200, out_stride=200 * 72),
+             dict(batch=3, in_stride=70 * 200, out_stride=200 * 72))
+    assert torch.equal(out_h.float().cpu(), out_e)
+    x = pair.act(_rt(2 * 6 * 10, 64, seed=2).bfloat16().float())
+    o_h = torch.zeros(2 * 3 * 5, 64, dtype=torch.bfloat16, device="cuda")
+    o_e = torch.zeros(2 * 3 * 5, 64)
+    pair.run("sumpool2x2", (x[0], 2, 3, 5, o_h), (x[1], 2, 3, 5, o_e))
+    assert rel_l2(o_h.float().cpu(), o_e) < BF16_TOL
