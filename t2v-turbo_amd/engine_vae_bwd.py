@@ -29,15 +29,23 @@ class VAEDecodeGradEngine(VAEDecodeEngine):
         if plan is None:
             plan = self._record_grad(z, scale)
             self.plans[key] = plan
+            if getattr(self.ops, "is_native", False):
+                # recording executed the backward list once (on a zero gradient) and that recycled the saved forward
+                # buffers: run the forward list again so the tape holds this call's activations
+                self._replay(plan, "rec")
         else:
             plan["static"]["z"].copy_(z)
             self._replay(plan, "rec")
+        plan["fwd_id"] = plan.get("fwd_id", 0) + 1
         self._last = plan
         return plan["out"].clone()
 
     def backward(self, dout):
         """d(loss)/dz for the most recent ``decode_frames_tape`` call."""
         plan = self._last
+        if plan.get("bwd_id") == plan["fwd_id"]:
+            raise RuntimeError("VAE decode gradient: backward was already run for this forward (its saved activations are gone)")
+        plan["bwd_id"] = plan["fwd_id"]
         plan["static"]["dout"].copy_(dout)
         self._replay(plan, "rec_bwd")
         return plan["dz"].clone()

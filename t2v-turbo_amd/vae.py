@@ -238,11 +238,15 @@ class _NativeDecodeGrad(torch.autograd.Function):
         eng = vae.native_grad_engine()
         out = eng.decode_frames_tape(z.detach().unsqueeze(2), scale=1.0).squeeze(2)
         ctx.plan = eng._last
+        ctx.fwd_id = eng._last["fwd_id"]
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         eng = ctx.vae.native_grad_engine()
+        if ctx.plan["fwd_id"] != ctx.fwd_id:
+            raise RuntimeError("native VAE decode gradient keeps ONE outstanding decode per input shape: another decode of "
+                               "the same shape ran before this backward (set vae.native_mode = 'off' for the torch path)")
         eng._last = ctx.plan
         dz = eng.backward(grad_out.unsqueeze(2)).squeeze(2)
         return dz.to(ctx.z_dtype), None

@@ -47,6 +47,22 @@ def main():
         ms_enc = timed(lambda: ae.encode(vid))
     out["vae_decode_16f_320x512"] = {"ms": round(ms_dec, 2), "tflop": 25.02, "tflops": round(25.02 / ms_dec * 1e3, 1)}
     out["vae_encode_16f_320x512"] = {"ms": round(ms_enc, 2), "tflop": 11.04, "tflops": round(11.04 / ms_enc * 1e3, 1)}
+    # reward-gradient branch: decode 6 frames with grad w.r.t. the latents, backward from the image gradient
+    ae.requires_grad_(False)
+    z6 = torch.randn(6, 4, 40, 64, device=dev, dtype=torch.bfloat16, requires_grad=True)
+    gimg = torch.randn(6, 3, 320, 512, device=dev, dtype=torch.bfloat16)
+
+    def fwd_bwd():
+        z6.grad = None
+        ae.decode(z6).backward(gimg)
+
+    ms_fb = timed(fwd_bwd, iters=5, warm=2)
+    ae.native_mode = "off"
+    ms_fb_torch = timed(fwd_bwd, iters=3, warm=1)
+    ae.native_mode = "auto"
+    out["vae_decode_fwd_bwd_6f_320x512"] = {"ms_native": round(ms_fb, 2), "ms_torch_autograd_same_gpu": round(ms_fb_torch, 2),
+                                            "tflop_fwd_plus_dx": round(2 * 6 * 1.5635, 2),
+                                            "tflops_native": round(2 * 6 * 1.5635 / ms_fb * 1e3, 1)}
     del ae
     with torch.device(dev):
         ms_model = UNet3DConditionModel(time_cond_proj_dim=256)
