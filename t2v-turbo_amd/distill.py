@@ -1,5 +1,6 @@
-"""One v1 consistency-distillation step (reference ``train_t2v_turbo_v1_lora.py:978-1196`` without the
-reward branches): student forward with grad, teacher cond + uncond forwards, CFG estimate, one DDIM
+"""One v1 consistency-distillation step (reference ``train_t2v_turbo_v1_lora.py:978-1196``, with the image-reward branch
+:1043-1063 when a ``reward_fn`` is given; the reward models themselves are out of scope and stay whatever the caller
+passes): student forward with grad, teacher cond + uncond forwards, CFG estimate, one DDIM
 solver step, target forward with the student's own weights, pseudo-Huber / L2 loss, backward, flat
 gradient all-reduce, clip, optimizer step.
 
@@ -17,7 +18,8 @@ from . import cd_math
 def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_embeds, uncond_prompt_embeds, *,
                  optimizer=None, grad_sync=None, fps=16, topk=20, w_min=5.0, w_max=15.0, time_cond_proj_dim=256,
                  timestep_scaling_factor=10.0, loss_type="huber", huber_c=0.001, max_grad_norm=1.0,
-                 num_ddim_timesteps=50, generator=None, autocast_dtype=None, rng=None):
+                 num_ddim_timesteps=50, generator=None, autocast_dtype=None, rng=None, vae=None, reward_fn=None, text=None,
+                 reward_scale=0.0, reward_frame_bsz=5, reward_train_bsz=1, vae_scale_factor=0.18215):
     """Returns (loss, info).  ``rng`` may pin the random draws for tests: dict(index, noise, w)."""
     dev, bsz = latents.device, latents.shape[0]
     acp = noise_scheduler.alphas_cumprod.to(dev)
@@ -54,6 +56,21 @@ def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_em
     pred_x_0 = cd_math.get_predicted_original_sample(noise_pred, start_timesteps, noisy, "epsilon", alpha_schedule, sigma_schedule)
     model_pred = c_skip_start * noisy + c_out_start * pred_x_0
 
+    # reward branch (train_t2v_turbo_v1_lora.py:1043-1063): a few frames of model_pred -> frozen VAE decode -> reward
+    reward_loss = None
+    if reward_fn is not None and reward_scale > 0:
+        assert vae is not None, "the reward branch decodes through the VAE"
+        n_frames = model_pred.shape[2]
+        idx = rng["reward_frames"] if "reward_frames" in rng else torch.randperm(n_frames)[:reward_frame_bsz]
+        b_idx = rng["reward_batch"] if "reward_batch" in rng else torch.randperm(bsz)[:reward_train_bsz]
+        selected_text = None if text is None else [text[int(i)] for i in b_idx]
+        sel = model_pred[b_idx][:, :, idx] / vae_scale_factor
+        sel = sel.permute(0, 2, 1, 3, 4)
+        sel = sel.reshape(len(b_idx) * len(idx), *sel.shape[2:])
+        decoded = vae.decode(sel.to(vae.dtype))
+        decoded = (decoded / 2 + 0.5).clamp(0, 1)
+        reward_loss = -reward_fn(decoded, selected_text).mean() * reward_scale
+
     # 8. teacher cond / uncond -> CFG estimate -> one DDIM solver step (no grad; native engine on the GPU)
     with torch.no_grad():
         tdt = next(teacher_unet.parameters()).dtype
@@ -76,7 +93,10 @@ def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_em
         loss = F.mse_loss(model_pred.float(), target.float(), reduction="mean")
     else:
         loss = cd_math.huber_loss(model_pred, target, huber_c)
-    info = {"index": index, "start_timesteps": start_timesteps, "timesteps": timesteps}
+    info = {"index": index, "start_timesteps": start_timesteps, "timesteps": timesteps, "distill_loss": loss.detach()}
+    if reward_loss is not None:
+        info["reward_loss"] = reward_loss.detach()
+        loss = loss + reward_loss.to(loss.dtype)
     if optimizer is not None or grad_sync is not None:
         if grad_sync is not None:
             grad_sync.zero_()

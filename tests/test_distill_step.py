@@ -69,3 +69,47 @@ def test_distill_step_matches_oracle_math_and_trains_lora_only():
     assert moved > len(params) // 4  # lora_up tensors get gradient on step 1 (down's grad is zero while up == 0)
     base = dict(student.named_parameters())
     assert torch.equal(base["out.2.conv.weight"].detach(), sd["out.2.weight"])
+
+
+def test_reward_branch_adds_the_reference_term():
+    """Image-reward branch (train_t2v_turbo_v1_lora.py:1043-1063): -mean(reward(decode(model_pred frames))) * scale is added
+    to the distillation loss and its gradient reaches the LoRA tensors through the frozen VAE."""
+    from t2v_turbo_amd.vae import AutoencoderKL
+    from tests.util import VAE_TINY_DD
+    cfg = tiny_unet_params()
+    sd = synth_state_dict(manifest("unet_tiny"))
+    teacher = UNetModel(**tiny_unet_params(time_cond_proj_dim=None)).eval()
+    teacher.load_state_dict({k: v for k, v in sd.items() if not k.startswith("time_cond_proj")}, strict=True)
+    teacher.requires_grad_(False)
+    student = UNetModel(**cfg)
+    student.load_state_dict(sd, strict=True)
+    student.requires_grad_(False)
+    lora.inject_trainable_lora_extended(student, r=4)
+    student.eval()
+    for p in lora.lora_parameters(student):  # LoRA "up" starts at zero: give the adapters something to differentiate
+        if float(p.detach().abs().max()) == 0:
+            torch.nn.init.normal_(p, std=0.02, generator=torch.Generator().manual_seed(5))
+    vae = AutoencoderKL(ddconfig=dict(VAE_TINY_DD), embed_dim=4).eval().requires_grad_(False)
+    sched = T2VTurboScheduler()
+    solver = cd_math.DDIMSolver(sched.alphas_cumprod.numpy(), ddim_timesteps=50)
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(1, 4, 3, 8, 8, generator=g)
+    pe, ue = torch.randn(1, 77, 128, generator=g), torch.randn(1, 77, 128, generator=g)
+    rng = dict(index=torch.tensor([7]), noise=torch.randn(lat.shape, generator=g), w=torch.tensor([8.0]),
+               reward_frames=torch.tensor([2, 0]), reward_batch=torch.tensor([0]))
+    seen = {}
+
+    def reward_fn(imgs, text):
+        seen["shape"], seen["text"] = tuple(imgs.shape), text
+        assert float(imgs.min()) >= 0 and float(imgs.max()) <= 1
+        return imgs.mean(dim=(1, 2, 3))
+
+    base, _ = distill_step(student, teacher, solver, sched, lat, pe, ue, rng=rng)
+    params = lora.lora_parameters(student)
+    sync = FlatGradSync(params)
+    loss, info = distill_step(student, teacher, solver, sched, lat, pe, ue, grad_sync=sync, rng=rng, vae=vae, reward_fn=reward_fn,
+                              text=["a cat"], reward_scale=2.0, reward_frame_bsz=2)
+    assert seen["shape"] == (2, 3, 64, 64) and seen["text"] == ["a cat"]
+    assert torch.allclose(info["distill_loss"], base.detach(), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(loss.detach(), info["distill_loss"] + info["reward_loss"], rtol=1e-6)
+    assert float(info["reward_loss"]) < 0 and float(sync.flat.abs().sum()) > 0
