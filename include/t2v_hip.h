@@ -186,6 +186,13 @@ int t2v_lcm_step(const float* x, const void* eps, int eps_dt, const float* noise
                  float sb_t, float c_skip, float c_out, float sa_p, float sb_p, long long n,
                  float* prev, float* denoised, void* stream);
 
+/* ---------------------------------------------------------------- diagnostics (tools/ only)
+ * Ablation bits for tools/gemm_one.py and tools/attn_one.py.  They only act in libraries built with
+ * -DT2V_GEMM_ABLATE / -DT2V_ATTN_ABLATE (runtime branches inside the K / KV loops cost ~20 %, so the product build
+ * compiles them out and these calls just store the value). */
+int t2v_gemm_debug(int bits);
+int t2v_attn_debug(int bits);
+
 /* ---------------------------------------------------------------- backward (dX) pieces of the VAE decoder
  * Reward-gradient branch (train_t2v_turbo_v1_lora.py:1047-1098: autograd through vae.decode, ae_modules.py:602-641).
  * Conv / linear data gradients are t2v_gemm launches on re-packed weights; these are the non-GEMM parts.

@@ -78,6 +78,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--vae", type=int, default=1)
     ap.add_argument("--out", default=os.path.join(ROOT, "t2v-turbo_amd", "gemm_tune.json"))
+    ap.add_argument("--widen", type=int, default=1, help="also tune the VAE encode / decode-gradient / ModelScope shapes")
     ap.add_argument("--cold", type=int, default=0, help="evict caches before every timed launch (what the UNet step sees)")
     args = ap.parse_args()
     os.environ["T2V_GEMM_TUNE"] = "0"  # record with the library heuristics
@@ -101,6 +102,29 @@ def main():
         with torch.no_grad():
             ae.decode_video(torch.randn(1, 4, 16, 40, 64, device=dev, dtype=torch.bfloat16))
         recs.append(next(iter(ae.native_engine().plans.values()))["rec"])
+        if args.widen:  # the rows beyond the headline step: VAE encode, reward-branch decode gradient, ModelScope denoiser
+            with torch.no_grad():
+                ae.encode(torch.randn(16, 3, 320, 512, device=dev, dtype=torch.bfloat16))
+            recs.append(next(iter(ae._engine_box.enc.plans.values()))["rec"])
+            ae.requires_grad_(False)
+            z6 = torch.randn(6, 4, 40, 64, device=dev, dtype=torch.bfloat16, requires_grad=True)
+            ae.decode(z6).backward(torch.randn(6, 3, 320, 512, device=dev, dtype=torch.bfloat16))
+            gp = next(iter(ae._engine_box.grad.plans.values()))
+            recs += [gp["rec"], gp["rec_bwd"]]
+            del ae
+            from oracle import synth
+            from t2v_turbo_amd.ms_unet3d import UNet3DConditionModel
+            with torch.device(dev):
+                ms = UNet3DConditionModel(time_cond_proj_dim=256)
+            for k, v in ms.state_dict().items():
+                if float(v.abs().max()) == 0:
+                    v.copy_(synth.synth_tensor(k, v.shape).to(v))
+            ms = ms.to(torch.bfloat16).eval()
+            with torch.no_grad():
+                ms(torch.randn(1, 4, 16, 32, 32, device=dev, dtype=torch.bfloat16), torch.tensor([999], device=dev),
+                   torch.randn(1, 77, 1024, device=dev, dtype=torch.bfloat16),
+                   timestep_cond=torch.randn(1, 256, device=dev, dtype=torch.bfloat16))
+            recs.append(next(iter(ms.native_engine().plans.values()))["rec"])
     lib = nt.load()
     ncfg = lib.t2v_gemm_num_configs()
     stream = torch.cuda.current_stream().cuda_stream
