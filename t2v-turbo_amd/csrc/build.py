@@ -10,7 +10,7 @@ ROOT = os.path.dirname(PKG)
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip"]
 LIB = os.path.join(PKG, "libt2v_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-         "-I", os.path.join(ROOT, "include"), "-I", HERE]
+         "-I", os.path.join(ROOT, "include"), "-I", HERE] + os.environ.get("T2V_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():

@@ -25,7 +25,9 @@ def main():
     ap.add_argument("--split", type=int, default=0)
     ap.add_argument("--act", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--debug", type=int, default=0)
+    ap.add_argument("--debug", type=int, default=0, help="ablation bits; need a -DT2V_GEMM_ABLATE build (T2V_EXTRA_HIPCC_FLAGS)")
+    ap.add_argument("--res", type=int, default=0, help="add a residual input")
+    ap.add_argument("--graph", type=int, default=1, help="time inside a hipGraph")
     a = ap.parse_args()
     ops = nt.HipOps()
     ops.init()
@@ -39,17 +41,31 @@ def main():
     wt = (torch.randn(a.n, taps * a.cin, device="cuda") * (taps * a.cin) ** -0.5).bfloat16()
     bias = torch.randn(a.n, device="cuda")
     out = torch.empty(M, a.n // 2 if a.act == 1 else a.n, device="cuda", dtype=torch.bfloat16)
+    res = torch.randn(M, a.n, device="cuda").bfloat16() if a.res else None
     kw = dict(M=M, N=a.n, mode=a.mode, n_img=a.nimg, h=a.h, wd=a.w, frames=a.frames, bias=bias, act=a.act,
-              tile_cfg=a.cfg, split_k=a.split)
+              tile_cfg=a.cfg, split_k=a.split, residual=res)
     for _ in range(3):
         ops.gemm(x, wt, out, **kw)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(a.iters):
-        ops.gemm(x, wt, out, **kw)
-    e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / a.iters
+    if a.graph:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(a.iters):
+                ops.gemm(x, wt, out, **kw)
+        g.replay()
+        torch.cuda.synchronize()
+    us = 1e30
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if a.graph:
+            g.replay()
+        else:
+            for _ in range(a.iters):
+                ops.gemm(x, wt, out, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = min(us, e0.elapsed_time(e1) * 1e3 / a.iters)
     print(f"debug={a.debug} mode={a.mode} M={M} N={a.n} K={taps * a.cin} cfg={a.cfg} split={a.split}: {us:.1f} us  "
           f"{2.0 * M * a.n * taps * a.cin / us / 1e6:.1f} TF/s")
 
