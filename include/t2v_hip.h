@@ -94,12 +94,6 @@ typedef struct t2v_gemm_desc {
     int tile_cfg, split_k;
     void* ws;
     long long ws_bytes;
-    /* LayerNorm of the A rows folded into the GEMM (attention.py:300-311 pre-LN blocks): the caller passes RAW rows,
-     * weights pre-scaled by gamma (W' = W diag(gamma), bias' = bias + W beta), per-row (mean, rstd) from
-     * t2v_row_stats and ln_colsum[n] = sum_k W'[n][k]; the epilogue starts with acc <- rstd[m] * (acc - mean[m] * ln_colsum[n]).
-     * NULL = off.  LINEAR mode, batch 1 only. */
-    const float* ln_stats;  /* fp32 [M][2] */
-    const float* ln_colsum; /* fp32 [N] */
 } t2v_gemm_desc;
 
 int t2v_gemm(const t2v_gemm_desc* d, void* stream);
@@ -136,9 +130,6 @@ int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, int c1, int 
                    void* stream);
 
 /* LayerNorm over the channel dim, eps, affine; bf16 in/out (attention.py:279-281). */
-/* per-row (mean, rstd) of a bf16 [M][C] matrix, fp32 [M][2]: the statistics half of a LayerNorm whose affine half is folded
- * into the consuming GEMM (t2v_gemm_desc.ln_stats). */
-int t2v_row_stats(const void* x, int ldx, int M, int C, float eps, float* stats, void* stream);
 int t2v_layernorm(const void* x, int ldx, int M, int C, const float* gamma, const float* beta,
                   float eps, void* out, int ldo, void* stream);
 

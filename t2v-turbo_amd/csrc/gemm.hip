@@ -87,21 +87,6 @@ struct Epi {
         const t2v_gemm_desc& dd = *d;
         if (ch_out >= n_out) return;
         const bool full = vec && ch_out + 16 <= n_out;
-        float gt[16];
-        if (gate) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) gt[e] = gate[e];
-        }
-        if (dd.ln_stats) {  // folded LayerNorm: acc <- rstd * (acc - mean * colsum[n]) on the raw-row product
-            const float2 st = *(const float2*)(dd.ln_stats + (long long)gm * 2);
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                if (ch_in + e < dd.N) v[e] = st.y * (v[e] - st.x * dd.ln_colsum[ch_in + e]);
-            if (gate) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) gt[e] = st.y * (gt[e] - st.x * dd.ln_colsum[ch_in + 32 + e]);
-            }
-        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] *= dd.alpha;
         if (dd.bias) {
@@ -122,10 +107,10 @@ struct Epi {
             for (int q = 0; q < 4; ++q) {
                 float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (dd.bias) b = *(const float4*)(dd.bias + ch_in + 32 + 4 * q);
-                v[4 * q] *= fast_gelu(gt[4 * q] * dd.alpha + b.x);
-                v[4 * q + 1] *= fast_gelu(gt[4 * q + 1] * dd.alpha + b.y);
-                v[4 * q + 2] *= fast_gelu(gt[4 * q + 2] * dd.alpha + b.z);
-                v[4 * q + 3] *= fast_gelu(gt[4 * q + 3] * dd.alpha + b.w);
+                v[4 * q] *= fast_gelu(gate[4 * q] * dd.alpha + b.x);
+                v[4 * q + 1] *= fast_gelu(gate[4 * q + 1] * dd.alpha + b.y);
+                v[4 * q + 2] *= fast_gelu(gate[4 * q + 2] * dd.alpha + b.z);
+                v[4 * q + 3] *= fast_gelu(gate[4 * q + 3] * dd.alpha + b.w);
             }
         }
         if (dd.rowvec) {
@@ -693,8 +678,6 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     T2V_REQUIRE(d.ldw >= p.K, T2V_EINVAL, "t2v_gemm: ldw < K");
     if (d.act == T2V_ACT_GEGLU) T2V_REQUIRE(d.N % 128 == 0, T2V_ESHAPE, "t2v_gemm: GEGLU needs N % 128 == 0");
     if (d.rowvec) T2V_REQUIRE(d.rowvec_div > 0, T2V_EINVAL, "t2v_gemm: rowvec_div");
-    if (d.ln_stats) T2V_REQUIRE(d.ln_colsum && d.mode == T2V_GEMM_LINEAR && d.batch == 1, T2V_EINVAL,
-                                "t2v_gemm: folded LayerNorm needs ln_colsum, LINEAR mode and batch 1");
     p.zero = t2v_zero_page();
     T2V_REQUIRE(p.zero, T2V_EHIP, "t2v_gemm: zero page allocation failed");
     const int n_out = d.act == T2V_ACT_GEGLU ? d.N / 2 : d.N;

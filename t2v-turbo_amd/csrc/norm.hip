@@ -318,46 +318,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, int ldx
     }
 }
 
-// ---- per-row (mean, rstd): LayerNorm statistics for GEMMs that fold the affine part (t2v_gemm_desc.ln_stats) ----
-template <int NJ, int ROWS>
-__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* x, int ldx, int M, int C, float eps, float* stats) {
-    const int lane = threadIdx.x & 63;
-    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
-    if (row0 >= M) return;
-    const int cpr = C / 8;
-    uint4 u[ROWS][NJ];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int ci = lane + j * 64;
-            u[r][j] = (ci < cpr && row0 + r < M) ? *(const uint4*)(x + (row0 + r) * ldx + ci * 8) : make_uint4(0, 0, 0, 0);
-        }
-    const float inv_c = 1.0f / (float)C;
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        if (row0 + r >= M) break;
-        float v[NJ][8];
-        float s = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            unpack8(u[r][j], v[j]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += v[j][e];
-        }
-        const float mean = wave_sum(s) * inv_c;
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            if (lane + j * 64 < cpr) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float dlt = v[j][e] - mean; q += dlt * dlt; }
-            }
-        const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
-        if (lane == 0) *(float2*)(stats + (row0 + r) * 2) = make_float2(mean, rstd);
-    }
-}
-
 // ---- row softmax, one wave per row, row in registers (n_pad <= 64*8*SM_MAX = 4096) -----------
 constexpr int SM_MAX = 8;
 __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* s, long long rows, int n, int n_pad, int ld) {
@@ -518,23 +478,6 @@ extern "C" int t2v_layernorm(const void* x, int ldx, int M, int C, const float* 
     else if (nj == 4) T2V_LN_LAUNCH(4, 2);
     else T2V_LN_LAUNCH(8, 1);
 #undef T2V_LN_LAUNCH
-    T2V_CHECK_LAUNCH();
-    return T2V_OK;
-}
-
-extern "C" int t2v_row_stats(const void* x, int ldx, int M, int C, float eps, float* stats, void* stream) {
-    T2V_REQUIRE(x && stats && M > 0, T2V_EINVAL, "t2v_row_stats: bad argument");
-    T2V_REQUIRE(C % 8 == 0 && C <= 64 * 8 * LN_MAX && ldx % 8 == 0, T2V_ESHAPE, "t2v_row_stats: unsupported C");
-    const int nj = (C / 8 + 63) / 64;
-#define T2V_RS_LAUNCH(NJ, ROWS)                                                                                            \
-    hipLaunchKernelGGL((row_stats_kernel<NJ, ROWS>), dim3((M + 4 * ROWS - 1) / (4 * ROWS)), dim3(256), 0, (hipStream_t)stream, \
-                       (const bf16_t*)x, ldx, M, C, eps, stats)
-    if (nj == 1) T2V_RS_LAUNCH(1, 4);
-    else if (nj == 2) T2V_RS_LAUNCH(2, 4);
-    else if (nj == 3) T2V_RS_LAUNCH(3, 2);
-    else if (nj == 4) T2V_RS_LAUNCH(4, 2);
-    else T2V_RS_LAUNCH(8, 1);
-#undef T2V_RS_LAUNCH
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }

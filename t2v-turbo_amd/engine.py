@@ -140,36 +140,6 @@ class Packer:
             return w.reshape(w.shape[0], -1).to(self.device, self.wdtype).contiguous()
         return self._memo(("conv", id(mod)), make)
 
-    def ln_mats(self, norm, mods, tag):
-        """LayerNorm folded into the Linear(s) that consume it: (W' = [W_0; W_1; ...] diag(gamma) in bf16,
-        bias' = bias + W beta, colsum[n] = sum_k W'[n][k] of the ROUNDED weights — what the MFMA actually sums)."""
-        def make():
-            ws = [effective_weight_bias(m)[0].float().reshape(effective_weight_bias(m)[0].shape[0], -1) for m in mods]
-            bs = [effective_weight_bias(m)[1] for m in mods]
-            w = torch.cat(ws, dim=0)
-            g, b = norm.weight.detach().float().to(w.device), norm.bias.detach().float().to(w.device)
-            bias = torch.cat([torch.zeros(x.shape[0], device=w.device) if bb is None else bb.detach().float().to(w.device)
-                              for x, bb in zip(ws, bs)])
-            wq = (w * g[None, :]).to(self.device, self.wdtype).contiguous()
-            return wq, (bias + w @ b).to(self.device).contiguous(), wq.float().sum(dim=1).contiguous()
-        return self._memo((tag, id(norm)) + tuple(id(m) for m in mods), make)
-
-    def ln_geglu(self, norm, proj):
-        """GEGLU projection with the preceding LayerNorm folded, packed [32 value | 32 gate] like ``geglu``."""
-        def make():
-            w, b = effective_weight_bias(proj)
-            w = w.float()
-            g, be = norm.weight.detach().float().to(w.device), norm.bias.detach().float().to(w.device)
-            b2 = b.detach().float() + w @ be
-            w2 = w * g[None, :]
-            inner = w2.shape[0] // 2
-            assert inner % 32 == 0
-            wp = torch.cat([w2[:inner].reshape(inner // 32, 32, -1), w2[inner:].reshape(inner // 32, 32, -1)], dim=1)
-            wp = wp.reshape(2 * inner, -1).to(self.device, self.wdtype).contiguous()
-            bp = torch.cat([b2[:inner].reshape(-1, 32), b2[inner:].reshape(-1, 32)], dim=1).reshape(-1)
-            return wp, bp.to(self.device).contiguous(), wp.float().sum(dim=1).contiguous()
-        return self._memo(("ln_geglu", id(norm), id(proj)), make)
-
     def mat_t(self, mod):
         """[K, N]^T pack of a Linear / 1x1 conv: the weight of its data gradient (dx = dy @ W)."""
         def make():
@@ -262,13 +232,12 @@ class _Engine:
         self.pool.put(ws)
         return out
 
-    def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None, ln=None):
+    def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None):
         w = self.pk.mat(mod) if w is None else w
         bias = self.pk.bias(mod) if isinstance(bias, str) else bias
         N = w.shape[0] if N is None else N
         out = self.buf(a.shape[0], N // 2 if act == nt.ACT_GEGLU else N, out_dtype)
-        kw = {} if ln is None else dict(ln_stats=ln[0], ln_colsum=ln[1])
-        self.ops.gemm(a, w, out, M=a.shape[0], N=N, bias=bias, residual=residual, act=act, **kw)
+        self.ops.gemm(a, w, out, M=a.shape[0], N=N, bias=bias, residual=residual, act=act)
         return out
 
     def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto"):
@@ -580,28 +549,14 @@ class UNetEngine(_Engine):
         a1, a2 = blk.attn1, blk.attn2
         self._check_heads(a1)
         inner = a1.heads * a1.dim_head
-        # LayerNorm folded into the consuming GEMM (row statistics + epilogue affine, t2v_gemm_desc.ln_stats).  Off by
-        # default: measured on MI355X it LOSES 1.0 ms per step (28.0 vs 27.0 ms) — at these sizes LayerNorm is latency-
-        # bound, so the statistics pass costs what the full LayerNorm did and the epilogue work lands on the critical
-        # path of the short-K GEMMs.  Kept for larger batches where the saved HBM pass starts to matter.
-        fold = os.environ.get("T2V_FOLD_LN", "0") == "1"
-        stats = self.buf(M, 2, torch.float32) if fold else None
-        ln = self.buf(M, C) if (not fold or not temporal) else None
+        ln = self.buf(M, C)
 
         def lnorm(norm, src):
             ops.layernorm(src, pk.f32(norm.weight), pk.f32(norm.bias), norm.eps, ln)
             return ln
 
-        def rstats(norm, src):
-            ops.row_stats(src, norm.eps, stats)
-            return stats
-
-        def temporal_attn(attn, norm, src):
-            if fold:
-                wq, bq, cs = pk.ln_mats(norm, [attn.to_q, attn.to_k, attn.to_v], "ln_qkv")
-                qkv = self.linear(src, None, w=wq, bias=bq, ln=(rstats(norm, src), cs))
-            else:
-                qkv = self.linear(lnorm(norm, src), None, w=pk.cat_mats([attn.to_q, attn.to_k, attn.to_v], "qkv"), bias=None)
+        def temporal_attn(attn, src):
+            qkv = self.linear(src, None, w=pk.cat_mats([attn.to_q, attn.to_k, attn.to_v], "qkv"), bias=None)
             o = self.buf(M, inner)
             probs = None
             if attn.record_attn_probs:
@@ -612,9 +567,7 @@ class UNetEngine(_Engine):
             self.pool.put(qkv)
             return o
 
-        def spatial_self_attn(attn, norm, src):
-            # V^T needs the normalised rows as the COLUMN operand of a transposed GEMM, so this LayerNorm is materialised
-            src = lnorm(norm, src)
+        def spatial_self_attn(attn, src):
             qk = self.linear(src, None, w=pk.cat_mats([attn.to_q, attn.to_k], "qk"), bias=None)
             kp = ((hw + 63) // 64) * 64
             vt = self.buf(n_img * inner, kp)
@@ -628,12 +581,8 @@ class UNetEngine(_Engine):
             self.pool.put(qk, vt)
             return o
 
-        def cross_attn(attn, norm, src):
-            if fold:
-                wq, bq, cs = pk.ln_mats(norm, [attn.to_q], "ln_q")
-                q = self.linear(src, None, w=wq, bias=bq, ln=(rstats(norm, src), cs))
-            else:
-                q = self.linear(lnorm(norm, src), attn.to_q, bias=None)
+        def cross_attn(attn, src):
+            q = self.linear(src, attn.to_q, bias=None)
             k, vt, kp, vt_stride = self.context_kv(attn)
             o = self.buf(M, inner)
             ops.attn_spatial(q, k, vt, kp, o, n_img, hw, self.ctx_len, attn.heads, F, attn.scale, vt_stride)
@@ -641,24 +590,23 @@ class UNetEngine(_Engine):
             return o
 
         # attn1: self attention (spatial or temporal)
-        o = temporal_attn(a1, blk.norm1, y) if temporal else spatial_self_attn(a1, blk.norm1, y)
+        src = lnorm(blk.norm1, y)
+        o = temporal_attn(a1, src) if temporal else spatial_self_attn(a1, src)
         y1 = self.linear(o, a1.to_out[0], residual=y)
         self.pool.put(o)
         # attn2: temporal self attention again, or text cross attention
-        o = temporal_attn(a2, blk.norm2, y1) if temporal else cross_attn(a2, blk.norm2, y1)
+        src = lnorm(blk.norm2, y1)
+        o = temporal_attn(a2, src) if temporal else cross_attn(a2, src)
         y2 = self.linear(o, a2.to_out[0], residual=y1)
         self.pool.put(o, y1)
         # GEGLU feed-forward
+        src = lnorm(blk.norm3, y2)
         proj = blk.ff.net[0]
         assert hasattr(proj, "proj"), "non-gated FeedForward is not built by the VideoCrafter2 config"
-        if fold:
-            wg, bg, cs = pk.ln_geglu(blk.norm3, proj.proj)
-            g = self.linear(y2, None, w=wg, bias=bg, act=nt.ACT_GEGLU, ln=(rstats(blk.norm3, y2), cs))
-        else:
-            wg, bg = pk.geglu(proj.proj)
-            g = self.linear(lnorm(blk.norm3, y2), None, w=wg, bias=bg, act=nt.ACT_GEGLU)
+        wg, bg = pk.geglu(proj.proj)
+        g = self.linear(src, None, w=wg, bias=bg, act=nt.ACT_GEGLU)
         y3 = self.linear(g, blk.ff.net[2], residual=y2)
-        self.pool.put(g, y2, ln, stats)
+        self.pool.put(g, y2, ln)
         return y3
 
     def spatial_transformer(self, st, x):

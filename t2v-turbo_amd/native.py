@@ -35,7 +35,6 @@ class GemmDesc(C.Structure):
         ("rowvec_div", C.c_int), ("ld_rowvec", C.c_int), ("residual", C.c_void_p), ("ldr", C.c_int),
         ("act", C.c_int), ("out", C.c_void_p), ("ldo", C.c_int), ("out_f32", C.c_int),
         ("tile_cfg", C.c_int), ("split_k", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_longlong),
-        ("ln_stats", C.c_void_p), ("ln_colsum", C.c_void_p),
     ]
 
 
@@ -64,7 +63,6 @@ _SIGS = {
     "t2v_group_norm_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "t2v_group_norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "t2v_row_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "t2v_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                 C.c_void_p, C.c_int, C.c_void_p]),
     "t2v_softmax_rows": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -201,10 +199,8 @@ class HipOps:
     # -- ops ----------------------------------------------------------------------------------------
     def gemm(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
              rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
-             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, ln_stats=None, ln_colsum=None):
+             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0):
         d = GemmDesc()
-        if ln_stats is not None:
-            d.ln_stats, d.ln_colsum = _p(ln_stats), _p(ln_colsum)
         d.a0, d.c0, d.lda0 = _p(a0), a0.shape[1], _row_stride(a0)
         if a1 is not None:
             d.a1, d.c1, d.lda1 = _p(a1), a1.shape[1], _row_stride(a1)
@@ -254,9 +250,6 @@ class HipOps:
         self._call("t2v_group_norm", _p(x0), x0.shape[1], _row_stride(x0), _p(x1),
                    0 if x1 is None else x1.shape[1], 0 if x1 is None else _row_stride(x1),
                    n_units, rows_per_unit, groups, eps, _p(gamma), _p(beta), int(silu), _p(ws), _p(out), _row_stride(out))
-
-    def row_stats(self, x, eps, stats):
-        self._call("t2v_row_stats", _p(x), _row_stride(x), x.shape[0], x.shape[1], eps, _p(stats))
 
     def layernorm(self, x, gamma, beta, eps, out):
         self._call("t2v_layernorm", _p(x), _row_stride(x), x.shape[0], x.shape[1], _p(gamma), _p(beta), eps, _p(out),

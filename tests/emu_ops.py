@@ -35,7 +35,7 @@ class EmuOps:
     # ------------------------------------------------------------------------------------ gemm
     def gemm(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
              rowvec=None, rowvec_div=0, residual=None, act=nt.ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
-             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), ln_stats=None, ln_colsum=None):
+             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0)):
         self._log("gemm")
         c0 = a0.shape[1]
         c1 = 0 if a1 is None else a1.shape[1]
@@ -79,9 +79,6 @@ class EmuOps:
                     raise ValueError(mode)
                 y = y.permute(0, 2, 3, 1).reshape(-1, N)
             assert y.shape[0] == M, (y.shape, M)
-            if ln_stats is not None:  # folded LayerNorm on the raw-row product
-                st = ln_stats.float()
-                y = st[:, 1:2] * (y - st[:, 0:1] * ln_colsum.float()[None, :N])
             y = y * alpha
             if bias is not None:
                 y = y + bias.float()[None, :N]
@@ -191,13 +188,6 @@ class EmuOps:
         C = src.shape[1]
         v = src.float().reshape(n_img, h, 2, w, 2, C).sum(dim=(2, 4))
         out.copy_(v.reshape(-1, C).to(out.dtype))
-
-    def row_stats(self, x, eps, stats):
-        self._log("row_stats")
-        xf = x.float()
-        mean = xf.mean(dim=1)
-        var = xf.var(dim=1, unbiased=False)
-        stats.copy_(torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=1))
 
     def layernorm(self, x, gamma, beta, eps, out):
         self._log("layernorm")

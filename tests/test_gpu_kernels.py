@@ -380,29 +380,3 @@ def test_transpose_and_sumpool(pair):
     o_e = torch.zeros(2 * 3 * 5, 64)
     pair.run("sumpool2x2", (x[0], 2, 3, 5, o_h), (x[1], 2, 3, 5, o_e))
     assert rel_l2(o_h.float().cpu(), o_e) < BF16_TOL
-
-
-@pytest.mark.parametrize("M,C,N,act", [(300, 320, 960, 0), (77, 640, 256, 1), (1000, 1280, 320, 0)])
-def test_gemm_with_folded_layernorm(pair, M, C, N, act):
-    """t2v_row_stats + the ln_stats / ln_colsum epilogue == LayerNorm followed by the plain GEMM (within bf16 rounding)."""
-    x = pair.act((_rt(M, C, seed=1) * 2.0 + 0.7).bfloat16().float())
-    gamma, beta = _rt(C, seed=3) * 0.2 + 1.0, _rt(C, seed=4) * 0.2
-    w = _rt(N, C, seed=5) * C ** -0.5
-    b = _rt(N, seed=6)
-    wq = (w * gamma[None, :]).bfloat16().float()
-    wp, cs, bias = pair.act(wq), pair.f32(wq.sum(dim=1)), pair.f32(b + w @ beta)
-    st_h, st_e = torch.zeros(M, 2, device="cuda"), torch.zeros(M, 2)
-    pair.run("row_stats", (x[0], 1e-5, st_h), (x[1], 1e-5, st_e))
-    assert rel_l2(st_h.cpu(), st_e) < 1e-5
-    n_out = N // 2 if act else N
-    out_h = torch.zeros(M, n_out, dtype=torch.bfloat16, device="cuda")
-    out_e = torch.zeros(M, n_out)
-    pair.run("gemm", (x[0], wp[0], out_h), (x[1], wp[1], out_e), dict(M=M, N=N, bias=bias[0], act=act, ln_stats=st_h, ln_colsum=cs[0]),
-             dict(M=M, N=N, bias=bias[1], act=act, ln_stats=st_e, ln_colsum=cs[1]))
-    assert rel_l2(out_h.float().cpu(), out_e) < BF16_TOL
-    # reference semantics: LayerNorm then Linear (GEGLU rows are packed [32 value | 32 gate] per 64)
-    y = torch.nn.functional.layer_norm(x[1], (C,), gamma, beta, 1e-5) @ w.t() + b
-    if act:
-        gg = y.reshape(M, N // 64, 2, 32)
-        y = (gg[:, :, 0] * torch.nn.functional.gelu(gg[:, :, 1])).reshape(M, N // 2)
-    assert rel_l2(out_e, y) < 6e-3  # only the bf16 rounding of W*gamma separates them
