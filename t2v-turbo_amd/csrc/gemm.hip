@@ -82,11 +82,15 @@ struct Epi {
     int n_out, vec;
     // pre_res: the run's 16 residual values already in registers (issued for the whole wave tile before the first
     // store, so their latency is paid once instead of once per run behind the previous run's stores)
+    // FAST: every run is a full, 16-byte aligned run (host-checked: vector-aligned operands, n_out % 16 == 0): the
+    // per-element partial paths compile away.  The epilogue is unrolled over the wave tile, so this is most of the kernel's
+    // code size, and these kernels pay for instruction fetch (a ~10 % longer epilogue measured 6 % slower end to end).
+    template <bool FAST = false>
     __device__ __forceinline__ void run(float* v, const float* gate, int gm, int ch_in, int ch_out, bool has_pre = false,
                                         uint4 pre0 = uint4{0, 0, 0, 0}, uint4 pre1 = uint4{0, 0, 0, 0}) const {
         const t2v_gemm_desc& dd = *d;
         if (ch_out >= n_out) return;
-        const bool full = vec && ch_out + 16 <= n_out;
+        const bool full = FAST || (vec && ch_out + 16 <= n_out);
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] *= dd.alpha;
         if (dd.bias) {
@@ -172,7 +176,7 @@ struct Epi {
 
 // BK = K elements per pipeline step (LDS rows of BK*2 bytes); WPE = waves per SIMD the register budget is
 // sized for (2 x 4-wave workgroups or one 8-wave workgroup per CU at WPE = 2)
-template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4, bool FAST = false>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
                     float v[16], gt[16];
 #pragma unroll
                     for (int e = 0; e < 16; ++e) { v[e] = acc[i][2 * u][e]; gt[e] = acc[i][2 * u + 1][e]; }
-                    epi.run(v, gt, gm, ch_lane + u * 64, (n0 + wave_n * WTN) / 2 + u * 32 + 16 * hi);
+                    epi.template run<FAST>(v, gt, gm, ch_lane + u * 64, (n0 + wave_n * WTN) / 2 + u * 32 + 16 * hi);
                 }
             }
         }
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
                 float v[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
-                epi.run(v, nullptr, gm, ch_lane + j * 32, ch_lane + j * 32, pre, rres[ii][j][0], rres[ii][j][1]);
+                epi.template run<FAST>(v, nullptr, gm, ch_lane + j * 32, ch_lane + j * 32, pre, rres[ii][j][0], rres[ii][j][1]);
             }
         }
     }
@@ -547,8 +551,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     epi.run(v, nullptr, gm, ch, ch);
 }
 
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST>
+int launch_impl(GemmParams& p, hipStream_t s);
+
 template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4>
 int launch(GemmParams& p, hipStream_t s) {
+    const int n_out = p.d.act == T2V_ACT_GEGLU ? p.d.N / 2 : p.d.N;
+    const bool fast = p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1;
+    return fast ? launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true>(p, s) : launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, false>(p, s);
+}
+
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST>
+int launch_impl(GemmParams& p, hipStream_t s) {
     p.tiles_m = (p.d.M + BM - 1) / BM;
     p.tiles_n = (p.d.N + BN - 1) / BN;
     {   // XCD grid: minimise xcd_n * A_bytes + xcd_m * W_bytes over the factorizations of 8 that the tile grid allows
@@ -569,10 +583,10 @@ int launch(GemmParams& p, hipStream_t s) {
     constexpr int smem = STAGES * (BM + BN) * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE>), grid, dim3(WM * WN * 64), smem, s, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST>), grid, dim3(WM * WN * 64), smem, s, p);
     T2V_CHECK_LAUNCH();
     if (p.splits > 1) {
         const long long work = (long long)p.d.M * ((p.d.N + 15) / 16);
