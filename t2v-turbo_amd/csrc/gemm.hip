@@ -91,9 +91,14 @@ struct Epi {
         const t2v_gemm_desc& dd = *d;
         if (ch_out >= n_out) return;
         const bool full = FAST || (vec && ch_out + 16 <= n_out);
+        // FAST kernels (alpha == 1, host-checked) start their accumulators at bias (+ rowvec + residual when there is no
+        // gate), so those terms cost nothing here and the residual's latency hides under the main loop
+        constexpr bool FOLD = FAST;
+        if (!FOLD) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] *= dd.alpha;
-        if (dd.bias) {
+            for (int e = 0; e < 16; ++e) v[e] *= dd.alpha;
+        }
+        if (!FOLD && dd.bias) {
             if (full) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -110,14 +115,16 @@ struct Epi {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (dd.bias) b = *(const float4*)(dd.bias + ch_in + 32 + 4 * q);
-                v[4 * q] *= fast_gelu(gate[4 * q] * dd.alpha + b.x);
-                v[4 * q + 1] *= fast_gelu(gate[4 * q + 1] * dd.alpha + b.y);
-                v[4 * q + 2] *= fast_gelu(gate[4 * q + 2] * dd.alpha + b.z);
-                v[4 * q + 3] *= fast_gelu(gate[4 * q + 3] * dd.alpha + b.w);
+                if (!FOLD && dd.bias) b = *(const float4*)(dd.bias + ch_in + 32 + 4 * q);
+                const float al = FOLD ? 1.0f : dd.alpha;
+                v[4 * q] *= fast_gelu(gate[4 * q] * al + b.x);
+                v[4 * q + 1] *= fast_gelu(gate[4 * q + 1] * al + b.y);
+                v[4 * q + 2] *= fast_gelu(gate[4 * q + 2] * al + b.z);
+                v[4 * q + 3] *= fast_gelu(gate[4 * q + 3] * al + b.w);
             }
         }
-        if (dd.rowvec) {
+        const bool folded_rr = FOLD && !gate;  // rowvec / residual already inside the accumulators
+        if (dd.rowvec && !folded_rr) {
             const float* rv = dd.rowvec + (long long)(gm / dd.rowvec_div) * dd.ld_rowvec + ch_out;
             if (full) {
 #pragma unroll
@@ -131,7 +138,7 @@ struct Epi {
                     if (ch_out + e < n_out) v[e] += rv[e];
             }
         }
-        if (dd.residual) {
+        if (dd.residual && !folded_rr) {
             const bf16_t* rp = (const bf16_t*)dd.residual + o_off + (long long)gm * dd.ldr + ch_out;
             if (full) {
                 float rf[16];
@@ -322,13 +329,39 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 
     // ---- fragment read addressing ---------------------------------------------------------------
     const int frow = lane & 31, hi = lane >> 5, swz = swz_of(frow);
+    const int ch_lane = n0 + wave_n * WTN + 16 * hi;
     f32x16_t acc[TM][TN];
+    // FAST kernels: the loads of everything linear in the epilogue (bias, and without a gate the time-embedding row vector
+    // and the residual tile) are issued HERE, before the DMA prologue, and turned into the accumulators' initial values
+    // after it — their latency hides under the first tiles' flight instead of sitting after the last MFMA.
+    constexpr bool FOLD = FAST;
+    const bool fold_rr = FOLD && d.act != T2V_ACT_GEGLU && p.splits == 1;
+    uint4 rinit[FOLD ? TM : 1][FOLD ? TN : 1][2];
+    float4 binit[FOLD ? TN : 1][4];
+    if constexpr (FOLD) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) {
+            const int ch = ch_lane + j * 32;
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int q = 0; q < 4; ++q)
+                binit[j][q] = (d.bias && ch < d.N) ? *(const float4*)(d.bias + ch + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int i = 0; i < TM; ++i) {
+            const int gm = m0 + wave_m * WTM + i * 32 + frow;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ch = ch_lane + j * 32;
+                rinit[i][j][0] = rinit[i][j][1] = uint4{0, 0, 0, 0};
+                if (fold_rr && d.residual && gm < d.M && ch < d.N) {
+                    const bf16_t* rp = (const bf16_t*)d.residual + o_off + (long long)gm * d.ldr + ch;
+                    rinit[i][j][0] = *(const uint4*)rp;
+                    rinit[i][j][1] = *(const uint4*)(rp + 8);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep these loads OLDER than the DMA prologue (counted vmcnt waits)
+    }
 
     // ---- software-pipelined K loop ------------------------------------------------------------------
     // Ring of STAGES slots, all filled by the prologue.  Fragments are double-buffered in registers (fa/fw[2]):
@@ -422,6 +455,42 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 #pragma unroll
     for (int s = 0; s < STAGES; ++s)
         if (s < nk) { issue(s); --seg_left; ++staged; if (staged < nk) next_segment_if_done(); }
+    // accumulators start at bias (+ row vector + residual) in FAST kernels, at zero otherwise
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int gm = m0 + wave_m * WTM + i * 32 + frow;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float init[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) init[e] = 0.f;
+            if constexpr (FOLD) {
+                const int ch = ch_lane + j * 32;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    init[4 * q] = binit[j][q].x; init[4 * q + 1] = binit[j][q].y;
+                    init[4 * q + 2] = binit[j][q].z; init[4 * q + 3] = binit[j][q].w;
+                }
+                if (fold_rr) {
+                    float rf[16];
+                    unpack8(rinit[i][j][0], rf);
+                    unpack8(rinit[i][j][1], rf + 8);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) init[e] += rf[e];
+                    if (d.rowvec && gm < d.M && ch < d.N) {
+                        const float* rv = d.rowvec + (long long)(gm / d.rowvec_div) * d.ld_rowvec + ch;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float4 r4 = *(const float4*)(rv + 4 * q);
+                            init[4 * q] += r4.x; init[4 * q + 1] += r4.y; init[4 * q + 2] += r4.z; init[4 * q + 3] += r4.w;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = init[e];
+        }
+    }
     if (nk >= STAGES) wait_vmcnt<LOADS*(STAGES - 1)>();
     else wait_vmcnt<0>();
     if (!ABL(16)) __builtin_amdgcn_s_barrier();
@@ -445,7 +514,6 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 
     // ---- epilogue straight from the accumulators: lane = token (frow), regs = 4-channel runs -------
     if (ABL(4) && acc[0][0][0] != 12345.678f) return;
-    const int ch_lane = n0 + wave_n * WTN + 16 * hi;
     if (p.splits > 1) {  // raw fp32 partial slab; the reduce kernel applies the epilogue
         float* ws = p.ws + ((long long)(z * p.splits + split) * d.M) * d.N;
 #pragma unroll
@@ -489,7 +557,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
     // paid once per batch instead of once per 16-channel run (the compiler cannot hoist a load over the previous run's
     // stores: residual and out may alias).  Register-starved variants (4 waves per SIMD) batch one tile row.
     constexpr int PF = (WPE >= 4) ? 1 : TM;
-    const bool pre = d.residual && p.vec4;
+    const bool pre = d.residual && p.vec4 && !FOLD;
 #pragma unroll
     for (int i0 = 0; i0 < TM; i0 += PF) {
         uint4 rres[PF][TN][2];
@@ -557,7 +625,8 @@ int launch_impl(GemmParams& p, hipStream_t s);
 template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4>
 int launch(GemmParams& p, hipStream_t s) {
     const int n_out = p.d.act == T2V_ACT_GEGLU ? p.d.N / 2 : p.d.N;
-    const bool fast = p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1;
+    const bool fast = p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1 && p.d.alpha == 1.0f &&
+                      (!p.d.rowvec || ((uintptr_t)p.d.rowvec % 16 == 0 && p.d.ld_rowvec % 4 == 0));
     return fast ? launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true>(p, s) : launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, false>(p, s);
 }
 
