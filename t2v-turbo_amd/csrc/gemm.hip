@@ -37,6 +37,8 @@ struct GemmParams {
     int h_out, w_out;
     int tiles_m, tiles_n;
     int xcd_m, xcd_n;  // the 8 XCDs as an xcd_m x xcd_n grid over the tile grid (product 8)
+    int nblk;          // blocks of that grid; per block: first linear tile index, first tile row / column, width in tiles
+    int blk_start[8], blk_r0[8], blk_c0[8], blk_w[8];
     int vec4;          // 4-channel runs may use vector accesses
     int splits, nk_per_split;
     float* ws;         // split-K partials [splits][M][N]
@@ -216,21 +218,15 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
     // 1/xcd_n of the weights instead of all of one operand.  The host picks the split that minimises the bytes the
     // eight L2s pull in total (xcd_n * A_bytes + xcd_m * W_bytes).
     int tile_m, tile_n;
-    {
-        int t = tile, r0 = 0, r1 = p.tiles_m, c0 = 0, c1 = p.tiles_n;
-        bool found = false;
-        for (int bi = 0; bi < p.xcd_m && !found; ++bi) {
-            r0 = bi * p.tiles_m / p.xcd_m; r1 = (bi + 1) * p.tiles_m / p.xcd_m;
-            for (int bj = 0; bj < p.xcd_n; ++bj) {
-                c0 = bj * p.tiles_n / p.xcd_n; c1 = (bj + 1) * p.tiles_n / p.xcd_n;
-                const int sz = (r1 - r0) * (c1 - c0);
-                if (t < sz) { found = true; break; }
-                t -= sz;
-            }
-        }
-        const int bw = c1 - c0;
-        tile_m = r0 + t / bw;
-        tile_n = c0 + t - (t / bw) * bw;
+    {   // block table precomputed on the host: a scalar scan instead of per-block integer divisions
+        int b = 0;
+#pragma unroll
+        for (int i = 1; i < 8; ++i)
+            if (i < p.nblk && tile >= p.blk_start[i]) b = i;
+        const int t = tile - p.blk_start[b], bw = p.blk_w[b];
+        const int q = t / bw;
+        tile_m = p.blk_r0[b] + q;
+        tile_n = p.blk_c0[b] + t - q * bw;
     }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
@@ -262,6 +258,8 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
         const int m = m0 + r;
         if (m >= d.M) {
             a_n[j] = -1; a_y[j] = 0; a_x[j] = 0;
+        } else if (p.taps == 1 && p.h_out == 1) {  // LINEAR: the grid is (M, 1, 1), no divisions
+            a_n[j] = m; a_y[j] = 0; a_x[j] = 0;
         } else {
             const int hw_o = p.h_out * p.w_out;
             const int n = m / hw_o, rem = m - n * hw_o;
@@ -647,6 +645,18 @@ int launch_impl(GemmParams& p, hipStream_t s) {
             if (cost < best) { best = cost; p.xcd_m = xm; p.xcd_n = xn; }
         }
         if (p.xcd_m > p.tiles_m || p.xcd_n > p.tiles_n) { p.xcd_m = 1; p.xcd_n = 1; }
+        p.nblk = 0;
+        int start = 0;
+        for (int bi = 0; bi < p.xcd_m; ++bi) {
+            const int r0 = bi * p.tiles_m / p.xcd_m, r1 = (bi + 1) * p.tiles_m / p.xcd_m;
+            for (int bj = 0; bj < p.xcd_n; ++bj) {
+                const int c0 = bj * p.tiles_n / p.xcd_n, c1 = (bj + 1) * p.tiles_n / p.xcd_n;
+                p.blk_start[p.nblk] = start; p.blk_r0[p.nblk] = r0; p.blk_c0[p.nblk] = c0; p.blk_w[p.nblk] = c1 - c0;
+                start += (r1 - r0) * (c1 - c0);
+                ++p.nblk;
+            }
+        }
+        for (int i = p.nblk; i < 8; ++i) { p.blk_start[i] = 1 << 30; p.blk_r0[i] = 0; p.blk_c0[i] = 0; p.blk_w[i] = 1; }
     }
     dim3 grid(p.tiles_m * p.tiles_n, p.d.batch, p.splits);
     constexpr int smem = STAGES * (BM + BN) * BK * 2;
