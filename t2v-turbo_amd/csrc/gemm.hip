@@ -329,37 +329,6 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
     const int frow = lane & 31, hi = lane >> 5, swz = swz_of(frow);
     const int ch_lane = n0 + wave_n * WTN + 16 * hi;
     f32x16_t acc[TM][TN];
-    // FAST kernels: the loads of everything linear in the epilogue (bias, and without a gate the time-embedding row vector
-    // and the residual tile) are issued HERE, before the DMA prologue, and turned into the accumulators' initial values
-    // after it — their latency hides under the first tiles' flight instead of sitting after the last MFMA.
-    constexpr bool FOLD = FAST;
-    const bool fold_rr = FOLD && d.act != T2V_ACT_GEGLU && p.splits == 1;
-    uint4 rinit[FOLD ? TM : 1][FOLD ? TN : 1][2];
-    float4 binit[FOLD ? TN : 1][4];
-    if constexpr (FOLD) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int ch = ch_lane + j * 32;
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                binit[j][q] = (d.bias && ch < d.N) ? *(const float4*)(d.bias + ch + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int gm = m0 + wave_m * WTM + i * 32 + frow;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int ch = ch_lane + j * 32;
-                rinit[i][j][0] = rinit[i][j][1] = uint4{0, 0, 0, 0};
-                if (fold_rr && d.residual && gm < d.M && ch < d.N) {
-                    const bf16_t* rp = (const bf16_t*)d.residual + o_off + (long long)gm * d.ldr + ch;
-                    rinit[i][j][0] = *(const uint4*)rp;
-                    rinit[i][j][1] = *(const uint4*)(rp + 8);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep these loads OLDER than the DMA prologue (counted vmcnt waits)
-    }
 
     // ---- software-pipelined K loop ------------------------------------------------------------------
     // Ring of STAGES slots, all filled by the prologue.  Fragments are double-buffered in registers (fa/fw[2]):
@@ -453,6 +422,39 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 #pragma unroll
     for (int s = 0; s < STAGES; ++s)
         if (s < nk) { issue(s); --seg_left; ++staged; if (staged < nk) next_segment_if_done(); }
+    // FAST kernels: everything linear in the epilogue (bias, and without a gate the time-embedding row vector and the
+    // residual tile) becomes the accumulators' initial value.  The loads are issued right AFTER the DMA prologue, so
+    // their latency overlaps the first tiles' flight, and they are the YOUNGEST vector-memory operations when consumed:
+    // the wait is then vmcnt(0).  (Issuing them before the DMAs made the compiler wait with a counted vmcnt over the
+    // younger LDS-DMAs; LDS-DMA and register loads do not retire in order with each other, and one run in four of the
+    // 4-step pipeline came out NaN.)  The counted waits of the K loop only ever see LDS-DMAs.
+    constexpr bool FOLD = FAST;
+    const bool fold_rr = FOLD && d.act != T2V_ACT_GEGLU && p.splits == 1;
+    uint4 rinit[FOLD ? TM : 1][FOLD ? TN : 1][2];
+    float4 binit[FOLD ? TN : 1][4];
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ch = ch_lane + j * 32;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                binit[j][q] = (d.bias && ch < d.N) ? *(const float4*)(d.bias + ch + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int gm = m0 + wave_m * WTM + i * 32 + frow;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ch = ch_lane + j * 32;
+                rinit[i][j][0] = rinit[i][j][1] = uint4{0, 0, 0, 0};
+                if (fold_rr && d.residual && gm < d.M && ch < d.N) {
+                    const bf16_t* rp = (const bf16_t*)d.residual + o_off + (long long)gm * d.ldr + ch;
+                    rinit[i][j][0] = *(const uint4*)rp;
+                    rinit[i][j][1] = *(const uint4*)(rp + 8);
+                }
+            }
+        }
+    }
     // accumulators start at bias (+ row vector + residual) in FAST kernels, at zero otherwise
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -623,7 +625,8 @@ int launch_impl(GemmParams& p, hipStream_t s);
 template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4>
 int launch(GemmParams& p, hipStream_t s) {
     const int n_out = p.d.act == T2V_ACT_GEGLU ? p.d.N / 2 : p.d.N;
-    const bool fast = p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1 && p.d.alpha == 1.0f &&
+    static const bool no_fast = getenv("T2V_GEMM_NOFAST") != nullptr;  // diagnostics: force the generic epilogue
+    const bool fast = !no_fast && p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1 && p.d.alpha == 1.0f &&
                       (!p.d.rowvec || ((uintptr_t)p.d.rowvec % 16 == 0 && p.d.ld_rowvec % 4 == 0));
     return fast ? launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true>(p, s) : launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, false>(p, s);
 }
