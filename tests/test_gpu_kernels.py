@@ -380,3 +380,18 @@ def test_transpose_and_sumpool(pair):
     o_e = torch.zeros(2 * 3 * 5, 64)
     pair.run("sumpool2x2", (x[0], 2, 3, 5, o_h), (x[1], 2, 3, 5, o_e))
     assert rel_l2(o_h.float().cpu(), o_e) < BF16_TOL
+
+
+@pytest.mark.parametrize("cfg", [0, 4, 12, 19])
+def test_gemm_fast_and_generic_epilogues_agree_with_emulation(pair, cfg):
+    """Both instantiations of every tile: the fast one (accumulators start at bias + row vector + residual; taken when
+    operands are vector aligned, N % 16 == 0 and alpha == 1) and the generic one (alpha != 1, N % 16 != 0, fp32 output)."""
+    fast = dict(M=700, N=320, c0=320, residual=True, rowvec_div=70, cfg=cfg)
+    assert _gemm_case(pair, **fast) < BF16_TOL
+    assert _gemm_case(pair, **{**fast, "act": 2}) < BF16_TOL                        # SiLU after the folded terms
+    assert _gemm_case(pair, **{**fast, "alpha": 0.37}) < BF16_TOL                   # alpha != 1 -> generic
+    assert _gemm_case(pair, M=700, N=72, c0=128, residual=True, cfg=cfg) < BF16_TOL  # N % 16 != 0 -> generic
+    assert _gemm_case(pair, M=333, N=320, c0=64, out_f32=True, rowvec_div=333, cfg=cfg) < 1e-5 + BF16_TOL * 0  # fp32 out
+    n, h, w = 4, 10, 16
+    assert _gemm_case(pair, M=n * h * w, N=128, c0=64, c1=64, mode=1, n_img=n, h=h, w=w, rows=n * h * w, residual=True,
+                      rowvec_div=h * w, cfg=cfg, seed=3) < BF16_TOL                  # conv + concat + both folded terms
