@@ -391,7 +391,7 @@ def test_gemm_fast_and_generic_epilogues_agree_with_emulation(pair, cfg):
     assert _gemm_case(pair, **{**fast, "act": 2}) < BF16_TOL                        # SiLU after the folded terms
     assert _gemm_case(pair, **{**fast, "alpha": 0.37}) < BF16_TOL                   # alpha != 1 -> generic
     assert _gemm_case(pair, M=700, N=72, c0=128, residual=True, cfg=cfg) < BF16_TOL  # N % 16 != 0 -> generic
-    assert _gemm_case(pair, M=333, N=320, c0=64, out_f32=True, rowvec_div=333, cfg=cfg) < 1e-5 + BF16_TOL * 0  # fp32 out
+    assert _gemm_case(pair, M=333, N=320, c0=64, out_f32=True, rowvec_div=333, cfg=cfg) < 1e-4  # fp32 out
     n, h, w = 4, 10, 16
     assert _gemm_case(pair, M=n * h * w, N=128, c0=64, c1=64, mode=1, n_img=n, h=h, w=w, rows=n * h * w, residual=True,
                       rowvec_div=h * w, cfg=cfg, seed=3) < BF16_TOL                  # conv + concat + both folded terms
