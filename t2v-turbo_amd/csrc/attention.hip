@@ -139,13 +139,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const bool tail = (t + 1) * KT > seq_kv;
         if (!ATT_ABL(1)) {
             float mloc = -INFINITY;
+            if (tail) {  // only the last tile has keys past seq_kv: a scalar branch, not 32 compare/select pairs per tile
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = s[h2][r];
+                        if (key_base + h2 * 32 + (r >> 3) * 16 + (r & 7) >= seq_kv) v = -INFINITY;
+                        asm volatile("" : "+v"(v));  // keep the masking inside this branch (no if-conversion into the hot path)
+                        s[h2][r] = v;
+                    }
+            }
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (tail && key_base + h2 * 32 + (r >> 3) * 16 + (r & 7) >= seq_kv) s[h2][r] = -INFINITY;
-                    mloc = fmaxf(mloc, s[h2][r]);
-                }
+                for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s[h2][r]);
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
             const float m_new = fmaxf(m_run, mloc);  // raw-score units
             const bool grew = m_new > m_run;
