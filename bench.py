@@ -35,6 +35,7 @@ VC2_UNET = dict(
 
 def build_model(device, dtype):
     from t2v_turbo_amd.unet3d import UNetModel
+    torch.manual_seed(1234)  # same random-init weights in every process / on every rank
     with torch.device(device):
         m = UNetModel(**VC2_UNET)
     g = torch.Generator(device=device).manual_seed(1234)
