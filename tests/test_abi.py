@@ -45,3 +45,16 @@ def test_calls_without_gpu_fail_cleanly():
     assert lib.t2v_version() >= 100
     assert lib.t2v_gemm(None, None) == -1  # T2V_EINVAL, no crash
     assert b"null" in lib.t2v_last_error()
+
+
+def test_header_is_plain_c():
+    """include/t2v_hip.h is the FFI contract: it must compile as C99 with nothing but the system headers."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        import pytest
+        pytest.skip("no gcc")
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "t2v_hip.h")
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
