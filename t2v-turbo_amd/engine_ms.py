@@ -63,7 +63,7 @@ class MSUNetEngine(UNetEngine):
         skips = [h]
         for blk in m.down_blocks:
             for i in range(len(blk.resnets)):
-                h = self.layer(blk, i, h, own_input=False)
+                h = self.layer(blk, i, h)
                 skips.append(h)
             if blk.downsamplers is not None:
                 h = self.conv(h, blk.downsamplers[0].conv, nt.GEMM_CONV3X3_S2)
@@ -82,7 +82,7 @@ class MSUNetEngine(UNetEngine):
             for i in range(len(blk.resnets)):
                 skip = skips.pop()
                 cat = Act([h.t, skip.t], h.n_img, h.h, h.w)
-                nh = self.layer(blk, i, cat, own_input=False)
+                nh = self.layer(blk, i, cat)
                 self.pool.put(h.t, skip.t)
                 h = nh
             if blk.upsamplers is not None:
@@ -96,7 +96,7 @@ class MSUNetEngine(UNetEngine):
         self.pool.put(*old.parts)
         return new
 
-    def layer(self, blk, i, h, own_input):
+    def layer(self, blk, i, h):
         """resnet -> temporal conv -> [spatial transformer -> temporal transformer] (unet_3d_blocks.py:547-561);
         the input belongs to the caller (skip connection / virtual concat)."""
         y = self.resnet2d(blk.resnets[i], h)
