@@ -690,8 +690,12 @@ const TileCfg kCfg[] = {{0, 0, 0},      {128, 128, 64}, {128, 64, 32},  {256, 64
                         {256, 128, 64, 32}, {128, 256, 64, 32}, {128, 128, 64, 32}, {256, 128, 64, 32},
                         // 256x256 with a 4-slot ring of 32-deep steps (128 KiB): 1.5 K-steps of DMA lookahead instead of 1,
                         // for weight panels that stream from HBM (cold) rather than from L2
-                        {256, 256, 64, 32}, {256, 256, 64, 32}};
-constexpr int kNumCfg = 21;  // (a 4-wave 128x128-wave-tile variant spills: 3 KB/lane scratch, 72 TF/s - dropped)
+                        {256, 256, 64, 32}, {256, 256, 64, 32},
+                        // 160x320 tiles, 10 waves (5x2, wave tile 32x160): for the 320-channel level, where 128-wide N tiles
+                        // waste a sixth of the MFMAs on padding and M = 40960 gives exactly 256 tiles = one per CU, with the
+                        // activation panel read once instead of once per N tile (wtn = 32 here just keeps GEGLU off it)
+                        {160, 320, 32, 64}, {160, 320, 32, 32}};
+constexpr int kNumCfg = 23;  // (a 4-wave 128x128-wave-tile variant spills: 3 KB/lane scratch, 72 TF/s - dropped)
 
 int dispatch(int cfg, GemmParams& p, hipStream_t s) {
     switch (cfg) {
@@ -716,6 +720,8 @@ int dispatch(int cfg, GemmParams& p, hipStream_t s) {
         case 19: return launch<256, 128, 4, 2, 3, 32, 4>(p, s);
         case 20: return launch<256, 256, 2, 4, 4, 32, 2>(p, s);
         case 21: return launch<256, 256, 4, 2, 4, 32, 2>(p, s);
+        case 22: return launch<160, 320, 5, 2, 2, 64, 3>(p, s);
+        case 23: return launch<160, 320, 5, 2, 3, 32, 3>(p, s);
         default: return T2V_EINVAL;
     }
 }

@@ -74,7 +74,7 @@ def _gemm_case(pair, *, M, N, c0, c1=0, mode=0, n_img=0, h=0, w=0, frames=0, bia
     return rel_l2(got, out_e)
 
 
-@pytest.mark.parametrize("cfg", list(range(1, 22)))
+@pytest.mark.parametrize("cfg", list(range(1, 24)))
 def test_gemm_linear_tiles_and_masking(pair, cfg):
     assert _gemm_case(pair, M=300, N=320, c0=320, residual=True, cfg=cfg) < BF16_TOL
     assert _gemm_case(pair, M=1024, N=192, c0=128, c1=64, cfg=cfg, seed=3) < BF16_TOL  # virtual concat
@@ -95,7 +95,7 @@ def test_gemm_epilogues(pair):
     assert _gemm_case(pair, M=2, N=1280, c0=320, act=nt.ACT_SILU, seed=9) < BF16_TOL  # M = batch rows
 
 
-@pytest.mark.parametrize("cfg", list(range(1, 22)))
+@pytest.mark.parametrize("cfg", list(range(1, 24)))
 def test_gemm_conv_modes(pair, cfg):
     from t2v_turbo_amd import native as nt
     n, h, w = 3, 10, 12
@@ -136,7 +136,7 @@ def test_gemm_split_k(pair, split):
 
 def test_gemm_geglu_all_tiles(pair):
     from t2v_turbo_amd import native as nt
-    for cfg in range(1, 22):
+    for cfg in range(1, 24):
         assert _gemm_case(pair, M=300, N=256, c0=128, act=nt.ACT_GEGLU, cfg=cfg, seed=cfg) < BF16_TOL
 
 
