@@ -198,6 +198,8 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
     constexpr int A_BYTES = BM * ROWB, STAGE_BYTES = (BM + BN) * ROWB;
     static_assert(BK == 64 || BK == 32, "BK");
     static_assert(A_IT >= 1 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
+    static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "every wave must own a whole number of 1 KiB DMA row groups");
+    static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tiles are whole 32x32 MFMA tiles");
     static_assert(LOADS * (STAGES - 1) < 64, "vmcnt field");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
