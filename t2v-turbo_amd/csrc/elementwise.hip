@@ -97,21 +97,23 @@ __global__ void lcm_step_kernel(const float* x, const void* eps, int eps_dt, con
     prev[i] = noise ? sa_p * dn + sb_p * noise[i] : dn;
 }
 
-// direct 3x3 s1 p1 conv for cin <= 8: thread = (token, 8 output channels); weights fp32 in LDS
+// direct 3x3 s1 p1 conv for cin <= 8: thread = (token, 8 output channels); weights fp32 in LDS, staged ONCE per block
+// (a block walks its share of the tokens grid-stride: staging the 46 KiB of a 4 -> 320 conv for every 6 tokens was
+// 9/10 of this kernel's time)
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_small_kernel(const bf16_t* x, int n_img, int H, int W, const float* wgt,
                                                          const float* bias, int cout, bf16_t* out) {
-    extern __shared__ float sw[];  // [9*CIN][cout]: a thread reads its 8 output channels as two float4
+    extern __shared__ float sw[];  // [9*CIN][cout + 4]: a thread reads its 8 output channels as two float4
+    const int ldw = cout + 4;      // +4: the transposing writes below (consecutive k, same oc) spread over 16 banks, not 1
     for (int i = threadIdx.x; i < cout * 9 * CIN; i += 256) {
         const int oc = i / (9 * CIN), k = i - oc * 9 * CIN;
-        sw[k * cout + oc] = wgt[i];
+        sw[k * ldw + oc] = wgt[i];
     }
     __syncthreads();
     const int nch = cout / 8;
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long M = (long long)n_img * H * W;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < M * nch; e += (long long)gridDim.x * 256) {
     const long long m = e / nch;
-    if (m >= M) return;
     const int oc0 = (int)(e % nch) * 8;
     const int px = (int)(m % W), py = (int)((m / W) % H);
     const long long nbase = (m / ((long long)W * H)) * H * W;
@@ -135,13 +137,14 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const bf16_t* x, int n_
             }
 #pragma unroll
             for (int c = 0; c < CIN; ++c) {
-                const float* wp = sw + ((ky * 3 + kx) * CIN + c) * cout + oc0;
+                const float* wp = sw + ((ky * 3 + kx) * CIN + c) * ldw + oc0;
                 const float4 w0 = *(const float4*)wp, w1 = *(const float4*)(wp + 4);
                 acc[0] += xv[c] * w0.x; acc[1] += xv[c] * w0.y; acc[2] += xv[c] * w0.z; acc[3] += xv[c] * w0.w;
                 acc[4] += xv[c] * w1.x; acc[5] += xv[c] * w1.y; acc[6] += xv[c] * w1.z; acc[7] += xv[c] * w1.w;
             }
         }
     *(uint4*)(out + m * cout + oc0) = pack8(acc);
+    }
 }
 
 inline unsigned nblk(long long n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
@@ -210,19 +213,23 @@ extern "C" int t2v_lcm_step(const float* x, const void* eps, int eps_dt, const f
 extern "C" int t2v_conv3x3_small_cin(const void* x, int n_img, int h, int w, int cin, const float* wgt, const float* bias,
                                      int cout, void* out, void* stream) {
     T2V_REQUIRE(x && wgt && out && n_img > 0 && h > 0 && w > 0, T2V_EINVAL, "t2v_conv3x3_small_cin");
-    T2V_REQUIRE((cin == 4 || cin == 8) && cout % 8 == 0 && cout * 9 * cin * 4 <= 150 * 1024, T2V_ESHAPE,
+    T2V_REQUIRE((cin == 4 || cin == 8) && cout % 8 == 0 && (cout + 4) * 9 * cin * 4 <= 150 * 1024, T2V_ESHAPE,
                 "t2v_conv3x3_small_cin: cin must be 4 or 8, cout a multiple of 8");
     const long long work = (long long)n_img * h * w * (cout / 8);
-    const int smem = cout * 9 * cin * 4;
+    const int smem = (cout + 4) * 9 * cin * 4;
+    // as many blocks as stay resident at once (LDS-limited), at least 8 tokens' worth of work each
+    const int per_cu = smem > 0 ? (160 * 1024) / smem : 1;
+    long long blocks = 256LL * (per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu));
+    if (blocks > (work + 255) / 256) blocks = (work + 255) / 256;
     hipStream_t s = (hipStream_t)stream;
     if (cin == 4) {
         static bool set4 = false;
         if (!set4) { hipFuncSetAttribute((const void*)conv_small_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set4 = true; }
-        hipLaunchKernelGGL(conv_small_kernel<4>, dim3(nblk(work)), dim3(256), smem, s, (const bf16_t*)x, n_img, h, w, wgt, bias, cout, (bf16_t*)out);
+        hipLaunchKernelGGL(conv_small_kernel<4>, dim3((unsigned)blocks), dim3(256), smem, s, (const bf16_t*)x, n_img, h, w, wgt, bias, cout, (bf16_t*)out);
     } else {
         static bool set8 = false;
         if (!set8) { hipFuncSetAttribute((const void*)conv_small_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set8 = true; }
-        hipLaunchKernelGGL(conv_small_kernel<8>, dim3(nblk(work)), dim3(256), smem, s, (const bf16_t*)x, n_img, h, w, wgt, bias, cout, (bf16_t*)out);
+        hipLaunchKernelGGL(conv_small_kernel<8>, dim3((unsigned)blocks), dim3(256), smem, s, (const bf16_t*)x, n_img, h, w, wgt, bias, cout, (bf16_t*)out);
     }
     T2V_CHECK_LAUNCH();
     return T2V_OK;

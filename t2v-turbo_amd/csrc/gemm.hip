@@ -90,8 +90,15 @@ struct Epi {
     template <bool FAST = false>
     __device__ __forceinline__ void run(float* v, const float* gate, int gm, int ch_in, int ch_out, bool has_pre = false,
                                         uint4 pre0 = uint4{0, 0, 0, 0}, uint4 pre1 = uint4{0, 0, 0, 0}) const {
-        const t2v_gemm_desc& dd = *d;
         if (ch_out >= n_out) return;
+        compute<FAST>(v, gate, gm, ch_in, ch_out, has_pre, pre0, pre1);
+        store<FAST>(v, gm, ch_out);
+    }
+    // everything up to the final values of the run (v is updated in place)
+    template <bool FAST = false>
+    __device__ __forceinline__ void compute(float* v, const float* gate, int gm, int ch_in, int ch_out, bool has_pre = false,
+                                            uint4 pre0 = uint4{0, 0, 0, 0}, uint4 pre1 = uint4{0, 0, 0, 0}) const {
+        const t2v_gemm_desc& dd = *d;
         const bool full = FAST || (vec && ch_out + 16 <= n_out);
         // FAST kernels (alpha == 1, host-checked) start their accumulators at bias (+ rowvec + residual when there is no
         // gate), so those terms cost nothing here and the residual's latency hides under the main loop
@@ -159,6 +166,11 @@ struct Epi {
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = silu_f(v[e]);
         }
+    }
+    template <bool FAST = false>
+    __device__ __forceinline__ void store(const float* v, int gm, int ch_out) const {
+        const t2v_gemm_desc& dd = *d;
+        const bool full = FAST || (vec && ch_out + 16 <= n_out);
         if (dd.out_f32) {
             float* op = (float*)dd.out + o_off + (long long)gm * dd.ldo + ch_out;
             if (full) {
@@ -182,6 +194,34 @@ struct Epi {
         }
     }
 };
+
+// Staged epilogue (FAST kernels): a wave parks one 32-row slab of its finished bf16 tile in LDS (row pitch P bytes) and
+// writes it out row-contiguously: LPR lanes cover one row's LPR*16 bytes, so a store instruction touches 64/LPR rows with
+// whole 64..512-byte runs instead of 32 rows with 32 bytes each (the accumulator layout gives a lane 16 channels of ONE
+// row, and the texture path spends a cycle per distinct cache line of an instruction, not per byte).
+template <int P, int LPR>
+__device__ __forceinline__ void flush_slab(const char* st, int lane, bf16_t* obase, int ldo, int gm0, int M, int col0, int n_out) {
+    static_assert((32 * LPR) % 64 == 0, "slab pieces per wave instruction");
+#pragma unroll
+    for (int it = 0; it < (32 * LPR) / 64; ++it) {
+        const int q = it * 64 + lane;
+        const int r = q / LPR, c = q - r * LPR;
+        const uint4 val = *(const uint4*)(st + r * P + c * 16);
+        const int gm = gm0 + r, ch = col0 + c * 8;
+        if (gm < M && ch < n_out) *(uint4*)(obase + (long long)gm * ldo + ch) = val;
+    }
+}
+// dynamic LDS of a kernel instantiation: the DMA ring, or the epilogue slabs of all waves if those need more
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FAST>
+constexpr int gemm_smem_bytes() {
+    const int ring = STAGES * (BM + BN) * BK * 2;
+#ifndef T2V_GEMM_DIRECT_EPI
+    const int slabs = FAST ? WM * WN * 32 * ((BN / WN) * 2 + 16) : 0;
+    return slabs > ring ? slabs : ring;
+#else
+    return ring;
+#endif
+}
 
 // BK = K elements per pipeline step (LDS rows of BK*2 bytes); WPE = waves per SIMD the register budget is
 // sized for (2 x 4-wave workgroups or one 8-wave workgroup per CU at WPE = 2)
@@ -516,7 +556,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 
     // ---- epilogue straight from the accumulators: lane = token (frow), regs = 4-channel runs -------
     if (ABL(4) && acc[0][0][0] != 12345.678f) return;
-    if (p.splits > 1) {  // raw fp32 partial slab; the reduce kernel applies the epilogue
+    if (!FAST && p.splits > 1) {  // raw fp32 partial slab (FAST kernels are never split: host-checked); the reduce kernel applies the epilogue
         float* ws = p.ws + ((long long)(z * p.splits + split) * d.M) * d.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -536,6 +576,57 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
     }
     Epi epi;
     epi.d = &d; epi.o_off = o_off; epi.vec = p.vec4;
+#ifndef T2V_GEMM_DIRECT_EPI
+    if constexpr (FAST) {  // host-checked: bf16 output, full 16-channel runs
+        constexpr int P = WTN * 2 + 16;  // +16: consecutive rows start 4 banks apart, 16 lanes x 16 bytes cover all 64
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave is past its last fragment read: the ring is dead
+        char* st = smem + wave * (32 * P);
+        char* st_w = st + frow * P + hi * 32;
+        bf16_t* obase = (bf16_t*)d.out + o_off;
+        if (d.act == T2V_ACT_GEGLU) {
+            epi.n_out = d.N / 2;
+            if constexpr (TN >= 2 && TN % 2 == 0) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int gm = m0 + wave_m * WTM + i * 32 + frow;
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int u = 0; u < TN / 2; ++u) {
+                        float v[16], gt[16];
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { v[e] = acc[i][2 * u][e]; gt[e] = acc[i][2 * u + 1][e]; }
+                        const int ch_out = (n0 + wave_n * WTN) / 2 + u * 32 + 16 * hi;
+                        if (gm < d.M && ch_out < epi.n_out) epi.template compute<true>(v, gt, gm, ch_lane + u * 64, ch_out);
+                        *(uint4*)(st_w + u * 64) = pack8(v);
+                        *(uint4*)(st_w + u * 64 + 16) = pack8(v + 8);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    flush_slab<P, TN * 2>(st, lane, obase, d.ldo, m0 + wave_m * WTM + i * 32, d.M, (n0 + wave_n * WTN) / 2, epi.n_out);
+                }
+            }
+            return;
+        }
+        epi.n_out = d.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int gm = m0 + wave_m * WTM + i * 32 + frow;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float v[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
+                if (gm < d.M && ch_lane + j * 32 < d.N) epi.template compute<true>(v, nullptr, gm, ch_lane + j * 32, ch_lane + j * 32);
+                *(uint4*)(st_w + j * 64) = pack8(v);
+                *(uint4*)(st_w + j * 64 + 16) = pack8(v + 8);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            flush_slab<P, TN * 4>(st, lane, obase, d.ldo, m0 + wave_m * WTM + i * 32, d.M, n0 + wave_n * WTN, d.N);
+        }
+        return;
+    }
+#endif
     if (d.act == T2V_ACT_GEGLU) {
         epi.n_out = d.N / 2;
         if constexpr (TN >= 2) {
@@ -629,7 +720,7 @@ int launch(GemmParams& p, hipStream_t s) {
     const int n_out = p.d.act == T2V_ACT_GEGLU ? p.d.N / 2 : p.d.N;
     static const bool no_fast = getenv("T2V_GEMM_NOFAST") != nullptr;  // diagnostics: force the generic epilogue
     const bool fast = !no_fast && p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1 && p.d.alpha == 1.0f &&
-                      (!p.d.rowvec || ((uintptr_t)p.d.rowvec % 16 == 0 && p.d.ld_rowvec % 4 == 0));
+                      !p.d.out_f32 && (!p.d.rowvec || ((uintptr_t)p.d.rowvec % 16 == 0 && p.d.ld_rowvec % 4 == 0));
     return fast ? launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true>(p, s) : launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, false>(p, s);
 }
 
@@ -664,7 +755,7 @@ int launch_impl(GemmParams& p, hipStream_t s) {
         for (int i = p.nblk; i < 8; ++i) { p.blk_start[i] = 1 << 30; p.blk_r0[i] = 0; p.blk_c0[i] = 0; p.blk_w[i] = 1; }
     }
     dim3 grid(p.tiles_m * p.tiles_n, p.d.batch, p.splits);
-    constexpr int smem = STAGES * (BM + BN) * BK * 2;
+    constexpr int smem = gemm_smem_bytes<BM, BN, WM, WN, STAGES, BK, FAST>();
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
