@@ -8,7 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip"]
-LIB = os.path.join(PKG, "libt2v_hip.so")
+# T2V_HIP_LIB_OUT: build a variant (e.g. with ablation switches) next to the product library instead of over it
+LIB = os.path.abspath(os.environ["T2V_HIP_LIB_OUT"]) if os.environ.get("T2V_HIP_LIB_OUT") else os.path.join(PKG, "libt2v_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
          "-I", os.path.join(ROOT, "include"), "-I", HERE] + os.environ.get("T2V_EXTRA_HIPCC_FLAGS", "").split()
 
@@ -36,7 +37,7 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(HERE, s.replace(".hip", ".o"))
+        o = os.path.join(HERE, s.replace(".hip", ".o" if not os.environ.get("T2V_HIP_LIB_OUT") else ".variant.o"))
         objs.append(o)
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(HERE, s), "-o", o]
         if verbose:

@@ -225,7 +225,7 @@ class HipOps:
         d.tile_cfg, d.split_k = tuned if tuned else (tile_cfg, split_k)
         ws = self.workspace(a0.device)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
-        self._call("t2v_gemm", C.byref(d), keep=d)
+        self._call("t2v_gemm", C.byref(d))  # the byref object holds a reference to d: a recording keeps its descriptors alive
 
     def conv_small(self, x, n_img, h, w, wgt, bias, out):
         self._call("t2v_conv3x3_small_cin", _p(x), n_img, h, w, x.shape[1], _p(wgt), _p(bias), out.shape[1], _p(out))

@@ -4,6 +4,12 @@ launches of the recorded descriptor, so no host launch overhead), next to a plai
 (M, N, K) via torch.mm and the two roofline floors (MFMA 2.5 PF/s dense bf16, HBM 8 TB/s on algorithmic bytes).
 
     python tools/gemm_profile_graph.py [--blas 1] [--out gpurun_out/gemm_profile.csv]
+
+Ablation sweep (where does each shape's time go): build the library with the switches compiled in and point the
+loader at it, then ask for the bit sets to time next to the full kernel (bits: t2v-turbo_amd/csrc/gemm.hip, ABL):
+
+    T2V_EXTRA_HIPCC_FLAGS=-DT2V_GEMM_ABLATE T2V_HIP_LIB_OUT=t2v-turbo_amd/libt2v_hip_ablate.so python t2v-turbo_amd/csrc/build.py --force
+    T2V_HIP_LIB=t2v-turbo_amd/libt2v_hip_ablate.so python tools/gemm_profile_graph.py --blas 0 --ablate 128,4,32,64 --top 30
 """
 import argparse
 import os
@@ -39,6 +45,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--blas", type=int, default=1)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "gemm_profile.csv"))
+    ap.add_argument("--ablate", default="", help="comma list of ablation bit sets to time per shape (ablate build only)")
+    ap.add_argument("--top", type=int, default=0, help="only the N shapes with the largest launch count x FLOPs (0 = all)")
     args = ap.parse_args()
     import bench
     from t2v_turbo_amd import native as nt
@@ -62,7 +70,13 @@ def main():
         else:
             seen[key] = [1, fn, a, d]
     rows = []
-    for key, (count, fn, a, d) in seen.items():
+    ablate = [int(b) for b in args.ablate.split(",") if b]
+    lib = nt.load()
+    items = list(seen.items())
+    if args.top:
+        items.sort(key=lambda kv: -kv[1][0] * (kv[0][1] * kv[0][2] * (kv[0][3] + 2000.0)))
+        items = items[:args.top]
+    for key, (count, fn, a, d) in items:
         mode, M, N, K, batch, act, has_res, has_rv = key
         s = torch.cuda.current_stream().cuda_stream
         us = graph_time(lambda: fn(*a, torch.cuda.current_stream().cuda_stream))
@@ -86,9 +100,14 @@ def main():
                 us_blas = None
             del A, B, Cc
         rows.append(dict(mode=mode, M=M, N=N, K=K, batch=batch, act=act, res=int(has_res), rv=int(has_rv), count=count,
+                         cfg=d.tile_cfg, split=d.split_k,
                          us=round(us, 2), total_ms=round(us * count / 1e3, 3), tflops=round(flops / us / 1e6, 1),
                          us_blas=None if us_blas is None else round(us_blas, 2),
                          us_mfma_floor=round(flops / 2.5e15 * 1e6, 2), us_hbm_floor=round(byts / 8e12 * 1e6, 2)))
+        for bits in ablate:  # same descriptor, parts of the kernel switched off
+            lib.t2v_gemm_debug(bits)
+            rows[-1][f"us_abl{bits}"] = round(graph_time(lambda: fn(*a, torch.cuda.current_stream().cuda_stream)), 2)
+        lib.t2v_gemm_debug(0)
         print(rows[-1], flush=True)
     rows.sort(key=lambda r: -r["total_ms"])
     tot = sum(r["total_ms"] for r in rows)
