@@ -247,7 +247,7 @@ __device__ __forceinline__ void flush_slab_nostore(const char* st, int lane, bf1
 }
 // dynamic LDS of a kernel instantiation: the DMA ring, or the epilogue slabs of all waves if those need more
 template <int BM, int BN, int WM, int WN, int STAGES, int BK, bool FAST>
-constexpr int gemm_smem_bytes() {
+constexpr int gemm_smem_bytes() {  // (the same for the DMA-staged and the register-staged kernels)
     const int ring = STAGES * (BM + BN) * BK * 2;
 #ifndef T2V_GEMM_DIRECT_EPI
     const int slabs = FAST ? WM * WN * 32 * ((BN / WN) * 2 + 16) : 0;
@@ -259,7 +259,9 @@ constexpr int gemm_smem_bytes() {
 
 // BK = K elements per pipeline step (LDS rows of BK*2 bytes); WPE = waves per SIMD the register budget is
 // sized for (2 x 4-wave workgroups or one 8-wave workgroup per CU at WPE = 2)
-template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4, bool FAST = false>
+// RS ("register-staged", experimental): operands travel global -> VGPR -> ds_write_b128 -> LDS instead of by LDS-DMA.  One
+// register set per wave holds the NEXT K step while the current one is computed; the LDS ring has exactly two slots.
+template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4, bool FAST = false, bool RS = false>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
     static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "every wave must own a whole number of 1 KiB DMA row groups");
     static_assert(BM % (WM * 32) == 0 && BN % (WN * 32) == 0, "wave tiles are whole 32x32 MFMA tiles");
     static_assert(LOADS * (STAGES - 1) < 64, "vmcnt field");
+    static_assert(!RS || STAGES == 2, "register-staged kernels use a two-slot ring");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const t2v_gemm_desc& d = p.d;
@@ -397,6 +400,28 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 #pragma unroll
         for (int j = 0; j < B_IT; ++j) wptr[j] += winc[j];
     };
+    // register-staged twin of issue(): gload() pulls the step the pointers stand at into this wave's register set,
+    // gstore(slot) parks that set in ring slot `slot` at exactly the addresses the DMAs would have written
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));  // (an array of the uint4 struct is not promoted to registers)
+    u32x4_t greg[RS ? LOADS : 1];
+    auto gload = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) greg[j] = *(const u32x4_t*)aptr[j];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) greg[A_IT + j] = *(const u32x4_t*)wptr[j];
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) aptr[j] += ainc[j];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) wptr[j] += winc[j];
+    };
+    auto gstore = [&](int slot) {
+        char* sa = smem + slot * STAGE_BYTES + lane * 16;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < A_IT; ++j) *(u32x4_t*)(sa + (wave + NW * j) * 1024) = greg[j];
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) *(u32x4_t*)(sb + (wave + NW * j) * 1024) = greg[A_IT + j];
+    };
     auto next_segment_if_done = [&]() {
         if (seg_left == 0) { ++seg; if (seg < p.taps * p.nsrc) begin_segment(); }
     };
@@ -451,6 +476,40 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
     // cover the LDS latency.
     auto kstep = [&](auto issue_tag, auto next_tag, auto younger) {
         constexpr bool ISSUE = decltype(issue_tag)::value, NEXT = decltype(next_tag)::value;
+        if constexpr (RS) {
+            // Step kt computes from slot buf.  Under its first slice the register set (step kt+1, loaded one whole step
+            // ago) is written to the other slot - free since every wave passed the previous hand-over barrier - and
+            // refilled with step kt+2.  The hand-over barrier then publishes slot kt+1 and retires slot kt.
+            const int nxt = buf ^ 1;
+#pragma unroll
+            for (int kk = 0; kk < NS - 1; ++kk) {
+                mfmas(kk & 1, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(buf, kk + 1, (kk + 1) & 1);
+                if (kk == 0) {
+                    if constexpr (NEXT) gstore(nxt);
+                    if constexpr (ISSUE) gload();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(kk & 1, 1, NM);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (NEXT) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my fragment reads of slot kt and my writes of slot kt+1
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                mfmas((NS - 1) & 1, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(nxt, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                mfmas((NS - 1) & 1, 0, 1);
+            }
+            mfmas((NS - 1) & 1, 1, NM);
+            __builtin_amdgcn_sched_barrier(0);
+            buf = nxt;
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < NS - 1; ++kk) {
             mfmas(kk & 1, 0, 1);
@@ -495,9 +554,13 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
     // prologue: fill the whole ring (steps 0 .. STAGES-1)
     begin_segment();
     int staged = 0;
+    if constexpr (RS) {  // step 0 on its way to the registers (parked in slot 0 below, after the accumulator-init loads went out)
+        gload(); --seg_left; ++staged; if (staged < nk) next_segment_if_done();
+    } else {
 #pragma unroll
-    for (int s = 0; s < STAGES; ++s)
-        if (s < nk) { issue(s); --seg_left; ++staged; if (staged < nk) next_segment_if_done(); }
+        for (int s = 0; s < STAGES; ++s)
+            if (s < nk) { issue(s); --seg_left; ++staged; if (staged < nk) next_segment_if_done(); }
+    }
     // FAST kernels: everything linear in the epilogue (bias, and without a gate the time-embedding row vector and the
     // residual tile) becomes the accumulators' initial value.  The loads are issued right AFTER the DMA prologue, so
     // their latency overlaps the first tiles' flight, and they are the YOUNGEST vector-memory operations when consumed:
@@ -567,8 +630,14 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
             for (int e = 0; e < 16; ++e) acc[i][j][e] = init[e];
         }
     }
-    if (nk >= STAGES) wait_vmcnt<LOADS*(STAGES - 1)>();
-    else wait_vmcnt<0>();
+    if constexpr (RS) {
+        gstore(0);
+        if (nk > 1) { gload(); --seg_left; ++staged; if (staged < nk) next_segment_if_done(); }  // step 1 stays in registers
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+        if (nk >= STAGES) wait_vmcnt<LOADS*(STAGES - 1)>();
+        else wait_vmcnt<0>();
+    }
     if (!ABL(16)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (ABL(128)) return;
@@ -749,10 +818,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     epi.run(v, nullptr, gm, ch, ch);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST, bool RS = false>
 int launch_impl(GemmParams& p, hipStream_t s);
 
-template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4, bool RS = false>
 int launch(GemmParams& p, hipStream_t s) {
     const int n_out = p.d.act == T2V_ACT_GEGLU ? p.d.N / 2 : p.d.N;
     static const bool no_fast = getenv("T2V_GEMM_NOFAST") != nullptr;  // diagnostics: force the generic epilogue
@@ -763,11 +832,11 @@ int launch(GemmParams& p, hipStream_t s) {
     if constexpr (BM / WM >= 128 && BN / WN >= 128) {
         return fast ? launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true>(p, s) : launch<BM, BN, WM, WN * 2, 4, 32, 2>(p, s);
     } else {
-        return fast ? launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true>(p, s) : launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, false>(p, s);
+        return fast ? launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, RS>(p, s) : launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, false, RS>(p, s);
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST, bool RS>
 int launch_impl(GemmParams& p, hipStream_t s) {
     p.tiles_m = (p.d.M + BM - 1) / BM;
     p.tiles_n = (p.d.N + BN - 1) / BN;
@@ -801,10 +870,10 @@ int launch_impl(GemmParams& p, hipStream_t s) {
     constexpr int smem = gemm_smem_bytes<BM, BN, WM, WN, STAGES, BK, FAST>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST>), grid, dim3(WM * WN * 64), smem, s, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST, RS>), grid, dim3(WM * WN * 64), smem, s, p);
     T2V_CHECK_LAUNCH();
     if (p.splits > 1) {
         const long long work = (long long)p.d.M * ((p.d.N + 15) / 16);
@@ -834,8 +903,12 @@ const TileCfg kCfg[] = {{0, 0, 0},      {128, 128, 64}, {128, 64, 32},  {256, 64
                         // 256x256 on FOUR waves, wave tile 128x128 (accumulators in AGPRs): half the LDS fragment bytes per
                         // MFMA of the 8-wave 256x256 tiles.  Compiles with a spill-free main loop; NOT yet run on hardware
                         // (added after the round's GPU budget was spent) - the tuned table never selects it.
-                        {256, 256, 128, 32}};
-constexpr int kNumCfg = 24;  // (a 4-wave 128x128-wave-tile variant spills: 3 KB/lane scratch, 72 TF/s - dropped)
+                        {256, 256, 128, 32},
+                        // register-staged twins (global -> VGPR -> ds_write_b128, two-slot ring) of 6, 1, 20, 23 and 17: the
+                        // candidates for the question tools/fill_rate.hip asks (is LDS-DMA's 16 B/clk per CU the operand
+                        // delivery limit).  Compile-verified only, like 24.
+                        {256, 128, 64, 64}, {128, 128, 64, 64}, {256, 256, 64, 32}, {160, 320, 32, 32}, {128, 256, 64, 32}};
+constexpr int kNumCfg = 29;  // (a 4-wave 128x128-wave-tile variant spills: 3 KB/lane scratch, 72 TF/s - dropped)
 
 int dispatch(int cfg, GemmParams& p, hipStream_t s) {
     switch (cfg) {
@@ -863,6 +936,11 @@ int dispatch(int cfg, GemmParams& p, hipStream_t s) {
         case 22: return launch<160, 320, 5, 2, 2, 64, 3>(p, s);
         case 23: return launch<160, 320, 5, 2, 3, 32, 3>(p, s);
         case 24: return launch<256, 256, 2, 2, 3, 32, 1>(p, s);
+        case 25: return launch<256, 128, 4, 2, 2, 64, 2, true>(p, s);
+        case 26: return launch<128, 128, 2, 2, 2, 64, 2, true>(p, s);
+        case 27: return launch<256, 256, 2, 4, 2, 32, 2, true>(p, s);
+        case 28: return launch<160, 320, 5, 2, 2, 32, 3, true>(p, s);
+        case 29: return launch<128, 256, 1, 4, 2, 32, 2, true>(p, s);
         default: return T2V_EINVAL;
     }
 }
