@@ -2,6 +2,8 @@
 (tests/emu_ops.py) on identical bf16-rounded inputs.  Tolerances: outputs are bf16 (8 mantissa
 bits) of fp32-accumulated values -> rel-L2 <= 4e-3 per op (fp32 outputs: <= 2e-3, limited by the
 bf16 inputs of MFMA products); statistics (fp32): 1e-4."""
+import os
+
 import pytest
 import torch
 
@@ -11,6 +13,10 @@ from tests.util import rel_l2
 pytestmark = pytest.mark.gpu
 
 BF16_TOL = 4e-3
+
+# tile ids every shape may be tuned to, all validated on hardware; T2V_TEST_EXPERIMENTAL_TILES=1 adds the ids that are so
+# far only compile-verified (24: 4-wave 256x256 with 128x128 wave tiles, 25-29: register-staged operand path)
+CFGS = list(range(1, 24)) + (list(range(24, 30)) if os.environ.get("T2V_TEST_EXPERIMENTAL_TILES") == "1" else [])
 
 
 def _rt(*shape, seed=0, scale=1.0):
@@ -74,7 +80,7 @@ def _gemm_case(pair, *, M, N, c0, c1=0, mode=0, n_img=0, h=0, w=0, frames=0, bia
     return rel_l2(got, out_e)
 
 
-@pytest.mark.parametrize("cfg", list(range(1, 24)))
+@pytest.mark.parametrize("cfg", CFGS)
 def test_gemm_linear_tiles_and_masking(pair, cfg):
     assert _gemm_case(pair, M=300, N=320, c0=320, residual=True, cfg=cfg) < BF16_TOL
     assert _gemm_case(pair, M=1024, N=192, c0=128, c1=64, cfg=cfg, seed=3) < BF16_TOL  # virtual concat
@@ -95,7 +101,7 @@ def test_gemm_epilogues(pair):
     assert _gemm_case(pair, M=2, N=1280, c0=320, act=nt.ACT_SILU, seed=9) < BF16_TOL  # M = batch rows
 
 
-@pytest.mark.parametrize("cfg", list(range(1, 24)))
+@pytest.mark.parametrize("cfg", CFGS)
 def test_gemm_conv_modes(pair, cfg):
     from t2v_turbo_amd import native as nt
     n, h, w = 3, 10, 12
@@ -136,7 +142,7 @@ def test_gemm_split_k(pair, split):
 
 def test_gemm_geglu_all_tiles(pair):
     from t2v_turbo_amd import native as nt
-    for cfg in range(1, 24):
+    for cfg in CFGS:
         assert _gemm_case(pair, M=300, N=256, c0=128, act=nt.ACT_GEGLU, cfg=cfg, seed=cfg) < BF16_TOL
 
 

@@ -10,6 +10,10 @@ loader at it, then ask for the bit sets to time next to the full kernel (bits: t
 
     T2V_EXTRA_HIPCC_FLAGS=-DT2V_GEMM_ABLATE T2V_HIP_LIB_OUT=t2v-turbo_amd/libt2v_hip_ablate.so python t2v-turbo_amd/csrc/build.py --force
     T2V_HIP_LIB=t2v-turbo_amd/libt2v_hip_ablate.so python tools/gemm_profile_graph.py --blas 0 --ablate 128,4,32,64 --top 30
+
+Other tile ids on the recorded descriptors (e.g. the experimental 24-29 against the tuned choice):
+
+    python tools/gemm_profile_graph.py --blas 0 --force-cfgs 24,25,26,27,28,29 --top 30
 """
 import argparse
 import os
@@ -46,6 +50,7 @@ def main():
     ap.add_argument("--blas", type=int, default=1)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "gemm_profile.csv"))
     ap.add_argument("--ablate", default="", help="comma list of ablation bit sets to time per shape (ablate build only)")
+    ap.add_argument("--force-cfgs", default="", help="comma list of tile ids to time every shape under as well (e.g. 24,25,27)")
     ap.add_argument("--top", type=int, default=0, help="only the N shapes with the largest launch count x FLOPs (0 = all)")
     args = ap.parse_args()
     import bench
@@ -108,6 +113,13 @@ def main():
             lib.t2v_gemm_debug(bits)
             rows[-1][f"us_abl{bits}"] = round(graph_time(lambda: fn(*a, torch.cuda.current_stream().cuda_stream)), 2)
         lib.t2v_gemm_debug(0)
+        for c in [int(v) for v in args.force_cfgs.split(",") if v]:  # same descriptor under another tile id (split-K as tuned)
+            lib.t2v_gemm_force_config(c)
+            try:
+                ok = fn(*a, torch.cuda.current_stream().cuda_stream) == 0
+                rows[-1][f"us_cfg{c}"] = round(graph_time(lambda: fn(*a, torch.cuda.current_stream().cuda_stream)), 2) if ok else None
+            finally:
+                lib.t2v_gemm_force_config(0)
         print(rows[-1], flush=True)
     rows.sort(key=lambda r: -r["total_ms"])
     tot = sum(r["total_ms"] for r in rows)

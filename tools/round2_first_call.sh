@@ -1,0 +1,13 @@
+#!/bin/bash
+# The measurements round 1 ran out of GPU budget for, in the order they decide things (≈ 2 GPU-minutes):
+#   1. L2 -> CU fill rate: LDS-DMA vs register-staged loads (is 16 B/clk/CU the delivery limit?)
+#   2. parity of the compile-verified tile ids 24-29 (the per-tile GEMM tests with the id range extended)
+#   3. those ids against the tuned choice on the 30 heaviest UNet shapes, in-graph
+# usage: gpurun --timeout 400 -- bash tools/round2_first_call.sh
+set -u
+mkdir -p gpurun_out
+hipcc --offload-arch=gfx950 -O3 tools/fill_rate.hip -o /tmp/fill_rate && timeout 60 /tmp/fill_rate 16 2000 | tee gpurun_out/fill_rate.txt
+T2V_TEST_EXPERIMENTAL_TILES=1 timeout 240 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=line -p no:cacheprovider \
+    -k "linear_tiles or conv_modes or geglu_all" 2>&1 | tail -15 | tee gpurun_out/experimental_tiles.txt
+timeout 200 python tools/gemm_profile_graph.py --blas 0 --force-cfgs 24,25,26,27,28,29 --top 30 \
+    --out gpurun_out/gemm_experimental_cfgs.csv 2>&1 | tail -3
