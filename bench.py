@@ -57,6 +57,25 @@ def synth_inputs(device, dtype):
     return x, ctx, tc
 
 
+# workgroup tile (rows, columns) of every tile id of t2v-turbo_amd/csrc/gemm.hip (kCfg)
+GEMM_TILES = {1: (128, 128), 2: (128, 64), 3: (256, 64), 4: (128, 128), 5: (128, 64), 6: (256, 128), 7: (256, 128),
+              8: (64, 128), 9: (256, 64), 10: (128, 128), 11: (128, 256), 12: (256, 256), 13: (256, 128), 14: (128, 256),
+              15: (256, 256), 16: (256, 128), 17: (128, 256), 18: (128, 128), 19: (256, 128), 20: (256, 256),
+              21: (256, 256), 22: (160, 320), 23: (160, 320), 24: (256, 256), 25: (256, 128), 26: (128, 128),
+              27: (256, 256), 28: (160, 320), 29: (128, 256)}
+
+
+def gemm_operand_gbyte(d, k_total):
+    """Bytes one t2v_gemm launch moves from L2 into LDS: every workgroup tile streams its (BM + BN) x K bf16 panel pair
+    once.  None when the launch runs on the library heuristic (tile id not recorded in the descriptor)."""
+    tile = GEMM_TILES.get(int(d.tile_cfg))
+    if tile is None:
+        return None
+    bm, bn = tile
+    tiles = -(-d.M // bm) * -(-d.N // bn) * max(d.batch, 1)
+    return tiles * (bm + bn) * k_total * 2 / 1e9
+
+
 def kernel_breakdown(engine, plan):
     """Replay the recorded launches with an event pair around each one (same stream the kernels run on)
     and aggregate per C-ABI entry point; GEMM launches carry their algorithmic FLOPs (2*M*N*K*batch)."""
@@ -82,6 +101,13 @@ def kernel_breakdown(engine, plan):
             taps = {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(d.mode, 9)
             tf = 2.0 * d.M * d.N * taps * (d.c0 + d.c1) * max(d.batch, 1) / 1e12
             a["tflop"] += tf
+            try:
+                og = gemm_operand_gbyte(d, taps * (d.c0 + d.c1))
+            except Exception:  # noqa: BLE001 - a derived figure must never cost the bench line
+                og = None
+            if og is not None:  # launches on a tuned tile id: operand traffic into LDS and the time it took
+                a["operand_gbyte"] = a.get("operand_gbyte", 0.0) + og
+                a["operand_ms"] = a.get("operand_ms", 0.0) + ms
             sh = shapes.setdefault((d.mode, d.M, d.N, taps * (d.c0 + d.c1), max(d.batch, 1), d.act, d.c1 > 0),
                                    {"n": 0, "ms": 0.0, "tflop": 0.0})
             sh["n"] += 1
@@ -280,6 +306,12 @@ def main():
                 "launches": gm["launches"], "tflop_per_step": round(gm["tflop"], 3), "ms_per_step": round(gm["ms"], 3),
                 "whole_step_frac": round(UNET_TFLOP_PER_STEP / (ms_per_step / 1e3) / MFMA_PEAK_TFLOPS, 4),
             }
+            if gm.get("operand_ms"):  # the rate the kernel is actually bound by
+                result["roofline"]["operand_delivery"] = {
+                    "gbyte_per_step": round(gm["operand_gbyte"], 2), "ms": round(gm["operand_ms"], 3),
+                    "tb_per_s": round(gm["operand_gbyte"] / gm["operand_ms"], 2),
+                    "what": "tile panels streamed L2 -> LDS: sum over launches of tiles x (BM + BN) x K x 2 bytes / their time; "
+                            "256 CUs x 16 B/clk x 2.4 GHz (one LDS-DMA lane per clock per CU) = 9.8 TB/s"}
             result["kernel_ms"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflop": round(v["tflop"], 3),
                                        **({"gbyte": round(v["gbyte"], 3), "gb_per_s": round(v["gbyte"] / (v["ms"] / 1e3), 1)}
                                           if v.get("gbyte") else {})}
