@@ -1,0 +1,711 @@
+"""Data gradient of the UNet forward: d(loss)/d(latents) for a loss on the denoiser output and / or on the recorded
+temporal attention probabilities — what ``get_motion_prior_score`` asks of autograd (``motion_prior_sample.py:59-84``:
+``latents.requires_grad_(True)`` -> UNet -> ``attn1.attention_probs`` of the output-block temporal transformers ->
+``autograd.grad(loss, latents)``), and the dX half of a native student backward.  All weights are
+frozen on this path: only data gradients are computed, never weight gradients, and the conditioning branch (time / fps /
+guidance embeddings, text K / V) carries none because it does not depend on the latents.
+
+Same construction as the VAE decoder's gradient engine: the forward is recorded together with a *tape* of closures, each
+recording its block's backward launches; forward and backward are two replayable launch lists over one buffer pool.
+Saved per block: GroupNorm inputs + (mean, rstd), LayerNorm inputs, q / k / v (or q, k, V^T) of every attention, the GEGLU
+pre-activation.  Recomputed in the backward: attention probabilities (GEMM-formulated for the spatial layers, in-register
+for the 16-frame temporal ones), everything element-wise.
+
+  conv3x3 / (3,1,1) / 1x1 dX   the implicit-GEMM kernel on re-packed weights (flipped taps, swapped channels)
+  stride-2 conv dX             zero-interleave the gradient to the input grid (``scatter2x``), then the flipped 3x3
+  nearest-x2 + conv dX         flipped 3x3 at the high resolution, then a 2x2 sum-pool
+  GroupNorm(+SiLU)             ``gn_bwd`` (two-part input for the skip concats; the residual branch rides in ``resid``)
+  LayerNorm                    ``layernorm_bwd`` (statistics recomputed per row; residual fused)
+  GEGLU                        ``geglu_bwd`` on the saved pre-activation (packed [32 value | 32 gate] column groups)
+  temporal attention           ``attn_temporal_bwd`` (one wave-sized problem per pixel and head; takes d(probs) as well)
+  spatial self / text cross    batched GEMMs around ``softmax_rows`` / ``softmax_bwd_rows`` with bf16 transposes
+
+Status: the dataflow is verified on CPU against torch autograd (tests/test_unet_grad_cpu.py, emulated op backend).  The
+device kernels for the five new ops are written (csrc/backward.hip) but have not run on hardware yet; ``native`` use
+raises until ``T2V_UNVALIDATED_KERNELS=1`` is set."""
+import torch
+import torch.nn as nn
+
+from . import native as nt
+from .engine import Act, UNetEngine, effective_weight_bias, leaf_out_channels
+from .unet3d import Downsample, ResBlock, SpatialTransformer, TemporalTransformer, TimestepEmbedSequential, Upsample
+
+
+class UNetGradEngine(UNetEngine):
+    # ---- public: forward with tape, then backward ----------------------------------------------------------------
+    def forward_tape(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None):
+        m = self.model
+        assert x.dim() == 5 and context is not None
+        self._check_weights(m)
+        for mod in m.modules():
+            if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training:
+                raise RuntimeError("native UNet gradient path: a Dropout(p>0) is in training mode; call .eval() first")
+        key = ("grad", tuple(x.shape), x.dtype, tuple(context.shape), context.dtype, isinstance(fps, int),
+               None if timestep_cond is None else tuple(timestep_cond.shape),
+               None if motion_cond is None else tuple(motion_cond.shape), x.device)
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = self._record_grad(x, timesteps, context, fps, timestep_cond, motion_cond)
+            self.plans[key] = plan
+            if getattr(self.ops, "is_native", False):
+                self._replay(plan, "rec")  # recording ran the backward once and recycled the saved buffers
+        else:
+            st = plan["static"]
+            st["x"].copy_(x)
+            st["ts"].copy_(timesteps)
+            st["ctx"].copy_(context)
+            if m.fps_cond:
+                st["fps"].fill_(fps) if isinstance(fps, int) else st["fps"].copy_(fps)
+            if timestep_cond is not None:
+                st["tc"].copy_(timestep_cond)
+            if motion_cond is not None:
+                st["mc"].copy_(motion_cond)
+            self._replay(plan, "rec")
+        plan["fwd_id"] = plan.get("fwd_id", 0) + 1
+        self._last = plan
+        self._publish_probs(plan)
+        return plan["out"].clone()
+
+    def backward(self, dout=None, dprobs=None):
+        """d(loss)/dx for the most recent ``forward_tape``.  ``dout``: gradient w.r.t. the output (or None = 0);
+        ``dprobs``: {attention module: gradient w.r.t. its ``attention_probs``} for any of the recorded layers."""
+        plan = self._last
+        if plan.get("bwd_id") == plan["fwd_id"]:
+            raise RuntimeError("UNet gradient: backward was already run for this forward (its saved activations are gone)")
+        plan["bwd_id"] = plan["fwd_id"]
+        st = plan["static"]
+        st["dout"].zero_() if dout is None else st["dout"].copy_(dout)
+        dprobs = dprobs or {}
+        known = {id(a) for a, _ in plan["probs"]}
+        for a in dprobs:
+            if id(a) not in known:
+                raise KeyError("dprobs given for a layer that does not record attention_probs")
+        for attn, _ in plan["probs"]:
+            buf = plan["dprobs"][id(attn)]
+            g = dprobs.get(attn)
+            buf.zero_() if g is None else buf.copy_(g)
+        self._replay(plan, "rec_bwd")
+        return plan["dx"].clone()
+
+    def _replay(self, plan, which):
+        ops = self.ops
+        if getattr(ops, "is_native", False):
+            ops.replay(plan[which], ops.stream())
+        else:
+            plan["fn" if which == "rec" else "fn_bwd"]()
+
+    # ---- recording ------------------------------------------------------------------------------------------------
+    def _record_grad(self, x, timesteps, context, fps, timestep_cond, motion_cond):
+        m, ops = self.model, self.ops
+        native = getattr(ops, "is_native", False)
+        if native:
+            import os
+            if os.environ.get("T2V_UNVALIDATED_KERNELS") != "1":
+                raise nt.NativeError("the UNet gradient path's device kernels have not been validated on hardware yet "
+                                     "(set T2V_UNVALIDATED_KERNELS=1 to run them anyway)")
+        self._begin(x.device)
+        B, Cin, F, H, W = x.shape
+        self.B, self.F = B, F
+        st = {"x": x.detach().clone().contiguous(), "ts": timesteps.detach().to(torch.int64).clone(),
+              "ctx": context.detach().clone().contiguous()}
+        if m.fps_cond:
+            st["fps"] = (torch.full_like(st["ts"], fps) if isinstance(fps, int) else fps.detach().to(torch.int64).clone())
+        if timestep_cond is not None:
+            st["tc"] = timestep_cond.detach().clone().contiguous()
+        if motion_cond is not None:
+            st["mc"] = motion_cond.detach().clone().contiguous()
+        out = torch.empty(B, m.out_channels, F, H, W, dtype=x.dtype, device=x.device)
+        st["dout"] = torch.zeros_like(out)
+        plan = {"static": st, "out": out, "dx": torch.empty_like(st["x"]), "probs": [], "dprobs": {}, "runs": 0}
+        self.plan = plan
+        self.tape, self.refs = [], {}
+
+        def fwd():
+            self.tape.clear()
+            self.refs.clear()
+            plan["probs"].clear()
+            self._forward_tape(st, out)
+
+        def bwd():
+            self._backward_tape(st["dout"], plan["dx"])
+
+        if native:
+            ops.init()
+            for which, fn in (("rec", fwd), ("rec_bwd", bwd)):
+                ops.recording = []
+                try:
+                    fn()
+                finally:
+                    plan[which] = ops.recording
+                    ops.recording = None
+        else:  # emulation backend (tests): the closures themselves are the plan; every forward is followed by one backward
+            fwd()
+            plan["fn"], plan["fn_bwd"] = fwd, bwd
+        plan["pool_bytes"] = self.pool.bytes
+        return plan
+
+    # ---- saved-activation bookkeeping: a tensor may be kept by several backward closures (skip connections) ----------
+    def hold(self, *ts):
+        for t in ts:
+            if t is not None:
+                self.refs[t.data_ptr()] = self.refs.get(t.data_ptr(), 0) + 1
+
+    def drop(self, *ts):
+        for t in ts:
+            if t is None:
+                continue
+            k = t.data_ptr()
+            n = self.refs.get(k, 0) - 1
+            if n > 0:
+                self.refs[k] = n
+            else:
+                self.refs.pop(k, None)
+                self.pool.put(t)
+
+    # ---- helpers ------------------------------------------------------------------------------------------------------
+    def gn_t(self, x, norm, units, rows, silu):
+        """GroupNorm(+SiLU) of an Act keeping (mean, rstd); the caller keeps x for the backward."""
+        ops = self.ops
+        G = norm.num_groups
+        ws = self.buf(1, max(ops.gn_ws_floats(units, rows, G), 1), torch.float32)
+        stats = self.buf(units, G * 2, torch.float32)
+        ops.gn_stats(x.parts[0], x.p1, units, rows, norm.eps, ws, stats, G)
+        out = self.buf(x.M, x.C)
+        ops.gn_apply(x.parts[0], x.p1, units, rows, stats, self.pk.f32(norm.weight), self.pk.f32(norm.bias), silu, out, G)
+        self.pool.put(ws)
+        return out, stats
+
+    def gn_b(self, x, norm, units, rows, silu, stats, dy, resid=None):
+        """-> dx [M, C] (one buffer even when x is a virtual concat: the consumer takes column slices)."""
+        ops = self.ops
+        G = norm.num_groups
+        ws = self.buf(1, max(ops.gn_bwd_ws_floats(units, rows, G), 1), torch.float32)
+        dx = self.buf(x.M, x.C)
+        ops.gn_bwd(x.parts[0], units, rows, stats, self.pk.f32(norm.weight), self.pk.f32(norm.bias), silu, dy, resid, ws, dx, G,
+                   x1=x.p1)
+        self.pool.put(ws)
+        return dx
+
+    def tconv_dgrad_w(self, mod):
+        """(3,1,1) conv data gradient as the same temporal conv over dy: w'[ci][(kt', co)] = w[co][ci][2 - kt']."""
+        def make():
+            w = effective_weight_bias(mod)[0]                       # [co, ci, 3, 1, 1]
+            wd = w[:, :, :, 0, 0].flip(2).permute(1, 2, 0)          # [ci, kt', co]
+            return wd.reshape(wd.shape[0], -1).to(self.device, self.adt).contiguous()
+        return self.pk._memo(("tconv_dgrad", id(mod)), make)
+
+    def mats_t(self, mods, tag):
+        """Transposed pack of row-concatenated Linear weights: [K, sum N] (dx = d[y0|y1|..] @ cat(W))."""
+        return self.pk._memo((tag,) + tuple(id(mm) for mm in mods),
+                             lambda: self.pk.cat_mats(mods, tag + "_fwd").t().contiguous())
+
+    def lin_b(self, dy, w_t, residual=None):
+        """dx = dy @ W for a [K, N]-transposed pack w_t (rows = input features)."""
+        out = self.buf(dy.shape[0], w_t.shape[0])
+        self.ops.gemm(dy, w_t, out, M=dy.shape[0], N=w_t.shape[0], residual=residual)
+        return out
+
+    def add(self, a, b):
+        out = self.buf(a.shape[0], a.shape[1])
+        self.ops.add(a, b, out)
+        return out
+
+    # ---- forward with tape ------------------------------------------------------------------------------------------
+    def _forward_tape(self, st, out):
+        m, ops, pk = self.model, self.ops, self.pk
+        B, F = self.B, self.F
+        x = st["x"]
+        _, Cin, _, H, W = x.shape
+        self._conditioning(st)
+        xt = self.buf(B * F * H * W, Cin)
+        ops.ncfhw_to_tokens(x, xt)
+        conv_in = m.input_blocks[0][0]
+        c_first = leaf_out_channels(conv_in)
+        h0 = self.buf(B * F * H * W, c_first)
+        ops.conv_small(xt, B * F, H, W, pk.small_conv(conv_in), pk.bias(conv_in), h0)
+        self.pool.put(xt)
+        h = Act(h0, B * F, H, W)
+        hs = []
+        for i, block in enumerate(m.input_blocks):
+            if i > 0:
+                h = self.run_sequential_t(block, h)
+            if i == 0 and m.addition_attention:
+                h = self.run_sequential_t(m.init_attn, h)
+            hs.append(h)
+            # h is a skip connection too: in the backward, the gradient the matching output block left for it is added
+            # here, i.e. after everything downstream of h on the main chain has been walked back
+            self.tape.append(("join", None))
+        h = self.run_sequential_t(m.middle_block, h)
+        for block in m.output_blocks:
+            skip = hs.pop()
+            # (reverse order!) once the block below is walked back, its input gradient [M, c(h) + c(skip)] splits in two
+            self.tape.append(("split", h.C))
+            h = self.run_sequential_t(block, Act([h.t, skip.t], h.n_img, h.h, h.w))
+        xin = h
+        self.hold(xin.t)
+        tt, st_out = self.gn_t(xin, m.out[0], B * F, H * W, True)
+        y = self.conv(Act(tt, h.n_img, h.h, h.w), m.out[2], nt.GEMM_CONV3X3, out_dtype=torch.float32)
+        self.pool.put(tt)
+        ops.tokens_to_ncfhw(y.t, out)
+        self.pool.put(y.t)
+        n_img = B * F
+
+        cpad = 4 if m.out_channels <= 4 else 8
+        assert m.out_channels <= 8, "the direct small-channel conv handles up to 8 gradient channels"
+
+        def exit_bwd(dout):
+            # conv_out data gradient (4 -> 320 channels) on the direct small-channel conv, like the VAE decoder's exit
+            d4 = self.buf(n_img * H * W, cpad)
+            if cpad != m.out_channels:
+                ops.fill_zero(d4)
+            ops.ncfhw_to_tokens(dout, d4)
+            dt = self.buf(n_img * H * W, xin.C)
+            ops.conv_small(d4, n_img, H, W, pk.small_conv_dgrad(m.out[2], cin_pad=cpad), None, dt)
+            self.pool.put(d4)
+            dx = self.gn_b(xin, m.out[0], n_img, H * W, True, st_out, dt)
+            self.pool.put(dt, st_out)
+            self.drop(xin.t)
+            return Act(dx, n_img, H, W)
+
+        def entry_bwd(dy, dx_out):
+            # conv_in data gradient (320 -> 4 channels): a narrow-N implicit GEMM like the forward's conv_out, fp32 out
+            d = self.conv(dy, conv_in, nt.GEMM_CONV3X3, w=pk.conv_dgrad(conv_in), bias=None, out_dtype=torch.float32)
+            self._free_view(dy.t)
+            ops.tokens_to_ncfhw(d.t, dx_out)
+            self.pool.put(d.t)
+
+        self.exit_bwd, self.entry_bwd = exit_bwd, entry_bwd
+
+    def _conditioning(self, st):
+        """Embedding / context branch of UNetEngine._forward (no dependence on the latents: no tape)."""
+        m, ops, pk = self.model, self.ops, self.pk
+        B = self.B
+        mc = m.model_channels
+        L, D = st["ctx"].shape[1], st["ctx"].shape[2]
+        t_emb = self.buf(B, mc)
+        ops.timestep_embedding(st["ts"], mc, False, t_emb)
+        emb_in = t_emb
+        if "tc" in st:
+            tcb = self.buf(B, st["tc"].shape[1])
+            ops.cast(st["tc"], tcb)
+            if "mc" in st:
+                cond = self.linear(tcb, m.time_cond_proj)
+                mcb = self.buf(B, st["mc"].shape[1])
+                ops.cast(st["mc"], mcb)
+                mproj = self.linear(mcb, m.motion_cond_proj)
+                emb_in = self.buf(B, mc)
+                ops.gemm(cond, pk.mat(m.combine_proj), emb_in, M=B, N=mc, a1=mproj, residual=t_emb)
+            else:
+                emb_in = self.linear(tcb, m.time_cond_proj, residual=t_emb)
+        e1 = self.linear(emb_in, m.time_embed[0], act=nt.ACT_SILU)
+        emb = self.linear(e1, m.time_embed[2])
+        if m.fps_cond:
+            f_emb = self.buf(B, mc)
+            ops.timestep_embedding(st["fps"], mc, False, f_emb)
+            f1 = self.linear(f_emb, m.fps_embedding[0], act=nt.ACT_SILU)
+            emb = self.linear(f1, m.fps_embedding[2], residual=emb)
+        emb_s = self.buf(B, emb.shape[1])
+        ops.silu(emb, emb_s)
+        resblocks = [mod for mod in m.modules() if isinstance(mod, ResBlock)]
+        self.emb_off, off = {}, 0
+        for rb in resblocks:
+            self.emb_off[id(rb)] = off
+            off += rb.out_channels
+        lins = [rb.emb_layers[1] for rb in resblocks]
+        w_all = pk.cat_mats(lins, "emb_all")
+        b_all = pk._memo(("emb_all_bias",) + tuple(id(l) for l in lins),
+                         lambda: torch.cat([pk.bias(l) for l in lins]).contiguous())
+        self.emb_all = self.linear(emb_s, None, w=w_all, bias=b_all, out_dtype=torch.float32)
+        self.ctx = self.buf(B * L, D)
+        ops.cast(st["ctx"], self.ctx)
+        self.ctx_len = L
+        self.ctx_kv = {}
+
+    def _backward_tape(self, dout, dx_out):
+        d = self.exit_bwd(dout)
+        skip_grads = []  # gradients of the skip tensors, in the order the output blocks produced them
+        for kind, fn in reversed(self.tape):
+            if kind == "split":
+                c0 = fn
+                # d is [M, c0 + c_skip]: the first c0 columns continue down the chain, the rest wait for their producer
+                skip_grads.append((d.t, c0))
+                d = Act(d.t[:, :c0], d.n_img, d.h, d.w)
+            elif kind == "join":
+                # the tensor this block produced was also a skip connection: add that gradient before going on
+                buf, c0 = skip_grads.pop()
+                total = self.add(d.t, buf[:, c0:])
+                self._free_view(d.t)
+                self.pool.put(buf)
+                d = Act(total, d.n_img, d.h, d.w)
+            else:
+                d = fn(d)
+        self.entry_bwd(d, dx_out)
+
+    def _free_view(self, t):
+        """Release a gradient tensor unless it is a column slice of a concat-gradient buffer (freed with the buffer)."""
+        if t.data_ptr() in self.pool.live and t.stride(0) == t.shape[1]:
+            self.pool.put(t)
+
+    def run_sequential_t(self, seq, h):
+        assert isinstance(seq, TimestepEmbedSequential)
+        for layer in seq:
+            if isinstance(layer, ResBlock):
+                h = self.res_block_t(layer, h)
+            elif isinstance(layer, SpatialTransformer):
+                h = self.spatial_transformer_t(layer, h)
+            elif isinstance(layer, TemporalTransformer):
+                h = self.temporal_transformer_t(layer, h)
+            elif isinstance(layer, Downsample):
+                assert layer.use_conv
+                h = self.downsample_t(layer, h)
+            elif isinstance(layer, Upsample):
+                assert layer.use_conv
+                src = h
+                h = self.upsample_t(layer, h)
+                if self.refs.get(src.t.data_ptr(), 0) == 0:  # an intermediate nobody keeps for the backward
+                    self.pool.put(src.t)
+            else:
+                raise NotImplementedError(f"native gradient path: unsupported layer {type(layer).__name__}")
+        return h
+
+    # ---- blocks ----------------------------------------------------------------------------------------------------------
+    def res_block_t(self, rb, x):
+        B, F = self.B, self.F
+        n, hw = x.n_img, x.h * x.w
+        off, cout = self.emb_off[id(rb)], rb.out_channels
+        self.hold(*x.parts)
+        t1, st1 = self.gn_t(x, rb.in_layers[0], B * F, hw, True)
+        h1 = self.conv(Act(t1, n, x.h, x.w), rb.in_layers[2], nt.GEMM_CONV3X3,
+                       rowvec=self.emb_all[:, off:off + cout], rowvec_div=F * hw)
+        self.pool.put(t1)
+        t2, st2 = self.gn_t(h1, rb.out_layers[0], B * F, hw, True)
+        identity = isinstance(rb.skip_connection, nn.Identity)
+        if identity:
+            skip, own = x.t, False
+        else:
+            sc = rb.skip_connection
+            assert effective_weight_bias(sc)[0].shape[-1] == 1, "3x3 skip convs are not built by the VideoCrafter2 config"
+            skip = self.buf(x.M, cout)
+            self.ops.gemm(x.parts[0], self.pk.mat(sc), skip, M=x.M, N=cout, a1=x.p1, bias=self.pk.bias(sc))
+            own = True
+        h2 = self.conv(Act(t2, n, x.h, x.w), rb.out_layers[3], nt.GEMM_CONV3X3, residual=skip)
+        self.pool.put(t2)
+        if own:
+            self.pool.put(skip)
+        geom = (n, x.h, x.w)
+        tc_bwd = None
+        y = h2
+        if rb.use_temporal_conv:
+            y, tc_bwd = self.temporal_conv_block_t(rb.temopral_conv, h2)
+
+        def bwd(dy):
+            d_h2 = tc_bwd(dy) if tc_bwd is not None else dy.t
+            d_t2 = self.conv(Act(d_h2, *geom), rb.out_layers[3], nt.GEMM_CONV3X3, w=self.pk.conv_dgrad(rb.out_layers[3]), bias=None)
+            d_h1 = self.gn_b(h1, rb.out_layers[0], B * F, hw, True, st2, d_t2.t)
+            self.pool.put(d_t2.t, h1.t, st2)
+            d_t1 = self.conv(Act(d_h1, *geom), rb.in_layers[2], nt.GEMM_CONV3X3, w=self.pk.conv_dgrad(rb.in_layers[2]), bias=None)
+            self.pool.put(d_h1)
+            d_skip = d_h2 if identity else self.lin_b(d_h2, self.pk.mat_t(rb.skip_connection))
+            dx = self.gn_b(x, rb.in_layers[0], B * F, hw, True, st1, d_t1.t, resid=d_skip)
+            self.pool.put(d_t1.t, st1)
+            if not identity:
+                self.pool.put(d_skip)
+            self._free_view(d_h2)
+            self.drop(*x.parts)
+            return Act(dx, *geom)
+
+        self.tape.append(("block", bwd))
+        return y
+
+    def temporal_conv_block_t(self, tc, h2):
+        """-> (output, backward closure: dy Act -> gradient w.r.t. h2 as a tensor)."""
+        B, F = self.B, self.F
+        n, hw = h2.n_img, h2.h * h2.w
+        geom = (n, h2.h, h2.w)
+        stages = (tc.conv1, tc.conv2, tc.conv3, tc.conv4)
+        saved = []
+        y = h2
+        for i, stage in enumerate(stages):
+            tt, st = self.gn_t(y, stage[0], B, F * hw, True)
+            ny = self.conv(Act(tt, *geom), stage[-1], nt.GEMM_TCONV3, frames=F, residual=h2.t if i == 3 else None)
+            self.pool.put(tt)
+            saved.append((y, st))
+            y = ny
+
+        def bwd(dy):
+            d = dy.t
+            for i in (3, 2, 1, 0):
+                yi, st = saved[i]
+                d_tt = self.conv(Act(d, *geom), stages[i][-1], nt.GEMM_TCONV3, frames=F, w=self.tconv_dgrad_w(stages[i][-1]), bias=None)
+                if i != 3:
+                    self.pool.put(d)
+                nd = self.gn_b(yi, stages[i][0], B, F * hw, True, st, d_tt.t, resid=dy.t if i == 0 else None)
+                self.pool.put(d_tt.t, st)
+                if i != 0:
+                    self.pool.put(yi.t)  # h2 itself (i == 0) belongs to the residual block's closure
+                d = nd
+            self._free_view(dy.t)
+            self.pool.put(h2.t)
+            return d
+
+        return y, bwd
+
+    def downsample_t(self, layer, x):
+        y = self.conv(x, layer.op, nt.GEMM_CONV3X3_S2)
+        n, h, w, cin = x.n_img, x.h, x.w, x.C
+
+        def bwd(dy):
+            z = self.buf(n * h * w, dy.C)
+            self.ops.scatter2x(dy.t, n, dy.h, dy.w, h, w, z)
+            self._free_view(dy.t)
+            dx = self.conv(Act(z, n, h, w), layer.op, nt.GEMM_CONV3X3, w=self.pk.conv_dgrad(layer.op), bias=None)
+            self.pool.put(z)
+            return dx
+
+        self.tape.append(("block", bwd))
+        return y
+
+    def upsample_t(self, layer, x):
+        y = self.conv(x, layer.conv, nt.GEMM_CONV3X3_UP2)
+        n, h, w, cin = x.n_img, x.h, x.w, x.C
+
+        def bwd(dy):
+            d_up = self.conv(dy, layer.conv, nt.GEMM_CONV3X3, w=self.pk.conv_dgrad(layer.conv), bias=None)  # at 2h x 2w
+            self._free_view(dy.t)
+            dx = self.buf(n * h * w, cin)
+            self.ops.sumpool2x2(d_up.t, n, h, w, dx)
+            self.pool.put(d_up.t)
+            return Act(dx, n, h, w)
+
+        self.tape.append(("block", bwd))
+        return y
+
+    def spatial_transformer_t(self, st, x):
+        return self._transformer_t(st, x, temporal=False)
+
+    def temporal_transformer_t(self, tt, x):
+        return self._transformer_t(tt, x, temporal=True)
+
+    def _transformer_t(self, tr, x, temporal):
+        B, F = self.B, self.F
+        n, hw = x.n_img, x.h * x.w
+        units, rows = (B, F * hw) if temporal else (B * F, hw)
+        self.hold(x.t)
+        t, stats = self.gn_t(x, tr.norm, units, rows, False)
+        y = self.linear(t, tr.proj_in)
+        self.pool.put(t)
+        blocks = []
+        for blk in tr.transformer_blocks:
+            y, b = self.transformer_block_t(blk, y, (n, hw), temporal)
+            blocks.append(b)
+        out = self.linear(y, tr.proj_out, residual=x.t)
+        self.pool.put(y)
+        geom = (n, x.h, x.w)
+
+        def bwd(dy):
+            d = self.lin_b(dy.t, self.pk.mat_t(tr.proj_out))
+            for b in reversed(blocks):
+                d = b(d)
+            d_t = self.lin_b(d, self.pk.mat_t(tr.proj_in))
+            self.pool.put(d)
+            dx = self.gn_b(x, tr.norm, units, rows, False, stats, d_t, resid=dy.t)
+            self.pool.put(d_t, stats)
+            self._free_view(dy.t)
+            self.drop(x.t)
+            return Act(dx, *geom)
+
+        self.tape.append(("block", bwd))
+        return Act(out, *geom)
+
+    def transformer_block_t(self, blk, y, x_geom, temporal):
+        """-> (output rows, backward closure: d(output) tensor -> d(input) tensor).  The block's input y stays alive
+        until the closure ran; the closure frees it."""
+        ops, pk = self.ops, self.pk
+        B, F = self.B, self.F
+        M, C = y.shape
+        n_img, hw = x_geom
+        a1, a2 = blk.attn1, blk.attn2
+        self._check_heads(a1)
+        inner = a1.heads * a1.dim_head
+
+        def lnorm(norm, src):
+            ln = self.buf(M, C)
+            ops.layernorm(src, pk.f32(norm.weight), pk.f32(norm.bias), norm.eps, ln)
+            return ln
+
+        def ln_b(norm, src, d_ln, resid):
+            dx = self.buf(M, C)
+            ops.layernorm_bwd(src, pk.f32(norm.weight), norm.eps, d_ln, resid, dx)
+            return dx
+
+        # ---- attention flavours: forward returns (o, backward: d_o -> d(ln input of the attention)) ------------------
+        def temporal_attn(attn, src):
+            mods = [attn.to_q, attn.to_k, attn.to_v]
+            qkv = self.linear(src, None, w=pk.cat_mats(mods, "qkv"), bias=None)
+            o = self.buf(M, inner)
+            probs = dprobs = None
+            if attn.record_attn_probs:
+                probs = torch.empty(B * hw * attn.heads, F, F, dtype=torch.float32, device=self.device)
+                self.plan["probs"].append((attn, probs))
+                dprobs = self.plan["dprobs"].setdefault(id(attn), torch.zeros_like(probs))
+            ops.attn_temporal(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], o, B, F, hw, attn.heads, attn.scale, probs)
+
+            def bwd(d_o):
+                dqkv = self.buf(M, 3 * inner)
+                ops.attn_temporal_bwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], d_o, dprobs,
+                                      dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:], B, F, hw, attn.heads, attn.scale)
+                self.pool.put(qkv, d_o)
+                d_ln = self.lin_b(dqkv, self.mats_t(mods, "qkv_t"))
+                self.pool.put(dqkv)
+                return d_ln
+            return o, bwd
+
+        def spatial_self_attn(attn, src):
+            heads = attn.heads
+            qk = self.linear(src, None, w=pk.cat_mats([attn.to_q, attn.to_k], "qk"), bias=None)
+            kp = ((hw + 63) // 64) * 64
+            vt = self.buf(n_img * inner, kp)
+            if kp != hw:
+                ops.fill_zero(vt)
+            ops.gemm(pk.mat(attn.to_v), src, vt, M=inner, N=hw, batch=n_img, w_strides=(hw * src.stride(0), 0), o_strides=(inner * kp, 0))
+            o = self.buf(M, inner)
+            ops.attn_spatial(qk[:, :inner], qk[:, inner:], vt, kp, o, n_img, hw, hw, heads, 1, attn.scale)
+            nb = n_img * heads
+
+            def tposed(src2d, rows, cols, in_stride, batch):
+                """[batch][rows][cols] -> [batch][cols][kp] (rows padded with zeros up to kp)."""
+                dst = self.buf(batch * cols, kp)
+                if kp != rows:
+                    ops.fill_zero(dst)
+                ops.transpose(src2d, rows, cols, dst, batch=batch, in_stride=in_stride, out_stride=cols * kp)
+                return dst
+
+            def bwd(d_o):
+                q, k = qk[:, :inner], qk[:, inner:]
+                ld = qk.stride(0)
+                hb = dict(batch=nb, batch_inner=heads)
+                # P = softmax(scale * Q K^T) per (image, head): rows (img, head, q), kp columns
+                s = self.buf(nb * hw, kp)
+                if kp != hw:
+                    ops.fill_zero(s)
+                ops.gemm(q[:, :64], k[:, :64], s, M=hw, N=hw, alpha=attn.scale, a_strides=(hw * ld, 64), w_strides=(hw * ld, 64),
+                         o_strides=(heads * hw * kp, hw * kp), **hb)
+                ops.softmax_rows(s, nb * hw, hw, kp, kp)
+                # dP[q][kv] = sum_c dO[q][c] V[kv][c]: W = V token-major per head = transpose of the V^T rows
+                v_tok = self.buf(nb * kp, 64)
+                ops.transpose(vt, 64, kp, v_tok, batch=nb, in_stride=64 * kp, out_stride=kp * 64)
+                dp = self.buf(nb * hw, kp)
+                ops.gemm(d_o[:, :64], v_tok, dp, M=hw, N=kp, a_strides=(hw * inner, 64), w_strides=(heads * kp * 64, kp * 64),
+                         o_strides=(heads * hw * kp, hw * kp), **hb)
+                self.pool.put(v_tok, vt)
+                # dV[kv][c] = sum_q P[q][kv] dO[q][c]: A = P^T [kv][q], W = dO^T [c][q] (one transpose per image covers all heads)
+                pT = tposed(s, hw, kp, hw * kp, nb)                       # [nb][kp][kp]
+                doT = tposed(d_o, hw, inner, hw * inner, n_img)           # [n_img][inner][kp] = [nb][64][kp]
+                self.pool.put(d_o)
+                d_v = self.buf(M, inner)
+                ops.gemm(pT, doT, d_v[:, :64], M=hw, N=64, a_strides=(heads * kp * kp, kp * kp), w_strides=(inner * kp, 64 * kp),
+                         o_strides=(hw * inner, 64), **hb)
+                self.pool.put(pT, doT)
+                ops.softmax_bwd_rows(s, dp, nb * hw, hw, kp, kp)         # dS in place on dP
+                self.pool.put(s)
+                dqk = self.buf(M, 2 * inner)
+                kT = tposed(k, hw, inner, hw * ld, n_img)
+                ops.gemm(dp, kT, dqk[:, :64], M=hw, N=64, alpha=attn.scale, a_strides=(heads * hw * kp, hw * kp),
+                         w_strides=(inner * kp, 64 * kp), o_strides=(hw * 2 * inner, 64), **hb)
+                self.pool.put(kT)
+                dsT = tposed(dp, hw, kp, hw * kp, nb)
+                qT = tposed(q, hw, inner, hw * ld, n_img)
+                self.pool.put(dp, qk)
+                ops.gemm(dsT, qT, dqk[:, inner:inner + 64], M=hw, N=64, alpha=attn.scale, a_strides=(heads * kp * kp, kp * kp),
+                         w_strides=(inner * kp, 64 * kp), o_strides=(hw * 2 * inner, 64), **hb)
+                self.pool.put(dsT, qT)
+                d1 = self.lin_b(dqk, self.mats_t([attn.to_q, attn.to_k], "qk_t"))
+                d_ln = self.lin_b(d_v, pk.mat_t(attn.to_v), residual=d1)
+                self.pool.put(dqk, d_v, d1)
+                return d_ln
+            return o, bwd
+
+        def cross_attn(attn, src):
+            heads, L = attn.heads, self.ctx_len
+            q = self.linear(src, attn.to_q, bias=None)
+            k, vt, kp, vt_stride = self.context_kv(attn)
+            o = self.buf(M, inner)
+            ops.attn_spatial(q, k, vt, kp, o, n_img, hw, L, heads, F, attn.scale, vt_stride)
+            ldk = k.stride(0)
+
+            def bwd(d_o):  # the text context carries no gradient: only dQ
+                d_q = self.buf(M, inner)
+                for b in range(B):  # the F frames of a clip share K / V
+                    rows = slice(b * F * hw, (b + 1) * F * hw)
+                    qb, dob, dqb = q[rows], d_o[rows], d_q[rows]
+                    kb = k[b * L:(b + 1) * L]
+                    vtb = torch.as_strided(vt, (inner, kp), (kp, 1), vt.storage_offset() + b * vt_stride)
+                    nbb = F * heads
+                    hb = dict(batch=nbb, batch_inner=heads)
+                    s = self.buf(nbb * hw, kp)
+                    ops.fill_zero(s)
+                    ops.gemm(qb[:, :64], kb[:, :64], s, M=hw, N=L, alpha=attn.scale, a_strides=(hw * inner, 64), w_strides=(0, 64),
+                             o_strides=(heads * hw * kp, hw * kp), **hb)
+                    ops.softmax_rows(s, nbb * hw, L, kp, kp)
+                    v_tok = self.buf(heads * kp, 64)
+                    ops.transpose(vtb, 64, kp, v_tok, batch=heads, in_stride=64 * kp, out_stride=kp * 64)
+                    dp = self.buf(nbb * hw, kp)
+                    ops.gemm(dob[:, :64], v_tok, dp, M=hw, N=kp, a_strides=(hw * inner, 64), w_strides=(0, kp * 64),
+                             o_strides=(heads * hw * kp, hw * kp), **hb)
+                    self.pool.put(v_tok)
+                    ops.softmax_bwd_rows(s, dp, nbb * hw, L, kp, kp)
+                    self.pool.put(s)
+                    kT = self.buf(inner, kp)
+                    ops.fill_zero(kT)
+                    ops.transpose(kb, L, inner, kT, batch=1, in_stride=0, out_stride=0)
+                    ops.gemm(dp, kT, dqb[:, :64], M=hw, N=64, alpha=attn.scale, a_strides=(heads * hw * kp, hw * kp),
+                             w_strides=(0, 64 * kp), o_strides=(hw * inner, 64), **hb)
+                    self.pool.put(dp, kT)
+                self.pool.put(q, d_o)
+                d_ln = self.lin_b(d_q, pk.mat_t(attn.to_q))
+                self.pool.put(d_q)
+                return d_ln
+            return o, bwd
+
+        # ---- forward ------------------------------------------------------------------------------------------------
+        ln = lnorm(blk.norm1, y)
+        o, attn1_b = temporal_attn(a1, ln) if temporal else spatial_self_attn(a1, ln)
+        self.pool.put(ln)
+        y1 = self.linear(o, a1.to_out[0], residual=y)
+        self.pool.put(o)
+        ln = lnorm(blk.norm2, y1)
+        o, attn2_b = temporal_attn(a2, ln) if temporal else cross_attn(a2, ln)
+        self.pool.put(ln)
+        y2 = self.linear(o, a2.to_out[0], residual=y1)
+        self.pool.put(o)
+        ln = lnorm(blk.norm3, y2)
+        proj = blk.ff.net[0]
+        assert hasattr(proj, "proj"), "non-gated FeedForward is not built by the VideoCrafter2 config"
+        wg, bg = pk.geglu(proj.proj)
+        hpre = self.linear(ln, None, w=wg, bias=bg)  # pre-activation kept for the backward (packed value | gate groups)
+        self.pool.put(ln)
+        g = self.buf(M, hpre.shape[1] // 2)
+        ops.geglu_fwd(hpre, g)
+        y3 = self.linear(g, blk.ff.net[2], residual=y2)
+        self.pool.put(g)
+
+        def bwd(dy3):
+            d_g = self.lin_b(dy3, pk.mat_t(blk.ff.net[2]))
+            d_h = self.buf(M, hpre.shape[1])
+            ops.geglu_bwd(hpre, d_g, d_h)
+            self.pool.put(d_g, hpre)
+            d_ln3 = self.lin_b(d_h, pk._memo(("geglu_t", id(proj.proj)), lambda: wg.t().contiguous()))
+            self.pool.put(d_h)
+            d_y2 = ln_b(blk.norm3, y2, d_ln3, dy3)
+            self.pool.put(d_ln3, dy3, y2)
+            d_o2 = self.lin_b(d_y2, pk.mat_t(a2.to_out[0]))
+            d_ln2 = attn2_b(d_o2)
+            d_y1 = ln_b(blk.norm2, y1, d_ln2, d_y2)
+            self.pool.put(d_ln2, d_y2, y1)
+            d_o1 = self.lin_b(d_y1, pk.mat_t(a1.to_out[0]))
+            d_ln1 = attn1_b(d_o1)
+            d_y = ln_b(blk.norm1, y, d_ln1, d_y1)
+            self.pool.put(d_ln1, d_y1, y)
+            return d_y
+
+        return y3, bwd

@@ -144,8 +144,9 @@ class EmuOps:
     def gn_bwd_ws_floats(self, n_units, rows_per_unit, groups=32):
         return 8
 
-    def gn_bwd(self, x, n_units, rows_per_unit, stats, gamma, beta, silu, dy, resid, ws, dx, groups=32):
+    def gn_bwd(self, x, n_units, rows_per_unit, stats, gamma, beta, silu, dy, resid, ws, dx, groups=32, x1=None):
         self._log("gn_bwd")
+        x = self._cat(x, x1)
         C = x.shape[1]
         cpg = C // groups
         st = stats.reshape(n_units, groups, 2).float()
@@ -166,6 +167,69 @@ class EmuOps:
         if resid is not None:
             d = d + resid.float()
         dx.copy_(d.to(dx.dtype))
+
+    def layernorm_bwd(self, x, gamma, eps, dy, resid, dx):
+        """dx = d/dx [LayerNorm(x)] . dy (+ resid); the affine bias does not enter."""
+        self._log("layernorm_bwd")
+        xf = x.float()
+        mean = xf.mean(dim=1, keepdim=True)
+        rstd = 1.0 / torch.sqrt(xf.var(dim=1, unbiased=False, keepdim=True) + eps)
+        xh = (xf - mean) * rstd
+        g = dy.float() * gamma.float()
+        d = rstd * (g - g.mean(dim=1, keepdim=True) - xh * (g * xh).mean(dim=1, keepdim=True))
+        if resid is not None:
+            d = d + resid.float()
+        dx.copy_(d.to(dx.dtype))
+
+    def geglu_fwd(self, h, out):
+        """h: [M, 2*inner] in 64-column groups [32 value | 32 gate] (the packed GEGLU projection); out = value * gelu(gate)."""
+        self._log("geglu_fwd")
+        g = h.float().reshape(h.shape[0], -1, 2, 32)
+        out.copy_((g[:, :, 0] * F.gelu(g[:, :, 1])).reshape(h.shape[0], -1).to(out.dtype))
+
+    def geglu_bwd(self, h, dy, dh):
+        self._log("geglu_bwd")
+        M = h.shape[0]
+        g = h.float().reshape(M, -1, 2, 32)
+        v, gate = g[:, :, 0], g[:, :, 1]
+        d = dy.float().reshape(M, -1, 32)
+        cdf = 0.5 * (1.0 + torch.erf(gate * 0.7071067811865476))
+        pdf = torch.exp(-0.5 * gate * gate) * 0.3989422804014327
+        out = torch.stack([d * gate * cdf, d * v * (cdf + gate * pdf)], dim=2)
+        dh.copy_(out.reshape(M, -1).to(dh.dtype))
+
+    def attn_temporal_bwd(self, q, k, v, do, dprobs, dq, dk, dv, n_clips, frames, hw, heads, scale):
+        """Backward of attn_temporal: (dq, dk, dv) from d(out) and, optionally, d(probs) [(b p head)][F][F] fp32."""
+        self._log("attn_temporal_bwd")
+        inner = heads * 64
+
+        def seqs(t):
+            return t.float().reshape(n_clips, frames, hw, heads, 64).permute(0, 2, 3, 1, 4).reshape(-1, frames, 64)
+
+        def rows(t):
+            return t.reshape(n_clips, hw, heads, frames, 64).permute(0, 3, 1, 2, 4).reshape(-1, inner)
+
+        Q, Kk, V, dO = seqs(q), seqs(k), seqs(v), seqs(do)
+        P = (Q @ Kk.transpose(1, 2) * scale).softmax(dim=2)
+        dP = dO @ V.transpose(1, 2)
+        if dprobs is not None:
+            dP = dP + dprobs.float()
+        dS = P * (dP - (P * dP).sum(dim=2, keepdim=True))
+        dq.copy_(rows(dS @ Kk * scale).to(dq.dtype))
+        dk.copy_(rows(dS.transpose(1, 2) @ Q * scale).to(dk.dtype))
+        dv.copy_(rows(P.transpose(1, 2) @ dO).to(dv.dtype))
+
+    def scatter2x(self, src, n_img, h, w, H, W, out):
+        """Adjoint of the stride-2 sampling: out[n, 2y, 2x] = src[n, y, x], zero elsewhere (H in {2h-1, 2h}, W likewise)."""
+        self._log("scatter2x")
+        C = src.shape[1]
+        z = torch.zeros(n_img, H, W, C)
+        z[:, 0:2 * h:2, 0:2 * w:2] = src.float().reshape(n_img, h, w, C)[:, :(H + 1) // 2, :(W + 1) // 2]
+        out.copy_(z.reshape(-1, C).to(out.dtype))
+
+    def add(self, a, b, out):
+        self._log("add")
+        out.copy_((a.float() + b.float()).to(out.dtype))
 
     def softmax_bwd_rows(self, p, dp, rows, n, n_pad, ld):
         self._log("softmax_bwd_rows")
