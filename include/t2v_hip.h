@@ -209,6 +209,34 @@ int t2v_transpose_bf16(const void* in, int ld_in, int rows, int cols, void* out,
                        long long in_stride, long long out_stride, void* stream);
 int t2v_sumpool2x2(const void* in, int n_img, int h, int w, int C, void* out, void* stream);
 
+/* ---------------------------------------------------------------- backward (dX) pieces of the UNet
+ * d(loss)/d(latents) through UNetModel.forward (openaimodel3d.py:672-740) for losses on the output and on the recorded
+ * temporal attention probabilities: motion_prior_sample.py:59-84 (autograd.grad(loss, latents)) and the data half of the
+ * student's backward (train_t2v_turbo_v1_lora.py:1190).  Convolution / linear / spatial-attention gradients are t2v_gemm
+ * launches; these are the rest.  STATUS: written after the round's GPU budget was spent - the engine's dataflow is verified on
+ * CPU against autograd with an emulation of exactly these semantics, the kernels themselves have not run on hardware yet.
+ * t2v_gn_bwd2: t2v_gn_bwd over a virtual channel concat [x0 | x1] (the skip connections), up to 4096 channels.
+ * t2v_layernorm_bwd: dx = d/dx LayerNorm(x) . dy (+ resid); statistics recomputed per row (attention.py:279-281).
+ * t2v_geglu_fwd / _bwd: h = packed pre-activation [M][2*inner] in 64-column groups [32 value | 32 gate] (the layout
+ *   T2V_ACT_GEGLU consumes); out = value * gelu(gate); dh in the same packed layout (attention.py:516-523).
+ * t2v_scatter2x: out[n][2y][2x] = src[n][y][x], zero elsewhere, H in {2h-1, 2h}: the gradient of a 3x3 s2 p1 conv is the
+ *   flipped 3x3 s1 p1 conv over this (openaimodel3d.py:63-72).
+ * t2v_add_bf16: out = a + b over [M][C] with row strides (gradient fan-in at the skip connections).
+ * t2v_attn_temporal_bwd: (dq, dk, dv) of t2v_attn_temporal from d(out) and, optionally, d(probs)
+ *   (fp32 [(b*HW+p)*heads+h][F][F], the layout of the forward's probs output); frames <= 16. */
+int t2v_gn_bwd2(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units, int rows_per_unit, int groups,
+                const float* stats, const float* gamma, const float* beta, int silu, const void* dy, int ldy, const void* resid,
+                int ldr, float* ws, void* dx, int ldo, void* stream);
+int t2v_layernorm_bwd(const void* x, int ldx, int M, int C, const float* gamma, float eps, const void* dy, int ldy,
+                      const void* resid, int ldr, void* dx, int ldo, void* stream);
+int t2v_geglu_fwd(const void* h, int ldh, long long M, int inner, void* out, int ldo, void* stream);
+int t2v_geglu_bwd(const void* h, int ldh, const void* dy, int ldy, long long M, int inner, void* dh, int ldd, void* stream);
+int t2v_scatter2x(const void* src, int n_img, int h, int w, int C, int H, int W, void* out, void* stream);
+int t2v_add_bf16(const void* a, int lda, const void* b, int ldb, void* out, int ldo, long long M, int C, void* stream);
+int t2v_attn_temporal_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout, int ldo,
+                          const float* dprobs, void* dq, int ldq2, void* dk, int ldk2, void* dv, int ldv2, int n_clips, int frames,
+                          int hw, int heads, float scale, void* stream);
+
 /* ---------------------------------------------------------------- optimizer / EMA over flat fp32 buffers
  * Replace bitsandbytes AdamW8bit / torch AdamW on the LoRA tensors (train_t2v_turbo_v1_lora.py:765-803),
  * accelerator.clip_grad_norm_ (:1193) and update_ema (utils/common_utils.py:307-319).

@@ -63,3 +63,25 @@ def get_motion_prior_score(unet, latents, ts, example_latent, original_context, 
         loss = temp_loss_scale * compute_temp_loss(attention_prob, attention_prob_example)
         score = torch.autograd.grad(loss, latents)[0].detach()
     return score, cond_teacher_output
+
+
+def get_motion_prior_score_native(grad_engine, unet, latents, ts, example_latent, original_context, inference_context,
+                                  temp_loss_scale):
+    """Same result as ``get_motion_prior_score`` with the differentiated pass on the UNet data-gradient engine
+    (``engine_unet_bwd.UNetGradEngine``): forward with tape, the (tiny) loss on the recorded probabilities differentiated by
+    autograd w.r.t. those probabilities only, and the engine's backward from there to the latents."""
+    with torch.no_grad():
+        _, attention_prob_example = get_temp_attn_prob(unet, example_latent, ts, original_context)
+        attention_prob_example = {k: v.clone() for k, v in attention_prob_example.items()}  # the next forward reuses the buffers
+    ctx = dict(inference_context)
+    out = grad_engine.forward_tape(latents.detach(), ts, ctx["context"], ctx.get("fps", 16), ctx.get("timestep_cond"),
+                                   ctx.get("motion_cond"))
+    modules = dict(unet.named_modules())
+    names = [n for n in attention_prob_example if n in modules]
+    leaves = {n: modules[n].attention_probs.detach().clone().requires_grad_(True) for n in names}
+    with torch.set_grad_enabled(True):
+        loss = temp_loss_scale * compute_temp_loss(leaves, attention_prob_example)
+        grads = torch.autograd.grad(loss, [leaves[n] for n in names])
+    score = grad_engine.backward(None, {modules[n]: g for n, g in zip(names, grads)})
+    return score.detach(), out
+

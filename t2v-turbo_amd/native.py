@@ -87,6 +87,18 @@ _SIGS = {
     "t2v_gn_bwd_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "t2v_gn_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                              C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "t2v_gn_bwd2": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                              C.c_int, C.c_void_p]),
+    "t2v_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "t2v_geglu_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "t2v_geglu_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "t2v_scatter2x": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "t2v_add_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_void_p]),
+    "t2v_attn_temporal_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.c_float, C.c_void_p]),
     "t2v_softmax_bwd_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "t2v_transpose_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
                                      C.c_longlong, C.c_void_p]),
@@ -304,10 +316,38 @@ class HipOps:
     def gn_bwd_ws_floats(self, n_units, rows_per_unit, groups=32):
         return int(self.lib.t2v_gn_bwd_ws_floats(n_units, rows_per_unit, groups))
 
-    def gn_bwd(self, x, n_units, rows_per_unit, stats, gamma, beta, silu, dy, resid, ws, dx, groups=32):
-        self._call("t2v_gn_bwd", _p(x), _row_stride(x), x.shape[1], n_units, rows_per_unit, groups, _p(stats), _p(gamma),
-                   _p(beta), int(silu), _p(dy), _row_stride(dy), _p(resid), 0 if resid is None else _row_stride(resid),
-                   _p(ws), _p(dx), _row_stride(dx))
+    def gn_bwd(self, x, n_units, rows_per_unit, stats, gamma, beta, silu, dy, resid, ws, dx, groups=32, x1=None):
+        if x1 is None and x.shape[1] <= 2048:
+            self._call("t2v_gn_bwd", _p(x), _row_stride(x), x.shape[1], n_units, rows_per_unit, groups, _p(stats), _p(gamma),
+                       _p(beta), int(silu), _p(dy), _row_stride(dy), _p(resid), 0 if resid is None else _row_stride(resid),
+                       _p(ws), _p(dx), _row_stride(dx))
+        else:  # virtual channel concat [x | x1]
+            self._call("t2v_gn_bwd2", _p(x), x.shape[1], _row_stride(x), _p(x1), 0 if x1 is None else x1.shape[1],
+                       0 if x1 is None else _row_stride(x1), n_units,
+                       rows_per_unit, groups, _p(stats), _p(gamma), _p(beta), int(silu), _p(dy), _row_stride(dy), _p(resid),
+                       0 if resid is None else _row_stride(resid), _p(ws), _p(dx), _row_stride(dx))
+
+    # -- backward pieces (UNet dX; device kernels not yet validated on hardware, see include/t2v_hip.h) ------------------
+    def layernorm_bwd(self, x, gamma, eps, dy, resid, dx):
+        self._call("t2v_layernorm_bwd", _p(x), _row_stride(x), x.shape[0], x.shape[1], _p(gamma), eps, _p(dy), _row_stride(dy),
+                   _p(resid), 0 if resid is None else _row_stride(resid), _p(dx), _row_stride(dx))
+
+    def geglu_fwd(self, h, out):
+        self._call("t2v_geglu_fwd", _p(h), _row_stride(h), h.shape[0], out.shape[1], _p(out), _row_stride(out))
+
+    def geglu_bwd(self, h, dy, dh):
+        self._call("t2v_geglu_bwd", _p(h), _row_stride(h), _p(dy), _row_stride(dy), h.shape[0], dy.shape[1], _p(dh), _row_stride(dh))
+
+    def scatter2x(self, src, n_img, h, w, H, W, out):
+        self._call("t2v_scatter2x", _p(src), n_img, h, w, src.shape[1], H, W, _p(out))
+
+    def add(self, a, b, out):
+        self._call("t2v_add_bf16", _p(a), _row_stride(a), _p(b), _row_stride(b), _p(out), _row_stride(out), a.shape[0], a.shape[1])
+
+    def attn_temporal_bwd(self, q, k, v, do, dprobs, dq, dk, dv, n_clips, frames, hw, heads, scale):
+        self._call("t2v_attn_temporal_bwd", _p(q), _row_stride(q), _p(k), _row_stride(k), _p(v), _row_stride(v), _p(do),
+                   _row_stride(do), _p(dprobs), _p(dq), _row_stride(dq), _p(dk), _row_stride(dk), _p(dv), _row_stride(dv),
+                   n_clips, frames, hw, heads, scale)
 
     def softmax_bwd_rows(self, p, dp, rows, n, n_pad, ld):
         self._call("t2v_softmax_bwd_rows", _p(p), _p(dp), rows, n, n_pad, ld)

@@ -74,3 +74,24 @@ def test_unet_grad_engine_batch2_motion_cond():
     m.native_mode = "off"
     (g_ref,) = torch.autograd.grad((m(xg, ts, context=ctx, fps=8, timestep_cond=tc, motion_cond=mc) * r_out).sum(), xg)
     assert rel_l2(eng.backward(r_out), g_ref) < 1e-4
+
+
+def test_motion_prior_score_on_the_gradient_engine():
+    """get_motion_prior_score (motion_prior_sample.py:59-84) two ways: autograd through the module, and the gradient engine
+    fed with d(loss)/d(probs)."""
+    from t2v_turbo_amd import motion_prior as mp
+    g = load("unet_tiny")
+    cfg = tiny_unet_params(record_attn_probs=True)
+    m = UNetModel(**cfg).eval()
+    m.load_state_dict(synth_state_dict(manifest("unet_tiny")), strict=True)
+    m.requires_grad_(False)
+    m.native_mode = "off"
+    gen = torch.Generator().manual_seed(3)
+    latents, example = g["x"].clone(), torch.randn(g["x"].shape, generator=gen)
+    ctx = {"context": g["ctx"], "fps": 16, "timestep_cond": g["tc"]}
+    score_ref, out_ref = mp.get_motion_prior_score(m, latents.clone(), g["ts"], example, ctx, ctx, 500.0)
+    eng = UNetGradEngine(m, EmuOps())
+    score, out = mp.get_motion_prior_score_native(eng, m, latents.clone(), g["ts"], example, ctx, ctx, 500.0)
+    assert rel_l2(out, out_ref.detach()) < 2e-5
+    assert float(score_ref.abs().max()) > 0
+    assert rel_l2(score, score_ref) < 1e-4
