@@ -6,7 +6,7 @@
 # usage: gpurun --timeout 400 -- bash tools/round2_first_call.sh
 set -u
 mkdir -p gpurun_out
-hipcc --offload-arch=gfx950 -O3 tools/fill_rate.hip -o /tmp/fill_rate && timeout 60 /tmp/fill_rate 16 2000 | tee gpurun_out/fill_rate.txt
+hipcc --offload-arch=gfx950 -O3 tools/fill_rate.hip -o /tmp/fill_rate && (timeout 60 /tmp/fill_rate 16 2000; timeout 60 /tmp/fill_rate 16 2000 64) | tee gpurun_out/fill_rate.txt
 T2V_TEST_EXPERIMENTAL_TILES=1 timeout 240 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=line -p no:cacheprovider \
     -k "linear_tiles or conv_modes or geglu_all" 2>&1 | tail -15 | tee gpurun_out/experimental_tiles.txt
 # 2b. the UNet data-gradient kernels (LayerNorm / GEGLU / temporal-attention backward, two-part GroupNorm backward ...) and the
