@@ -110,6 +110,10 @@ int main(int argc, char** argv) {
     const long long window = (argc > 1 ? atoll(argv[1]) : 16) << 20;  // MiB; 16 MiB: half the aggregate L2, all of it in the Infinity Cache
     const int iters = argc > 2 ? atoi(argv[2]) : 4000;
     const long long span = (argc > 3 ? atoll(argv[3]) : 0) << 10;  // KiB per workgroup (multiple of 16), 0 = sweep the whole window
+    if (span < 0 || span > (1 << 20) || span % 16384 != 0 || window % 16384 != 0) {
+        fprintf(stderr, "span must be a multiple of 16 KiB, at most 1024 KiB (the slack behind the window)\n");
+        return 2;
+    }
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
