@@ -883,6 +883,28 @@ int launch_impl(GemmParams& p, hipStream_t s) {
     return T2V_OK;
 }
 
+}  // namespace
+
+// The compile-verified tile ids (24+) are instantiated in their own translation unit (gemm_exp.hip = this file with
+// T2V_GEMM_EXP_ONLY): what the compiler emits for an instantiation depends on what else the unit holds (with all ids in one
+// unit the 256x128 / 4-waves-per-SIMD kernel picked up a scratch reload inside its K loop), and the validated ids' code
+// should be exactly what ran on hardware.
+int t2v_gemm_launch_experimental(int cfg, GemmParams& p, hipStream_t s);
+#ifdef T2V_GEMM_EXP_ONLY
+int t2v_gemm_launch_experimental(int cfg, GemmParams& p, hipStream_t s) {
+    switch (cfg) {
+        case 24: return launch<256, 256, 2, 2, 3, 32, 1>(p, s);
+        case 25: return launch<256, 128, 4, 2, 2, 64, 2, true>(p, s);
+        case 26: return launch<128, 128, 2, 2, 2, 64, 2, true>(p, s);
+        case 27: return launch<256, 256, 2, 4, 2, 32, 2, true>(p, s);
+        case 28: return launch<160, 320, 5, 2, 2, 32, 3, true>(p, s);
+        case 29: return launch<128, 256, 1, 4, 2, 32, 2, true>(p, s);
+        default: return T2V_EINVAL;
+    }
+}
+#else
+
+namespace {
 struct TileCfg { int bm, bn, wtn, bk = 64; };
 // id -> (BM, BN, per-wave N width); waves / stages: see dispatch()
 const TileCfg kCfg[] = {{0, 0, 0},      {128, 128, 64}, {128, 64, 32},  {256, 64, 64}, {128, 128, 64},
@@ -935,12 +957,7 @@ int dispatch(int cfg, GemmParams& p, hipStream_t s) {
         case 21: return launch<256, 256, 4, 2, 4, 32, 2>(p, s);
         case 22: return launch<160, 320, 5, 2, 2, 64, 3>(p, s);
         case 23: return launch<160, 320, 5, 2, 3, 32, 3>(p, s);
-        case 24: return launch<256, 256, 2, 2, 3, 32, 1>(p, s);
-        case 25: return launch<256, 128, 4, 2, 2, 64, 2, true>(p, s);
-        case 26: return launch<128, 128, 2, 2, 2, 64, 2, true>(p, s);
-        case 27: return launch<256, 256, 2, 4, 2, 32, 2, true>(p, s);
-        case 28: return launch<160, 320, 5, 2, 2, 32, 3, true>(p, s);
-        case 29: return launch<128, 256, 1, 4, 2, 32, 2, true>(p, s);
+        case 24: case 25: case 26: case 27: case 28: case 29: return t2v_gemm_launch_experimental(cfg, p, s);
         default: return T2V_EINVAL;
     }
 }
@@ -1043,3 +1060,4 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     p.debug = g_debug;
     return dispatch(cfg, p, s);
 }
+#endif  // T2V_GEMM_EXP_ONLY
