@@ -95,3 +95,25 @@ def test_motion_prior_score_on_the_gradient_engine():
     assert rel_l2(out, out_ref.detach()) < 2e-5
     assert float(score_ref.abs().max()) > 0
     assert rel_l2(score, score_ref) < 1e-4
+
+
+def test_gradients_match_the_reference_fixture():
+    """tests/golden/unet_tiny_grad.npz holds autograd gradients computed by the REFERENCE UNetModel and the reference's own
+    ``compute_temp_loss`` (tests/golden/make_golden_grad.py): the engine must reproduce both."""
+    from t2v_turbo_amd import motion_prior as mp
+    g, gg = load("unet_tiny"), load("unet_tiny_grad")
+    m = UNetModel(**tiny_unet_params(record_attn_probs=True)).eval()
+    m.load_state_dict(synth_state_dict(manifest("unet_tiny")), strict=True)
+    m.requires_grad_(False)
+    m.native_mode = "off"
+    eng = UNetGradEngine(m, EmuOps())
+    y = eng.forward_tape(g["x"], g["ts"], g["ctx"], 16, g["tc"], None)
+    assert rel_l2(y, gg["out"]) < 2e-5
+    assert rel_l2(eng.backward(gg["r_out"]), gg["dx_out"]) < 1e-4
+    ctx = {"context": g["ctx"], "fps": 16, "timestep_cond": g["tc"]}
+    score, out = mp.get_motion_prior_score_native(eng, m, g["x"].clone(), g["ts"], gg["example"], ctx, ctx, 500.0)
+    assert rel_l2(out, gg["out"]) < 2e-5
+    assert rel_l2(score, gg["score"]) < 1e-4
+    # and the module's own autograd path (what runs today on the GPU) against the same fixture
+    score_t, _ = mp.get_motion_prior_score(m, g["x"].clone(), g["ts"], gg["example"], ctx, ctx, 500.0)
+    assert rel_l2(score_t, gg["score"]) < 1e-4
