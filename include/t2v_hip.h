@@ -249,6 +249,16 @@ int t2v_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
 int t2v_ema_update(float* target, const float* src, float rate, long long n, void* stream);
 int t2v_sumsq(const float* x, long long n, float* ws, float* out, void* stream);
 
+/* ---------------------------------------------------------------- LoRA training path (utils/lora.py:45-50,124-129,204-209)
+ * t2v_gather_f32: indexed re-layout of fp32 data.  accumulate = 0: out[i] = idx[i] >= 0 ? alpha*src[idx[i]] : 0;
+ * accumulate = 1: out[i] += alpha*src[idx[i]] where idx[i] >= 0.  out is fp32 (T2V_F32) or bf16 (T2V_BF16).
+ * One launch packs every lora_down / lora_up tensor (flat fp32 parameters) into the bf16 GEMM operand layouts, and one
+ * launch scatters every LoRA weight gradient from the GEMM output layout into the flat gradient buffer the
+ * all-reduce and the optimizer work on (what autograd's AccumulateGrad does per tensor in the reference,
+ * train_t2v_turbo_v1_lora.py:1190). */
+int t2v_gather_f32(const float* src, const int* idx, float alpha, void* out, int dt_out, int accumulate, long long n,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -82,12 +82,20 @@ class Act:
 
 
 # =================================================================================== weights
-def effective_weight_bias(mod):
+def is_lora_leaf(mod):
+    base = getattr(mod, "linear", None) or getattr(mod, "conv", None)
+    return base is not None and hasattr(mod, "lora_up") and hasattr(mod, "lora_down")
+
+
+def effective_weight_bias(mod, merge=True):
     """(weight, bias) of a Linear/Conv leaf; LoRA-injected leaves (utils/lora.py:19-230 layout:
     .linear|.conv, .lora_down, .lora_up, .scale[, .selector]) are merged on the fly:
-    W + scale * up @ diag(sel) @ down — what ``collapse_lora`` (utils/lora.py:793-830) would bake in."""
+    W + scale * up @ diag(sel) @ down — what ``collapse_lora`` (utils/lora.py:793-830) would bake in.
+    ``merge=False`` (the training engine, which runs the LoRA branch as its own GEMMs): the frozen base only."""
     base = getattr(mod, "linear", None) or getattr(mod, "conv", None)
     if base is not None and hasattr(mod, "lora_up") and hasattr(mod, "lora_down"):
+        if not merge:
+            return base.weight.detach(), base.bias
         w = base.weight.detach().float()
         up = mod.lora_up.weight.detach().float().flatten(1)
         down = mod.lora_down.weight.detach().float().flatten(1)
@@ -106,9 +114,13 @@ def leaf_out_channels(mod):
 class Packer:
     """Packs leaf parameters into kernel layouts; cached until any parameter changes."""
 
-    def __init__(self, wdtype, device):
+    def __init__(self, wdtype, device, merge_lora=True):
         self.wdtype, self.device = wdtype, device
+        self.merge_lora = merge_lora
         self.cache = {}
+
+    def wb(self, mod):
+        return effective_weight_bias(mod, self.merge_lora)
 
     def _memo(self, key, fn):
         if key not in self.cache:
@@ -119,20 +131,20 @@ class Packer:
         return None if p is None else self._memo(("f32", id(p)), lambda: p.detach().to(self.device, torch.float32).contiguous())
 
     def bias(self, mod):
-        b = effective_weight_bias(mod)[1]
+        b = self.wb(mod)[1]
         return None if b is None else self._memo(("bias", id(mod)), lambda: b.detach().to(self.device, torch.float32).contiguous())
 
     def mat(self, mod):
         """[N, K] row-major weight of a Linear / 1x1 conv / k=1 Conv1d."""
         def make():
-            w = effective_weight_bias(mod)[0]
+            w = self.wb(mod)[0]
             return w.reshape(w.shape[0], -1).to(self.device, self.wdtype).contiguous()
         return self._memo(("mat", id(mod)), make)
 
     def conv(self, mod):
         """[N, taps*Cin], tap-major: Conv2d [N,C,3,3] -> (ky,kx,c); Conv3d [N,C,3,1,1] -> (kt,c)."""
         def make():
-            w = effective_weight_bias(mod)[0]
+            w = self.wb(mod)[0]
             if w.dim() == 5:
                 w = w[:, :, :, 0, 0].permute(0, 2, 1)
             else:
@@ -143,14 +155,14 @@ class Packer:
     def mat_t(self, mod):
         """[K, N]^T pack of a Linear / 1x1 conv: the weight of its data gradient (dx = dy @ W)."""
         def make():
-            w = effective_weight_bias(mod)[0]
+            w = self.wb(mod)[0]
             return w.reshape(w.shape[0], -1).t().to(self.device, self.wdtype).contiguous()
         return self._memo(("mat_t", id(mod)), make)
 
     def conv_dgrad(self, mod):
         """3x3 conv data gradient as a 3x3 conv over dy: w'[ci][(ky',kx'), co] = w[co][ci][2-ky'][2-kx']."""
         def make():
-            w = effective_weight_bias(mod)[0]          # [co, ci, 3, 3]
+            w = self.wb(mod)[0]          # [co, ci, 3, 3]
             wd = w.flip(2, 3).permute(1, 2, 3, 0)      # [ci, ky', kx', co]
             return wd.reshape(wd.shape[0], -1).to(self.device, self.wdtype).contiguous()
         return self._memo(("conv_dgrad", id(mod)), make)
@@ -159,7 +171,7 @@ class Packer:
         """fp32 [cout'][9][cin'] pack for the direct small-channel conv computing the data gradient of ``mod``:
         cout' = mod's input channels (optionally zero-padded rows), cin' = mod's output channels padded to cin_pad."""
         def make():
-            w = effective_weight_bias(mod)[0].float()  # [co, ci, 3, 3]
+            w = self.wb(mod)[0].float()  # [co, ci, 3, 3]
             wd = w.flip(2, 3).permute(1, 2, 3, 0)      # [ci, ky', kx', co]
             if cin_pad > wd.shape[-1]:
                 wd = torch.nn.functional.pad(wd, (0, cin_pad - wd.shape[-1]))
@@ -175,7 +187,7 @@ class Packer:
     def geglu(self, proj):
         """GEGLU projection packed in 64-row groups [32 value rows | 32 gate rows] (T2V_ACT_GEGLU)."""
         def make():
-            w, b = effective_weight_bias(proj)
+            w, b = self.wb(proj)
             inner = w.shape[0] // 2
             assert inner % 32 == 0
             wv, wg = w[:inner].reshape(inner // 32, 32, -1), w[inner:].reshape(inner // 32, 32, -1)
@@ -187,16 +199,18 @@ class Packer:
     def small_conv(self, mod, cin_pad=None):
         """fp32 [cout][9][cin] for the direct small-Cin conv."""
         def make():
-            w = effective_weight_bias(mod)[0].float().permute(0, 2, 3, 1)  # N,3,3,C
+            w = self.wb(mod)[0].float().permute(0, 2, 3, 1)  # N,3,3,C
             if cin_pad and cin_pad > w.shape[-1]:
                 w = torch.nn.functional.pad(w, (0, cin_pad - w.shape[-1]))
             return w.reshape(w.shape[0], -1).to(self.device).contiguous()
         return self._memo(("small", id(mod), cin_pad), make)
 
 
-def params_fingerprint(module):
+def params_fingerprint(module, skip=()):
     fp = 0
     for p in module.parameters():
+        if id(p) in skip:
+            continue
         fp = (fp * 1000003 + p._version + (p.data_ptr() & 0xFFFFFFF)) & 0xFFFFFFFFFFFF
     return fp
 
@@ -259,8 +273,8 @@ class _Engine:
         return Act(out, x.n_img, ho, wo)
 
     # ---- plan management --------------------------------------------------------------------------------
-    def _check_weights(self, module):
-        fp = params_fingerprint(module)
+    def _check_weights(self, module, skip=()):
+        fp = params_fingerprint(module, skip)
         if fp != self.fingerprint:
             self.plans.clear()
             self.fingerprint = fp

@@ -1,0 +1,330 @@
+"""LoRA branch and LoRA weight gradients of the student UNet on the native engine (the trainable part of the v1
+distillation step: ``utils/lora.py:45-50,124-129,204-209`` forward, ``train_t2v_turbo_v1_lora.py:1190`` backward).
+
+For an injected leaf  y = x (*) W + s * ((x (*) D) U^T)  with rank r (D = ``lora_down``, U = ``lora_up``, s = ``scale``,
+(*) the leaf's gather: linear, 3x3 / strided / upsampled conv, (3,1,1) temporal conv) the engine runs
+
+  forward    t = x (*) D            [M, rp]      same implicit-GEMM mode as the base leaf, N = rp (rank padded to 64)
+             z = s t U^T (+ res)    [M, N]       K = rp
+             y = x (*) W + z                      the frozen base leaf with z as its residual operand
+  backward   dU = s dy^T t                        K = tokens: both operands transposed to K-contiguous bf16, split-K
+             g  = s dy U             [M, rp]
+             dx = adjoint(dy; W) + adjoint(g; D)  second term chained in as the residual of the first
+             dD[r, tap, c] = sum_m G[m, tap, r] x[m, c],   G = adjoint(g; selection)   (the im2col matrix is never built:
+                                                  the rank-r gradient is gathered to the INPUT grid instead — 9 rp columns
+                                                  where im2col would have 9 Cin)
+
+The frozen base weights are packed once.  The LoRA tensors change every optimizer step, so their operand layouts
+(D forward / D data-gradient / U / U^T, bf16, zero-padded to rank 64) are re-laid from ONE flat fp32 copy of the trainable
+parameters by ONE indexed-gather launch per step (``t2v_gather_f32``); one more gather carries every weight gradient from the
+GEMM output layout into the flat gradient buffer (``dist.FlatGradSync``) that the all-reduce and ``optim.FlatAdamW`` work
+on.  Leaves of the conditioning branch (time / fps / guidance MLPs, ``emb_layers``: M = B rows) stay in torch autograd; the
+engine hands back d(loss)/d(emb_all), column sums of the ResBlock gradients taken as one more GEMM against a clip-indicator
+row.  Dropout on the LoRA branch / temporal convs is not applied (the engine requires ``.eval()``): DESIGN.md §0.
+
+Status: dataflow verified on CPU against torch autograd (tests/test_unet_lora_grad_cpu.py); not yet run on hardware."""
+import torch
+import torch.nn as nn
+
+from . import native as nt
+from .engine import Act, is_lora_leaf
+
+RP = 64  # rank granularity: K of a GEMM is a multiple of 64
+
+
+def _pad(n, m):
+    return (n + m - 1) // m * m
+
+
+def _pad_to(t, shape):
+    """int64 index tensor zero^H^H^H^H -1-padded up to ``shape`` (trailing side of every dim)."""
+    out = torch.full(shape, -1, dtype=torch.int64)
+    out[tuple(slice(0, s) for s in t.shape)] = t
+    return out
+
+
+class LoraGroup:
+    """1..n injected leaves reading the same input through the same gather mode (q/k/v of an attention = one group)."""
+    saved = None
+
+
+class LoraTrainMixin:
+    lora_params = None
+
+    # ---- binding ------------------------------------------------------------------------------------------------------
+    def bind_lora(self, params):
+        """``params``: the trainable LoRA tensors in flat-buffer order (``lora.lora_parameters(model)``)."""
+        self.lora_params = list(params)
+        self.lora_off, off = {}, 0
+        for p in self.lora_params:
+            self.lora_off[id(p)] = off
+            off += p.numel()
+        self.lora_numel = off
+        self.lora_ids = set(self.lora_off)
+        self.plans.clear()
+        self.fingerprint = None
+
+    @property
+    def training_lora(self):
+        return self.lora_params is not None
+
+    def engine_leaves(self):
+        """Injected leaves whose gradients the engine computes (token-row leaves; the B-row conditioning branch is torch's)."""
+        m = self.model
+        cond = set()
+        for name in ("time_embed", "fps_embedding", "time_cond_proj", "motion_cond_proj", "combine_proj"):
+            sub = getattr(m, name, None)
+            if sub is not None:
+                cond.update(id(x) for x in sub.modules())
+        from .unet3d import ResBlock
+        for mod in m.modules():
+            if isinstance(mod, ResBlock):
+                cond.update(id(x) for x in mod.emb_layers.modules())
+        return [mod for mod in m.modules() if is_lora_leaf(mod) and id(mod) not in cond]
+
+    def conditioning_parameters(self):
+        mine = {id(p) for mod in self.engine_leaves() for p in (mod.lora_up.weight, mod.lora_down.weight)}
+        return [p for p in self.lora_params if id(p) not in mine]
+
+    # ---- arenas -------------------------------------------------------------------------------------------------------
+    def _lora_begin(self):
+        dev = self.device
+        n_lp = n_e = 0
+        for mod in self.engine_leaves():
+            down, up = mod.lora_down.weight, mod.lora_up.weight
+            if id(down) not in self.lora_off or id(up) not in self.lora_off:
+                raise ValueError("a LoRA leaf's tensors are not in the list given to bind_lora")
+            if not isinstance(mod.selector, nn.Identity):
+                raise NotImplementedError("native LoRA training: a selector is set on an injected leaf")
+            r, cin, n_out = down.shape[0], down.shape[1], up.shape[0]
+            taps = down.numel() // (r * cin)
+            rp, ce, npad = _pad(r, RP), _pad(cin, 64), _pad(n_out, 64)
+            n_lp += 2 * rp * taps * ce + n_out * rp + rp * npad
+            n_e += n_out * rp + taps * rp * ce
+        self.lp = torch.zeros(n_lp, dtype=self.adt, device=dev)
+        self.lp_idx = torch.full((n_lp,), -1, dtype=torch.int32, device=dev)
+        self.lp_used = 0
+        self.E = torch.zeros(n_e, dtype=torch.float32, device=dev)
+        self.e_used = 0
+        self.g_idx = torch.full((self.lora_numel,), -1, dtype=torch.int32, device=dev)
+        self.src_flat = torch.empty(self.lora_numel + 1, dtype=torch.float32, device=dev)
+        self.one_idx = self.lora_numel  # src_flat[-1] == 1: constant entries of an operand (none today) can index it
+        self._groups = {}
+        self._refresh_src()
+
+    def _refresh_src(self):
+        ps = self.lora_params
+        with torch.no_grad():
+            first = ps[0]
+            flat = None
+            # optim.FlatAdamW re-homes the parameters as consecutive views of one buffer: take it as it is
+            if all(p.is_contiguous() for p in ps) and first.dtype == torch.float32 and first.device == self.src_flat.device:
+                base, ok = first.data_ptr(), True
+                for p in ps:
+                    if p.data_ptr() != base + 4 * self.lora_off[id(p)] or p.dtype != torch.float32:
+                        ok = False
+                        break
+                if ok and first.untyped_storage().nbytes() - (first.storage_offset() * 4) >= 4 * self.lora_numel:
+                    flat = torch.as_strided(first.detach(), (self.lora_numel,), (1,), first.storage_offset())
+            if flat is not None:
+                self.src_flat[:-1].copy_(flat)
+            else:
+                torch.cat([p.detach().reshape(-1).to(self.src_flat.device, torch.float32) for p in ps], out=self.src_flat[:-1])
+            self.src_flat[-1] = 1.0
+
+    def refresh_lora_packs(self):
+        """Per step: flat parameters -> every bf16 operand layout, one launch."""
+        self._refresh_src()
+        if self.lp_used:
+            self.ops.gather(self.src_flat, self.lp_idx[:self.lp_used], self.lp[:self.lp_used])
+
+    def _lp_alloc(self, idx2d):
+        """Operand pack in the arena: records its gather indices and fills it (record time only: torch indexing)."""
+        n = idx2d.numel()
+        a = self.lp_used
+        assert a + n <= self.lp.numel(), "LoRA pack arena overflow"
+        self.lp_used = a + _pad(n, 8)
+        di = idx2d.reshape(-1).to(self.device)
+        self.lp_idx[a:a + n] = di.to(torch.int32)
+        vals = torch.where(di >= 0, self.src_flat[di.clamp_min(0)], torch.zeros((), device=self.device))
+        self.lp[a:a + n] = vals.to(self.adt)
+        return self.lp[a:a + n].view(idx2d.shape)
+
+    def _e_alloc(self, rows, cols):
+        a = self.e_used
+        assert a + rows * cols <= self.E.numel(), "LoRA gradient arena overflow"
+        self.e_used = a + rows * cols
+        return a, self.E[a:a + rows * cols].view(rows, cols)
+
+    def sel_pack(self, taps, rp):
+        """Selection weights of the gathered rank-r gradient: out[m, tap*rp + r] = g[m - offset(tap), r]  (tap flipped)."""
+        def make():
+            w = torch.zeros(taps, rp, taps, rp)
+            for tap in range(taps):
+                w[tap, :, taps - 1 - tap, :] = torch.eye(rp)
+            return w.reshape(taps * rp, taps * rp).to(self.device, self.adt).contiguous()
+        return self.pk._memo(("lora_sel", taps, rp), make)
+
+    def clip_indicator(self, m_rows):
+        """[B, Mp] bf16, 1 on the rows of clip b: A operand of the column-sum GEMM (d loss / d emb_all)."""
+        def make():
+            B = self.B
+            mp = _pad(m_rows, 64)
+            ind = torch.zeros(B, mp)
+            per = m_rows // B
+            for b in range(B):
+                ind[b, b * per:(b + 1) * per] = 1
+            return ind.to(self.device, self.adt).contiguous()
+        return self.pk._memo(("clip_ind", m_rows, self.B), make)
+
+    # ---- groups -------------------------------------------------------------------------------------------------------
+    def lgroup(self, mods, mode, perm=None):
+        key = (mode,) + tuple(id(m) for m in mods)
+        g = self._groups.get(key)
+        if g is not None:
+            return g
+        taps = {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(mode, 9)
+        assert taps == 1 or len(mods) == 1
+        g = LoraGroup()
+        g.mods, g.mode, g.taps, g.n = mods, mode, taps, len(mods)
+        g.N, g.npad, g.scale, g.Uf, g.UT, g.EU = [], [], [], [], [], []
+        df_rows, db_cols = [], []
+        r0 = mods[0].lora_down.weight.shape[0]
+        g.rp = rp = _pad(r0, RP)
+        g.cin = cin = mods[0].lora_down.weight.shape[1]
+        g.ce = ce = _pad(cin, 64)
+        e_d_off, g.ED = self._e_alloc((g.n if taps == 1 else taps) * rp, ce)
+        for i, mod in enumerate(mods):
+            down, up = mod.lora_down.weight, mod.lora_up.weight
+            r, n_out = down.shape[0], up.shape[0]
+            assert _pad(r, RP) == rp and down.shape[1] == cin
+            idx_d = self.lora_off[id(down)] + torch.arange(down.numel()).view(down.shape)
+            if taps == 9:
+                t = idx_d.permute(0, 2, 3, 1).reshape(r, 9, cin)
+            elif taps == 3:
+                t = idx_d[:, :, :, 0, 0].permute(0, 2, 1)
+            else:
+                t = idx_d.reshape(r, 1, cin)
+            t = _pad_to(t, (rp, taps, ce))
+            df_rows.append(t.reshape(rp, taps * ce))
+            db_cols.append(t.flip(1).permute(2, 1, 0).reshape(ce, taps * rp))   # [c][(tap', r)] = D[r][c][flipped tap']
+            idx_u = self.lora_off[id(up)] + torch.arange(up.numel()).view(n_out, r)
+            if perm is not None:
+                idx_u = idx_u[perm]                                              # packed row j <- original row perm[j]
+            uf = _pad_to(idx_u, (n_out, rp))
+            npad = _pad(n_out, 64)
+            g.Uf.append(self._lp_alloc(uf))
+            g.UT.append(self._lp_alloc(_pad_to(uf.t(), (rp, npad))))
+            g.N.append(n_out)
+            g.npad.append(npad)
+            g.scale.append(float(mod.scale))
+            # where each parameter element's gradient lands in the E arena
+            e_u_off, eu = self._e_alloc(n_out, rp)
+            g.EU.append(eu)
+            e = e_u_off + torch.arange(n_out * rp).view(n_out, rp)[:, :r]
+            if perm is not None:
+                full = torch.empty_like(e)
+                full[perm] = e
+                e = full
+            o = self.lora_off[id(up)]
+            self.g_idx[o:o + up.numel()] = e.reshape(-1).to(self.device, torch.int32)
+            if taps == 1:
+                e = e_d_off + torch.arange(g.n * rp * ce).view(g.n, rp, ce)[i, :r, :cin]
+            else:
+                e = e_d_off + torch.arange(taps * rp * ce).view(taps, rp, ce)[:, :r, :cin].permute(1, 2, 0)
+            o = self.lora_off[id(down)]
+            self.g_idx[o:o + down.numel()] = e.reshape(-1).to(self.device, torch.int32)
+        g.Df = self._lp_alloc(torch.cat(df_rows, dim=0))
+        g.Db = self._lp_alloc(torch.cat(db_cols, dim=1))
+        g.ntot = sum(g.N)
+        self._groups[key] = g
+        return g
+
+    def saved_group(self, mods, mode):
+        if not self.training_lora or mods is None:
+            return None
+        g = self._groups.get((mode,) + tuple(id(m) for m in mods))
+        return g if g is not None and g.saved is not None else None
+
+    # ---- forward: z = residual + sum_i s_i (x (*) D_i) U_i^T ----------------------------------------------------------------
+    def lora_z(self, grp, x, m_out, residual=None, frames=0):
+        """x: Act (1 or 2 parts, channels padded to the group's ce).  Returns (z buffer to release, z view [m_out, sum N])."""
+        ops = self.ops
+        nrp = grp.n * grp.rp
+        t = self.buf(m_out, nrp)
+        if grp.mode == nt.GEMM_LINEAR:
+            ops.gemm(x.parts[0], grp.Df, t, M=m_out, N=nrp, a1=x.p1)
+        else:
+            ops.gemm(x.parts[0], grp.Df, t, M=m_out, N=nrp, a1=x.p1, mode=grp.mode, n_img=x.n_img, h=x.h, wd=x.w, frames=frames)
+        zf = self.buf(m_out, _pad(grp.ntot, 8))
+        z = zf[:, :grp.ntot]
+        c0 = 0
+        for i in range(grp.n):
+            res = None if residual is None else residual[:, c0:c0 + grp.N[i]]
+            ops.gemm(t[:, i * grp.rp:(i + 1) * grp.rp], grp.Uf[i], z[:, c0:c0 + grp.N[i]], M=m_out, N=grp.N[i],
+                     alpha=grp.scale[i], residual=res)
+            c0 += grp.N[i]
+        self.hold(*x.parts)
+        grp.saved = (x, t)
+        return zf, z
+
+    # ---- backward ---------------------------------------------------------------------------------------------------------
+    def tposed(self, src, rows, cols, batch=1, in_stride=0):
+        """[batch][rows][cols] -> [batch][cols][rows padded to 64 with zeros] (K-contiguous GEMM operand)."""
+        rp = _pad(rows, 64)
+        dst = self.buf(batch * cols, rp)
+        if rp != rows:
+            self.ops.fill_zero(dst)
+        self.ops.transpose(src, rows, cols, dst, batch=batch, in_stride=in_stride, out_stride=cols * rp)
+        return dst
+
+    @staticmethod
+    def split_for(m, n, k):
+        """Split-K factor of a weight-gradient GEMM: a handful of output tiles, K = tokens."""
+        tiles = ((m + 127) // 128) * ((n + 127) // 128)
+        return max(1, min(448 // tiles, k // 512, 64))
+
+    def lora_wgrad(self, grp, dy, colsum=None):
+        """dU of every leaf of the group (+ optional per-clip column sums of dy) and g = s dy U.  dy: [M, sum npad]."""
+        ops = self.ops
+        x, t = grp.saved
+        m = dy.shape[0]
+        mp = _pad(m, 64)
+        dyT = self.tposed(dy, m, dy.shape[1])
+        tT = self.tposed(t, m, t.shape[1])
+        g = self.buf(m, grp.n * grp.rp)
+        c0 = 0
+        for i in range(grp.n):
+            n_out, rp = grp.N[i], grp.rp
+            ops.gemm(dyT[c0:c0 + n_out], tT[i * rp:(i + 1) * rp], grp.EU[i], M=n_out, N=rp, alpha=grp.scale[i],
+                     split_k=self.split_for(n_out, rp, mp))
+            ops.gemm(dy[:, c0:c0 + grp.npad[i]], grp.UT[i], g[:, i * rp:(i + 1) * rp], M=m, N=rp, alpha=grp.scale[i])
+            c0 += grp.npad[i]
+        if colsum is not None:
+            ind = self.clip_indicator(m)
+            ops.gemm(ind, dyT[:grp.N[0]], colsum, M=ind.shape[0], N=grp.N[0], split_k=self.split_for(ind.shape[0], grp.N[0], mp))
+        self.pool.put(dyT, tT, t)
+        return g
+
+    def lora_wgrad_down(self, grp, G):
+        """dD from the rank-r gradient gathered to the input grid: G [M_in, rows of ED] against the saved input."""
+        ops = self.ops
+        x, _ = grp.saved
+        m_in = x.M
+        mp = _pad(m_in, 64)
+        GT = self.tposed(G, m_in, G.shape[1])
+        c0 = 0
+        for part in x.parts:
+            c = part.shape[1]
+            xT = self.tposed(part, m_in, c)
+            ops.gemm(GT, xT, grp.ED[:, c0:c0 + c], M=GT.shape[0], N=c, split_k=self.split_for(GT.shape[0], c, mp))
+            self.pool.put(xT)
+            c0 += c
+        self.pool.put(GT)
+        self.drop(*x.parts)
+        grp.saved = None
+
+    def lora_grads_into(self, flat_grad, accumulate=True):
+        """E arena -> flat gradient buffer in parameter layout (one launch).  Conditioning-branch tensors are not touched
+        when accumulating (their gradient comes from torch), and zeroed otherwise."""
+        self.ops.gather(self.E, self.g_idx, flat_grad, accumulate=accumulate)

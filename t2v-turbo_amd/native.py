@@ -107,6 +107,7 @@ _SIGS = {
                                  C.c_float, C.c_float, C.c_float, C.c_int, C.c_float, C.c_void_p]),
     "t2v_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_longlong, C.c_void_p]),
     "t2v_sumsq": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "t2v_gather_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p]),
     "t2v_lcm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -369,6 +370,11 @@ class HipOps:
 
     def sumsq(self, x, ws, out):
         self._call("t2v_sumsq", _p(x), x.numel(), _p(ws), _p(out))
+
+    def gather(self, src, idx, out, alpha=1.0, accumulate=False):
+        """out.flat[i] = alpha * src.flat[idx[i]] (0 where idx < 0), or += with ``accumulate``; src fp32, idx int32."""
+        assert src.dtype == torch.float32 and idx.dtype == torch.int32 and idx.numel() == out.numel()
+        self._call("t2v_gather_f32", _p(src), _p(idx), alpha, _p(out), _DT[out.dtype], 1 if accumulate else 0, out.numel())
 
     def lcm_step(self, x, eps, noise, sa_t, sb_t, c_skip, c_out, sa_p, sb_p, prev, denoised):
         self._call("t2v_lcm_step", _p(x), _p(eps), _DT[eps.dtype], _p(noise), sa_t, sb_t, c_skip, c_out, sa_p, sb_p,

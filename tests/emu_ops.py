@@ -35,8 +35,13 @@ class EmuOps:
     # ------------------------------------------------------------------------------------ gemm
     def gemm(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
              rowvec=None, rowvec_div=0, residual=None, act=nt.ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
-             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0)):
+             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0):
         self._log("gemm")
+        # device-side argument rules (csrc/gemm.hip, t2v_gemm): operand row strides, batch strides and base addresses
+        assert a0.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and (a1 is None or a1.stride(0) % 8 == 0), "lda/ldw % 8"
+        assert all(v % 8 == 0 for v in tuple(a_strides) + tuple(w_strides)), "batch strides % 8"
+        assert a0.storage_offset() % 8 == 0 and w.storage_offset() % 8 == 0, "operand base must be 16-byte aligned"
+        assert residual is None or residual.dtype == self.act_dtype, "residual is an activation-dtype tensor"
         c0 = a0.shape[1]
         c1 = 0 if a1 is None else a1.shape[1]
         cin = c0 + c1
@@ -339,6 +344,18 @@ class EmuOps:
         if z is not None:
             v = v + torch.tensor(cc).reshape(shp) * z
         out.copy_(v)
+
+    def gather(self, src, idx, out, alpha=1.0, accumulate=False):
+        self._log("gather")
+        assert src.dtype == torch.float32 and idx.dtype == torch.int32 and idx.numel() == out.numel()
+        assert out.is_contiguous() and src.is_contiguous()
+        j = idx.long()
+        v = torch.where(j >= 0, src.reshape(-1)[j.clamp_min(0)] * alpha, torch.zeros((), dtype=torch.float32))
+        o = out.view(-1)
+        if accumulate:
+            o.copy_(torch.where(j >= 0, o.float() + v, o.float()).to(out.dtype))
+        else:
+            o.copy_(v.to(out.dtype))
 
     def lcm_step(self, x, eps, noise, sa_t, sb_t, c_skip, c_out, sa_p, sb_p, prev, denoised):
         self._log("lcm_step")
