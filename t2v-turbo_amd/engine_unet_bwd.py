@@ -27,25 +27,29 @@ import torch
 import torch.nn as nn
 
 from . import native as nt
-from .engine import Act, UNetEngine, effective_weight_bias, leaf_out_channels
+from .engine import Act, Packer, UNetEngine, effective_weight_bias, is_lora_leaf, leaf_out_channels
+from .engine_lora import LoraTrainMixin, _pad
 from .unet3d import Downsample, ResBlock, SpatialTransformer, TemporalTransformer, TimestepEmbedSequential, Upsample
 
 
-class UNetGradEngine(UNetEngine):
+class UNetGradEngine(LoraTrainMixin, UNetEngine):
     # ---- public: forward with tape, then backward ----------------------------------------------------------------
-    def forward_tape(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None):
+    def forward_tape(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None, emb_all=None):
+        """``emb_all`` (LoRA training only): the conditioning branch's output [B, sum of ResBlock widths] fp32, computed by
+        the caller in torch (``conditioning_torch``) so that autograd owns that branch's 27 tiny leaves."""
         m = self.model
         assert x.dim() == 5 and context is not None
-        self._check_weights(m)
+        assert (emb_all is not None) == self.training_lora, "emb_all is given exactly when LoRA tensors are bound"
+        self._check_weights(m, self.lora_ids if self.training_lora else ())
         for mod in m.modules():
             if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training:
                 raise RuntimeError("native UNet gradient path: a Dropout(p>0) is in training mode; call .eval() first")
         key = ("grad", tuple(x.shape), x.dtype, tuple(context.shape), context.dtype, isinstance(fps, int),
                None if timestep_cond is None else tuple(timestep_cond.shape),
-               None if motion_cond is None else tuple(motion_cond.shape), x.device)
+               None if motion_cond is None else tuple(motion_cond.shape), x.device, self.training_lora)
         plan = self.plans.get(key)
         if plan is None:
-            plan = self._record_grad(x, timesteps, context, fps, timestep_cond, motion_cond)
+            plan = self._record_grad(x, timesteps, context, fps, timestep_cond, motion_cond, emb_all)
             self.plans[key] = plan
             if getattr(self.ops, "is_native", False):
                 self._replay(plan, "rec")  # recording ran the backward once and recycled the saved buffers
@@ -60,15 +64,20 @@ class UNetGradEngine(UNetEngine):
                 st["tc"].copy_(timestep_cond)
             if motion_cond is not None:
                 st["mc"].copy_(motion_cond)
+            if emb_all is not None:
+                st["emb_all"].copy_(emb_all.detach())
+                self.refresh_lora_packs()
             self._replay(plan, "rec")
         plan["fwd_id"] = plan.get("fwd_id", 0) + 1
         self._last = plan
         self._publish_probs(plan)
         return plan["out"].clone()
 
-    def backward(self, dout=None, dprobs=None):
+    def backward(self, dout=None, dprobs=None, flat_grad=None, accumulate=True):
         """d(loss)/dx for the most recent ``forward_tape``.  ``dout``: gradient w.r.t. the output (or None = 0);
-        ``dprobs``: {attention module: gradient w.r.t. its ``attention_probs``} for any of the recorded layers."""
+        ``dprobs``: {attention module: gradient w.r.t. its ``attention_probs``} for any of the recorded layers.
+        LoRA training: the weight gradients land in ``flat_grad`` (fp32, ``bind_lora`` order; added to what is there
+        when ``accumulate``) and ``self.d_emb_all`` holds d(loss)/d(emb_all) for the caller's torch branch."""
         plan = self._last
         if plan.get("bwd_id") == plan["fwd_id"]:
             raise RuntimeError("UNet gradient: backward was already run for this forward (its saved activations are gone)")
@@ -85,6 +94,11 @@ class UNetGradEngine(UNetEngine):
             g = dprobs.get(attn)
             buf.zero_() if g is None else buf.copy_(g)
         self._replay(plan, "rec_bwd")
+        if self.training_lora:
+            self.d_emb_all = plan["d_emb"]
+            if flat_grad is not None:
+                assert flat_grad.dtype == torch.float32 and flat_grad.numel() == self.lora_numel and flat_grad.is_contiguous()
+                self.lora_grads_into(flat_grad, accumulate)
         return plan["dx"].clone()
 
     def _replay(self, plan, which):
@@ -95,7 +109,7 @@ class UNetGradEngine(UNetEngine):
             plan["fn" if which == "rec" else "fn_bwd"]()
 
     # ---- recording ------------------------------------------------------------------------------------------------
-    def _record_grad(self, x, timesteps, context, fps, timestep_cond, motion_cond):
+    def _record_grad(self, x, timesteps, context, fps, timestep_cond, motion_cond, emb_all=None):
         m, ops = self.model, self.ops
         native = getattr(ops, "is_native", False)
         if native:
@@ -117,6 +131,12 @@ class UNetGradEngine(UNetEngine):
         out = torch.empty(B, m.out_channels, F, H, W, dtype=x.dtype, device=x.device)
         st["dout"] = torch.zeros_like(out)
         plan = {"static": st, "out": out, "dx": torch.empty_like(st["x"]), "probs": [], "dprobs": {}, "runs": 0}
+        if self.training_lora:
+            # frozen base weights are packed as they are; the LoRA branch runs as its own GEMMs on per-step operand packs
+            self.pk = Packer(self.adt, x.device, merge_lora=False)
+            self._lora_begin()
+            st["emb_all"] = emb_all.detach().to(x.device, torch.float32).clone().contiguous()
+            plan["d_emb"] = torch.zeros_like(st["emb_all"])
         self.plan = plan
         self.tape, self.refs = [], {}
 
@@ -189,7 +209,7 @@ class UNetGradEngine(UNetEngine):
     def tconv_dgrad_w(self, mod):
         """(3,1,1) conv data gradient as the same temporal conv over dy: w'[ci][(kt', co)] = w[co][ci][2 - kt']."""
         def make():
-            w = effective_weight_bias(mod)[0]                       # [co, ci, 3, 1, 1]
+            w = self.pk.wb(mod)[0]                                  # [co, ci, 3, 1, 1]
             wd = w[:, :, :, 0, 0].flip(2).permute(1, 2, 0)          # [ci, kt', co]
             return wd.reshape(wd.shape[0], -1).to(self.device, self.adt).contiguous()
         return self.pk._memo(("tconv_dgrad", id(mod)), make)
@@ -199,11 +219,113 @@ class UNetGradEngine(UNetEngine):
         return self.pk._memo((tag,) + tuple(id(mm) for mm in mods),
                              lambda: self.pk.cat_mats(mods, tag + "_fwd").t().contiguous())
 
-    def lin_b(self, dy, w_t, residual=None):
-        """dx = dy @ W for a [K, N]-transposed pack w_t (rows = input features)."""
+    def rel(self, *ts):
+        """Forward-side release of an intermediate: kept alive while a backward closure / LoRA group still holds it."""
+        for t in ts:
+            if t is not None and self.refs.get(t.data_ptr(), 0) == 0:
+                self.pool.put(t)
+
+    # ---- leaves: forward with the LoRA branch (training), backward with the LoRA weight gradients -----------------------
+    def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None, lora=None, perm=None):
+        """``a``: tensor or two-part Act.  ``lora``: the injected leaves whose row-concatenated weights ``w`` holds (default:
+        [mod]); ``perm``: packed output row j = original row perm[j] (GEGLU packing)."""
+        x = a if isinstance(a, Act) else Act(a, 0, 0, 0)
+        mods = lora if lora is not None else ([mod] if mod is not None else None)
+        zf = None
+        if self.training_lora and mods and all(is_lora_leaf(mm) for mm in mods):
+            assert act == nt.ACT_NONE
+            zf, residual = self.lora_z(self.lgroup(mods, nt.GEMM_LINEAR, perm), x, x.M, residual)
+        w = self.pk.mat(mod) if w is None else w
+        bias = self.pk.bias(mod) if isinstance(bias, str) else bias
+        N = w.shape[0] if N is None else N
+        out = self.buf(x.M, N // 2 if act == nt.ACT_GEGLU else N, out_dtype)
+        self.ops.gemm(x.parts[0], w, out, M=x.M, N=N, a1=x.p1, bias=bias, residual=residual, act=act)
+        if zf is not None:
+            self.pool.put(zf)
+        return out
+
+    def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto"):
+        zf = None
+        if w is None and self.training_lora and is_lora_leaf(mod):
+            if mode == nt.GEMM_CONV3X3_S2:
+                m_out = x.n_img * ((x.h - 1) // 2 + 1) * ((x.w - 1) // 2 + 1)
+            elif mode == nt.GEMM_CONV3X3_UP2:
+                m_out = x.n_img * 4 * x.h * x.w
+            else:
+                m_out = x.M
+            zf, residual = self.lora_z(self.lgroup([mod], mode), x, m_out, residual, frames)
+        y = super().conv(x, mod, mode, frames=frames, rowvec=rowvec, rowvec_div=rowvec_div, residual=residual,
+                         out_dtype=out_dtype, w=w, bias=bias)
+        if zf is not None:
+            self.pool.put(zf)
+        return y
+
+    def lin_b(self, dy, w_t, residual=None, lora=None, need_dx=True, colsum=None):
+        """dx = dy @ W for a [K, N]-transposed pack w_t (rows = input features); ``lora``: the leaves behind w_t — in
+        training their weight gradients are taken here and their branch's data gradient joins dx."""
+        grp = self.saved_group(lora, nt.GEMM_LINEAR)
+        dl = None
+        if grp is not None:
+            g = self.lora_wgrad(grp, dy, colsum)
+            if need_dx:
+                dl = self.buf(dy.shape[0], grp.ce)
+                self.ops.gemm(g, grp.Db, dl, M=dy.shape[0], N=grp.ce, residual=residual)
+                residual = dl
+            self.lora_wgrad_down(grp, g)
+            self.pool.put(g)
+        if not need_dx:
+            return None
         out = self.buf(dy.shape[0], w_t.shape[0])
         self.ops.gemm(dy, w_t, out, M=dy.shape[0], N=w_t.shape[0], residual=residual)
+        if dl is not None:
+            self.pool.put(dl)
         return out
+
+    def conv_b(self, dy, mod, mode, in_geom, frames=0, colsum=None, out_dtype=None, dy_pad=None):
+        """Data gradient of a conv leaf: dy is an Act on the leaf's OUTPUT grid, the result an Act on its input grid
+        ``in_geom`` = (n_img, h, w).  The adjoint of every gather mode is the 3x3 / (3,1,1) kernel itself on re-packed
+        weights (stride 2: zero-interleaved dy; nearest-x2: 2x2 sum-pool of the result).  In training the leaf's LoRA weight
+        gradients are taken here as well.  ``dy_pad``: dy with its columns zero-padded to 64 (narrow exit conv)."""
+        ops = self.ops
+        n, h, w = in_geom
+        m_in = n * h * w
+        base = self.tconv_dgrad_w(mod) if mode == nt.GEMM_TCONV3 else self.pk.conv_dgrad(mod)
+        inner_mode = nt.GEMM_TCONV3 if mode == nt.GEMM_TCONV3 else nt.GEMM_CONV3X3
+
+        def run(src, wpack, residual=None, odt=None, pool=True):
+            """adjoint gather of ``src`` (a tensor on the output grid) against an [N, taps*c] pack"""
+            if mode == nt.GEMM_CONV3X3_S2:
+                z = self.buf(m_in, src.shape[1])
+                ops.scatter2x(src, n, dy.h, dy.w, h, w, z)
+                y = self.conv(Act(z, n, h, w), None, inner_mode, w=wpack, bias=None, residual=residual, out_dtype=odt)
+                self.pool.put(z)
+                return y.t
+            if mode == nt.GEMM_CONV3X3_UP2:
+                hi = self.conv(Act(src, n, 2 * h, 2 * w), None, inner_mode, w=wpack, bias=None, residual=residual)
+                if not pool:
+                    return hi.t
+                lo = self.buf(m_in, wpack.shape[0])
+                ops.sumpool2x2(hi.t, n, h, w, lo)
+                self.pool.put(hi.t)
+                return lo
+            return self.conv(Act(src, n, h, w), None, inner_mode, frames=frames, w=wpack, bias=None, residual=residual,
+                             out_dtype=odt).t
+
+        grp = self.saved_group([mod], mode)
+        dl = None
+        if grp is not None:
+            g = self.lora_wgrad(grp, dy.t if dy_pad is None else dy_pad, colsum)
+            dl = run(g, grp.Db, pool=False)                      # LoRA branch's data gradient (high-res for UP2: pooled with the base)
+            G = run(g, self.sel_pack(grp.taps, grp.rp))          # rank-r gradient gathered to the input grid, per tap
+            self.pool.put(g)
+            self.lora_wgrad_down(grp, G)
+            self.pool.put(G)
+        cin = base.shape[0]
+        res = None if dl is None else dl[:, :cin]
+        dx = run(dy.t, base, residual=res, odt=out_dtype)
+        if dl is not None:
+            self.pool.put(dl)
+        return Act(dx, n, h, w)
 
     def add(self, a, b):
         out = self.buf(a.shape[0], a.shape[1])
@@ -224,6 +346,15 @@ class UNetGradEngine(UNetEngine):
         h0 = self.buf(B * F * H * W, c_first)
         ops.conv_small(xt, B * F, H, W, pk.small_conv(conv_in), pk.bias(conv_in), h0)
         self.pool.put(xt)
+        if self.training_lora and is_lora_leaf(conv_in):
+            # LoRA branch of the entry conv: the 4-channel latent zero-padded to one 64-channel K slab of the implicit GEMM
+            x64 = self.buf(B * F * H * W, 64)
+            ops.fill_zero(x64)
+            ops.ncfhw_to_tokens(x, x64)
+            zf, z = self.lora_z(self.lgroup([conv_in], nt.GEMM_CONV3X3), Act(x64, B * F, H, W), B * F * H * W)
+            h0b = self.add(h0, z)
+            self.pool.put(h0, zf)
+            h0 = h0b
         h = Act(h0, B * F, H, W)
         hs = []
         for i, block in enumerate(m.input_blocks):
@@ -245,7 +376,7 @@ class UNetGradEngine(UNetEngine):
         self.hold(xin.t)
         tt, st_out = self.gn_t(xin, m.out[0], B * F, H * W, True)
         y = self.conv(Act(tt, h.n_img, h.h, h.w), m.out[2], nt.GEMM_CONV3X3, out_dtype=torch.float32)
-        self.pool.put(tt)
+        self.rel(tt)
         ops.tokens_to_ncfhw(y.t, out)
         self.pool.put(y.t)
         n_img = B * F
@@ -262,6 +393,20 @@ class UNetGradEngine(UNetEngine):
             dt = self.buf(n_img * H * W, xin.C)
             ops.conv_small(d4, n_img, H, W, pk.small_conv_dgrad(m.out[2], cin_pad=cpad), None, dt)
             self.pool.put(d4)
+            grp = self.saved_group([m.out[2]], nt.GEMM_CONV3X3)
+            if grp is not None:  # LoRA of the exit conv: dy zero-padded to 64 columns (K of  g = s dy U)
+                d64 = self.buf(n_img * H * W, 64)
+                ops.fill_zero(d64)
+                ops.ncfhw_to_tokens(dout, d64)
+                g = self.lora_wgrad(grp, d64)
+                self.pool.put(d64)
+                dl = self.conv(Act(g, n_img, H, W), None, nt.GEMM_CONV3X3, w=grp.Db, bias=None).t
+                G = self.conv(Act(g, n_img, H, W), None, nt.GEMM_CONV3X3, w=self.sel_pack(9, grp.rp), bias=None).t
+                self.pool.put(g)
+                self.lora_wgrad_down(grp, G)
+                dt2 = self.add(dt, dl)
+                self.pool.put(G, dt, dl)
+                dt = dt2
             dx = self.gn_b(xin, m.out[0], n_img, H * W, True, st_out, dt)
             self.pool.put(dt, st_out)
             self.drop(xin.t)
@@ -269,7 +414,7 @@ class UNetGradEngine(UNetEngine):
 
         def entry_bwd(dy, dx_out):
             # conv_in data gradient (320 -> 4 channels): a narrow-N implicit GEMM like the forward's conv_out, fp32 out
-            d = self.conv(dy, conv_in, nt.GEMM_CONV3X3, w=pk.conv_dgrad(conv_in), bias=None, out_dtype=torch.float32)
+            d = self.conv_b(dy, conv_in, nt.GEMM_CONV3X3, (n_img, H, W), out_dtype=torch.float32)
             self._free_view(dy.t)
             ops.tokens_to_ncfhw(d.t, dx_out)
             self.pool.put(d.t)
@@ -282,6 +427,19 @@ class UNetGradEngine(UNetEngine):
         B = self.B
         mc = m.model_channels
         L, D = st["ctx"].shape[1], st["ctx"].shape[2]
+        resblocks = [mod for mod in m.modules() if isinstance(mod, ResBlock)]
+        self.emb_off, off = {}, 0
+        for rb in resblocks:
+            self.emb_off[id(rb)] = off
+            off += rb.out_channels
+        self.ctx = self.buf(B * L, D)
+        ops.cast(st["ctx"], self.ctx)
+        self.ctx_len = L
+        self.ctx_kv = {}
+        if self.training_lora:  # the M = B-row branch belongs to torch autograd (engine_lora.py); its result is an input
+            assert st["emb_all"].shape == (B, off)
+            self.emb_all = st["emb_all"]
+            return
         t_emb = self.buf(B, mc)
         ops.timestep_embedding(st["ts"], mc, False, t_emb)
         emb_in = t_emb
@@ -306,20 +464,26 @@ class UNetGradEngine(UNetEngine):
             emb = self.linear(f1, m.fps_embedding[2], residual=emb)
         emb_s = self.buf(B, emb.shape[1])
         ops.silu(emb, emb_s)
-        resblocks = [mod for mod in m.modules() if isinstance(mod, ResBlock)]
-        self.emb_off, off = {}, 0
-        for rb in resblocks:
-            self.emb_off[id(rb)] = off
-            off += rb.out_channels
         lins = [rb.emb_layers[1] for rb in resblocks]
         w_all = pk.cat_mats(lins, "emb_all")
         b_all = pk._memo(("emb_all_bias",) + tuple(id(l) for l in lins),
                          lambda: torch.cat([pk.bias(l) for l in lins]).contiguous())
         self.emb_all = self.linear(emb_s, None, w=w_all, bias=b_all, out_dtype=torch.float32)
-        self.ctx = self.buf(B * L, D)
-        ops.cast(st["ctx"], self.ctx)
-        self.ctx_len = L
-        self.ctx_kv = {}
+
+    def context_kv_t(self, attn):
+        """Training: K / V of ONE cross-attention layer through its own injected to_k / to_v (token-major rows of the text
+        context), V^T by a per-clip transpose.  (Inference stacks all 16 layers' projections into two GEMMs.)"""
+        ops = self.ops
+        B, L = self.B, self.ctx_len
+        inner = attn.heads * attn.dim_head
+        kp = _pad(L, 64)
+        k = self.linear(self.ctx, attn.to_k, bias=None)
+        v = self.linear(self.ctx, attn.to_v, bias=None)
+        vt = self.buf(B * inner, kp)
+        ops.fill_zero(vt)
+        ops.transpose(v, L, inner, vt, batch=B, in_stride=L * inner, out_stride=inner * kp)
+        self.pool.put(v)
+        return k, vt, kp, inner * kp
 
     def _backward_tape(self, dout, dx_out):
         d = self.exit_bwd(dout)
@@ -377,7 +541,7 @@ class UNetGradEngine(UNetEngine):
         t1, st1 = self.gn_t(x, rb.in_layers[0], B * F, hw, True)
         h1 = self.conv(Act(t1, n, x.h, x.w), rb.in_layers[2], nt.GEMM_CONV3X3,
                        rowvec=self.emb_all[:, off:off + cout], rowvec_div=F * hw)
-        self.pool.put(t1)
+        self.rel(t1)
         t2, st2 = self.gn_t(h1, rb.out_layers[0], B * F, hw, True)
         identity = isinstance(rb.skip_connection, nn.Identity)
         if identity:
@@ -385,11 +549,10 @@ class UNetGradEngine(UNetEngine):
         else:
             sc = rb.skip_connection
             assert effective_weight_bias(sc)[0].shape[-1] == 1, "3x3 skip convs are not built by the VideoCrafter2 config"
-            skip = self.buf(x.M, cout)
-            self.ops.gemm(x.parts[0], self.pk.mat(sc), skip, M=x.M, N=cout, a1=x.p1, bias=self.pk.bias(sc))
+            skip = self.linear(x, sc)
             own = True
         h2 = self.conv(Act(t2, n, x.h, x.w), rb.out_layers[3], nt.GEMM_CONV3X3, residual=skip)
-        self.pool.put(t2)
+        self.rel(t2)
         if own:
             self.pool.put(skip)
         geom = (n, x.h, x.w)
@@ -400,12 +563,14 @@ class UNetGradEngine(UNetEngine):
 
         def bwd(dy):
             d_h2 = tc_bwd(dy) if tc_bwd is not None else dy.t
-            d_t2 = self.conv(Act(d_h2, *geom), rb.out_layers[3], nt.GEMM_CONV3X3, w=self.pk.conv_dgrad(rb.out_layers[3]), bias=None)
+            d_t2 = self.conv_b(Act(d_h2, *geom), rb.out_layers[3], nt.GEMM_CONV3X3, geom)
             d_h1 = self.gn_b(h1, rb.out_layers[0], B * F, hw, True, st2, d_t2.t)
             self.pool.put(d_t2.t, h1.t, st2)
-            d_t1 = self.conv(Act(d_h1, *geom), rb.in_layers[2], nt.GEMM_CONV3X3, w=self.pk.conv_dgrad(rb.in_layers[2]), bias=None)
+            # training: the per-clip column sums of d_h1 are d(loss)/d(emb_all) of this block (rowvec of the forward conv)
+            colsum = self.plan["d_emb"][:, off:off + cout] if self.training_lora else None
+            d_t1 = self.conv_b(Act(d_h1, *geom), rb.in_layers[2], nt.GEMM_CONV3X3, geom, colsum=colsum)
             self.pool.put(d_h1)
-            d_skip = d_h2 if identity else self.lin_b(d_h2, self.pk.mat_t(rb.skip_connection))
+            d_skip = d_h2 if identity else self.lin_b(d_h2, self.pk.mat_t(rb.skip_connection), lora=[rb.skip_connection])
             dx = self.gn_b(x, rb.in_layers[0], B * F, hw, True, st1, d_t1.t, resid=d_skip)
             self.pool.put(d_t1.t, st1)
             if not identity:
@@ -428,7 +593,7 @@ class UNetGradEngine(UNetEngine):
         for i, stage in enumerate(stages):
             tt, st = self.gn_t(y, stage[0], B, F * hw, True)
             ny = self.conv(Act(tt, *geom), stage[-1], nt.GEMM_TCONV3, frames=F, residual=h2.t if i == 3 else None)
-            self.pool.put(tt)
+            self.rel(tt)
             saved.append((y, st))
             y = ny
 
@@ -436,7 +601,7 @@ class UNetGradEngine(UNetEngine):
             d = dy.t
             for i in (3, 2, 1, 0):
                 yi, st = saved[i]
-                d_tt = self.conv(Act(d, *geom), stages[i][-1], nt.GEMM_TCONV3, frames=F, w=self.tconv_dgrad_w(stages[i][-1]), bias=None)
+                d_tt = self.conv_b(Act(d, *geom), stages[i][-1], nt.GEMM_TCONV3, geom, frames=F)
                 if i != 3:
                     self.pool.put(d)
                 nd = self.gn_b(yi, stages[i][0], B, F * hw, True, st, d_tt.t, resid=dy.t if i == 0 else None)
@@ -455,11 +620,8 @@ class UNetGradEngine(UNetEngine):
         n, h, w, cin = x.n_img, x.h, x.w, x.C
 
         def bwd(dy):
-            z = self.buf(n * h * w, dy.C)
-            self.ops.scatter2x(dy.t, n, dy.h, dy.w, h, w, z)
+            dx = self.conv_b(dy, layer.op, nt.GEMM_CONV3X3_S2, (n, h, w))
             self._free_view(dy.t)
-            dx = self.conv(Act(z, n, h, w), layer.op, nt.GEMM_CONV3X3, w=self.pk.conv_dgrad(layer.op), bias=None)
-            self.pool.put(z)
             return dx
 
         self.tape.append(("block", bwd))
@@ -470,12 +632,9 @@ class UNetGradEngine(UNetEngine):
         n, h, w, cin = x.n_img, x.h, x.w, x.C
 
         def bwd(dy):
-            d_up = self.conv(dy, layer.conv, nt.GEMM_CONV3X3, w=self.pk.conv_dgrad(layer.conv), bias=None)  # at 2h x 2w
+            dx = self.conv_b(dy, layer.conv, nt.GEMM_CONV3X3_UP2, (n, h, w))
             self._free_view(dy.t)
-            dx = self.buf(n * h * w, cin)
-            self.ops.sumpool2x2(d_up.t, n, h, w, dx)
-            self.pool.put(d_up.t)
-            return Act(dx, n, h, w)
+            return dx
 
         self.tape.append(("block", bwd))
         return y
@@ -493,20 +652,20 @@ class UNetGradEngine(UNetEngine):
         self.hold(x.t)
         t, stats = self.gn_t(x, tr.norm, units, rows, False)
         y = self.linear(t, tr.proj_in)
-        self.pool.put(t)
+        self.rel(t)
         blocks = []
         for blk in tr.transformer_blocks:
             y, b = self.transformer_block_t(blk, y, (n, hw), temporal)
             blocks.append(b)
         out = self.linear(y, tr.proj_out, residual=x.t)
-        self.pool.put(y)
+        self.rel(y)
         geom = (n, x.h, x.w)
 
         def bwd(dy):
-            d = self.lin_b(dy.t, self.pk.mat_t(tr.proj_out))
+            d = self.lin_b(dy.t, self.pk.mat_t(tr.proj_out), lora=[tr.proj_out])
             for b in reversed(blocks):
                 d = b(d)
-            d_t = self.lin_b(d, self.pk.mat_t(tr.proj_in))
+            d_t = self.lin_b(d, self.pk.mat_t(tr.proj_in), lora=[tr.proj_in])
             self.pool.put(d)
             dx = self.gn_b(x, tr.norm, units, rows, False, stats, d_t, resid=dy.t)
             self.pool.put(d_t, stats)
@@ -541,7 +700,7 @@ class UNetGradEngine(UNetEngine):
         # ---- attention flavours: forward returns (o, backward: d_o -> d(ln input of the attention)) ------------------
         def temporal_attn(attn, src):
             mods = [attn.to_q, attn.to_k, attn.to_v]
-            qkv = self.linear(src, None, w=pk.cat_mats(mods, "qkv"), bias=None)
+            qkv = self.linear(src, None, w=pk.cat_mats(mods, "qkv"), bias=None, lora=mods)
             o = self.buf(M, inner)
             probs = dprobs = None
             if attn.record_attn_probs:
@@ -555,19 +714,26 @@ class UNetGradEngine(UNetEngine):
                 ops.attn_temporal_bwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], d_o, dprobs,
                                       dqkv[:, :inner], dqkv[:, inner:2 * inner], dqkv[:, 2 * inner:], B, F, hw, attn.heads, attn.scale)
                 self.pool.put(qkv, d_o)
-                d_ln = self.lin_b(dqkv, self.mats_t(mods, "qkv_t"))
+                d_ln = self.lin_b(dqkv, self.mats_t(mods, "qkv_t"), lora=mods)
                 self.pool.put(dqkv)
                 return d_ln
             return o, bwd
 
         def spatial_self_attn(attn, src):
             heads = attn.heads
-            qk = self.linear(src, None, w=pk.cat_mats([attn.to_q, attn.to_k], "qk"), bias=None)
+            qk = self.linear(src, None, w=pk.cat_mats([attn.to_q, attn.to_k], "qk"), bias=None, lora=[attn.to_q, attn.to_k])
             kp = ((hw + 63) // 64) * 64
             vt = self.buf(n_img * inner, kp)
             if kp != hw:
                 ops.fill_zero(vt)
-            ops.gemm(pk.mat(attn.to_v), src, vt, M=inner, N=hw, batch=n_img, w_strides=(hw * src.stride(0), 0), o_strides=(inner * kp, 0))
+            if self.training_lora and is_lora_leaf(attn.to_v):
+                # training: V token-major through the injected leaf, then transposed per image (inference: V^T straight
+                # out of a GEMM with the weight as the row operand)
+                v = self.linear(src, attn.to_v, bias=None)
+                ops.transpose(v, hw, inner, vt, batch=n_img, in_stride=hw * inner, out_stride=inner * kp)
+                self.pool.put(v)
+            else:
+                ops.gemm(pk.mat(attn.to_v), src, vt, M=inner, N=hw, batch=n_img, w_strides=(hw * src.stride(0), 0), o_strides=(inner * kp, 0))
             o = self.buf(M, inner)
             ops.attn_spatial(qk[:, :inner], qk[:, inner:], vt, kp, o, n_img, hw, hw, heads, 1, attn.scale)
             nb = n_img * heads
@@ -619,8 +785,8 @@ class UNetGradEngine(UNetEngine):
                 ops.gemm(dsT, qT, dqk[:, inner:inner + 64], M=hw, N=64, alpha=attn.scale, a_strides=(heads * kp * kp, kp * kp),
                          w_strides=(inner * kp, 64 * kp), o_strides=(hw * 2 * inner, 64), **hb)
                 self.pool.put(dsT, qT)
-                d1 = self.lin_b(dqk, self.mats_t([attn.to_q, attn.to_k], "qk_t"))
-                d_ln = self.lin_b(d_v, pk.mat_t(attn.to_v), residual=d1)
+                d1 = self.lin_b(dqk, self.mats_t([attn.to_q, attn.to_k], "qk_t"), lora=[attn.to_q, attn.to_k])
+                d_ln = self.lin_b(d_v, pk.mat_t(attn.to_v), residual=d1, lora=[attn.to_v])
                 self.pool.put(dqk, d_v, d1)
                 return d_ln
             return o, bwd
@@ -628,41 +794,62 @@ class UNetGradEngine(UNetEngine):
         def cross_attn(attn, src):
             heads, L = attn.heads, self.ctx_len
             q = self.linear(src, attn.to_q, bias=None)
-            k, vt, kp, vt_stride = self.context_kv(attn)
+            own_kv = self.training_lora and is_lora_leaf(attn.to_k) and is_lora_leaf(attn.to_v)
+            k, vt, kp, vt_stride = self.context_kv_t(attn) if own_kv else self.context_kv(attn)
             o = self.buf(M, inner)
             ops.attn_spatial(q, k, vt, kp, o, n_img, hw, L, heads, F, attn.scale, vt_stride)
-            ldk = k.stride(0)
+            mq = F * hw  # the frames of a clip share K / V: per clip and head, ONE attention of F*hw queries over L keys
 
-            def bwd(d_o):  # the text context carries no gradient: only dQ
+            def bwd(d_o):
                 d_q = self.buf(M, inner)
-                for b in range(B):  # the F frames of a clip share K / V
-                    rows = slice(b * F * hw, (b + 1) * F * hw)
+                dk = dv = None
+                if own_kv:  # the text context itself carries no gradient, its injected to_k / to_v projections do
+                    dk, dv = self.buf(B * L, inner), self.buf(B * L, inner)
+                    mqp = _pad(mq, 64)
+                hb = dict(batch=heads, batch_inner=heads)
+                for b in range(B):
+                    rows = slice(b * mq, (b + 1) * mq)
                     qb, dob, dqb = q[rows], d_o[rows], d_q[rows]
                     kb = k[b * L:(b + 1) * L]
                     vtb = torch.as_strided(vt, (inner, kp), (kp, 1), vt.storage_offset() + b * vt_stride)
-                    nbb = F * heads
-                    hb = dict(batch=nbb, batch_inner=heads)
-                    s = self.buf(nbb * hw, kp)
+                    s = self.buf(heads * mq, kp)
                     ops.fill_zero(s)
-                    ops.gemm(qb[:, :64], kb[:, :64], s, M=hw, N=L, alpha=attn.scale, a_strides=(hw * inner, 64), w_strides=(0, 64),
-                             o_strides=(heads * hw * kp, hw * kp), **hb)
-                    ops.softmax_rows(s, nbb * hw, L, kp, kp)
+                    ops.gemm(qb[:, :64], kb[:, :64], s, M=mq, N=L, alpha=attn.scale, a_strides=(0, 64), w_strides=(0, 64),
+                             o_strides=(0, mq * kp), **hb)
+                    ops.softmax_rows(s, heads * mq, L, kp, kp)
                     v_tok = self.buf(heads * kp, 64)
                     ops.transpose(vtb, 64, kp, v_tok, batch=heads, in_stride=64 * kp, out_stride=kp * 64)
-                    dp = self.buf(nbb * hw, kp)
-                    ops.gemm(dob[:, :64], v_tok, dp, M=hw, N=kp, a_strides=(hw * inner, 64), w_strides=(0, kp * 64),
-                             o_strides=(heads * hw * kp, hw * kp), **hb)
+                    dp = self.buf(heads * mq, kp)
+                    ops.gemm(dob[:, :64], v_tok, dp, M=mq, N=kp, a_strides=(0, 64), w_strides=(0, kp * 64),
+                             o_strides=(0, mq * kp), **hb)
                     self.pool.put(v_tok)
-                    ops.softmax_bwd_rows(s, dp, nbb * hw, L, kp, kp)
+                    if own_kv:  # dV[kv][c] = sum_q P[q][kv] dO[q][c], contraction over all F*hw queries of the clip
+                        pT = self.tposed(s, mq, kp, batch=heads, in_stride=mq * kp)
+                        doT = self.tposed(dob, mq, inner)
+                        ops.gemm(pT, doT, dv[b * L:(b + 1) * L][:, :64], M=L, N=64, a_strides=(0, kp * mqp),
+                                 w_strides=(0, 64 * mqp), o_strides=(0, 64), split_k=self.split_for(L * heads, 64, mqp), **hb)
+                        self.pool.put(pT, doT)
+                    ops.softmax_bwd_rows(s, dp, heads * mq, L, kp, kp)
                     self.pool.put(s)
                     kT = self.buf(inner, kp)
                     ops.fill_zero(kT)
                     ops.transpose(kb, L, inner, kT, batch=1, in_stride=0, out_stride=0)
-                    ops.gemm(dp, kT, dqb[:, :64], M=hw, N=64, alpha=attn.scale, a_strides=(heads * hw * kp, hw * kp),
-                             w_strides=(0, 64 * kp), o_strides=(hw * inner, 64), **hb)
-                    self.pool.put(dp, kT)
+                    ops.gemm(dp, kT, dqb[:, :64], M=mq, N=64, alpha=attn.scale, a_strides=(0, mq * kp),
+                             w_strides=(0, 64 * kp), o_strides=(0, 64), **hb)
+                    self.pool.put(kT)
+                    if own_kv:  # dK[kv][c] = scale * sum_q dS[q][kv] Q[q][c]
+                        dsT = self.tposed(dp, mq, kp, batch=heads, in_stride=mq * kp)
+                        qT = self.tposed(qb, mq, inner)
+                        ops.gemm(dsT, qT, dk[b * L:(b + 1) * L][:, :64], M=L, N=64, alpha=attn.scale, a_strides=(0, kp * mqp),
+                                 w_strides=(0, 64 * mqp), o_strides=(0, 64), split_k=self.split_for(L * heads, 64, mqp), **hb)
+                        self.pool.put(dsT, qT)
+                    self.pool.put(dp)
                 self.pool.put(q, d_o)
-                d_ln = self.lin_b(d_q, pk.mat_t(attn.to_q))
+                if own_kv:
+                    self.lin_b(dk, None, lora=[attn.to_k], need_dx=False)
+                    self.lin_b(dv, None, lora=[attn.to_v], need_dx=False)
+                    self.pool.put(dk, dv, k, vt)
+                d_ln = self.lin_b(d_q, pk.mat_t(attn.to_q), lora=[attn.to_q])
                 self.pool.put(d_q)
                 return d_ln
             return o, bwd
@@ -670,39 +857,43 @@ class UNetGradEngine(UNetEngine):
         # ---- forward ------------------------------------------------------------------------------------------------
         ln = lnorm(blk.norm1, y)
         o, attn1_b = temporal_attn(a1, ln) if temporal else spatial_self_attn(a1, ln)
-        self.pool.put(ln)
+        self.rel(ln)
         y1 = self.linear(o, a1.to_out[0], residual=y)
-        self.pool.put(o)
+        self.rel(o)
         ln = lnorm(blk.norm2, y1)
         o, attn2_b = temporal_attn(a2, ln) if temporal else cross_attn(a2, ln)
-        self.pool.put(ln)
+        self.rel(ln)
         y2 = self.linear(o, a2.to_out[0], residual=y1)
-        self.pool.put(o)
+        self.rel(o)
         ln = lnorm(blk.norm3, y2)
         proj = blk.ff.net[0]
         assert hasattr(proj, "proj"), "non-gated FeedForward is not built by the VideoCrafter2 config"
         wg, bg = pk.geglu(proj.proj)
-        hpre = self.linear(ln, None, w=wg, bias=bg)  # pre-activation kept for the backward (packed value | gate groups)
-        self.pool.put(ln)
+        ff_inner = wg.shape[0] // 2
+        j = torch.arange(2 * ff_inner)  # packed GEGLU row j (64-row groups [32 value | 32 gate]) <- original projection row
+        geglu_perm = (j // 64) * 32 + (j % 32) + (j % 64 >= 32) * ff_inner
+        # pre-activation kept for the backward (packed value | gate groups)
+        hpre = self.linear(ln, None, w=wg, bias=bg, lora=[proj.proj], perm=geglu_perm)
+        self.rel(ln)
         g = self.buf(M, hpre.shape[1] // 2)
         ops.geglu_fwd(hpre, g)
         y3 = self.linear(g, blk.ff.net[2], residual=y2)
-        self.pool.put(g)
+        self.rel(g)
 
         def bwd(dy3):
-            d_g = self.lin_b(dy3, pk.mat_t(blk.ff.net[2]))
+            d_g = self.lin_b(dy3, pk.mat_t(blk.ff.net[2]), lora=[blk.ff.net[2]])
             d_h = self.buf(M, hpre.shape[1])
             ops.geglu_bwd(hpre, d_g, d_h)
             self.pool.put(d_g, hpre)
-            d_ln3 = self.lin_b(d_h, pk._memo(("geglu_t", id(proj.proj)), lambda: wg.t().contiguous()))
+            d_ln3 = self.lin_b(d_h, pk._memo(("geglu_t", id(proj.proj)), lambda: wg.t().contiguous()), lora=[proj.proj])
             self.pool.put(d_h)
             d_y2 = ln_b(blk.norm3, y2, d_ln3, dy3)
             self.pool.put(d_ln3, dy3, y2)
-            d_o2 = self.lin_b(d_y2, pk.mat_t(a2.to_out[0]))
+            d_o2 = self.lin_b(d_y2, pk.mat_t(a2.to_out[0]), lora=[a2.to_out[0]])
             d_ln2 = attn2_b(d_o2)
             d_y1 = ln_b(blk.norm2, y1, d_ln2, d_y2)
             self.pool.put(d_ln2, d_y2, y1)
-            d_o1 = self.lin_b(d_y1, pk.mat_t(a1.to_out[0]))
+            d_o1 = self.lin_b(d_y1, pk.mat_t(a1.to_out[0]), lora=[a1.to_out[0]])
             d_ln1 = attn1_b(d_o1)
             d_y = ln_b(blk.norm1, y, d_ln1, d_y1)
             self.pool.put(d_ln1, d_y1, y)

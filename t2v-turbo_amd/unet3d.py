@@ -487,8 +487,8 @@ class UNetModel(nn.Module):
             self._engine_box.engine = UNetEngine(self, HipOps())
         return self._engine_box.engine
 
-    def _forward_composite(self, x, timesteps, context, features_adapter, fps, timestep_cond, motion_cond):
-        """Reference-semantics torch path (openaimodel3d.py:672-740)."""
+    def _embedding(self, timesteps, fps, timestep_cond, motion_cond):
+        """Time (+ guidance-scale, + motion) and fps embedding, one row per clip (openaimodel3d.py:683-706)."""
         t_emb = sinusoidal_embedding(timesteps, self.model_channels).to(self.dtype)
         cond = self.time_cond_proj(timestep_cond) if timestep_cond is not None else 0.0
         if motion_cond is not None:
@@ -498,6 +498,18 @@ class UNetModel(nn.Module):
             if type(fps) == int:
                 fps = torch.full_like(timesteps, fps)
             emb = emb + self.fps_embedding(sinusoidal_embedding(fps, self.model_channels).to(self.dtype))
+        return emb
+
+    def conditioning_emb_all(self, timesteps, fps=16, timestep_cond=None, motion_cond=None):
+        """[B, sum of ResBlock widths] fp32: every ResBlock's ``emb_layers(emb)`` side by side, in ``modules()`` order — the
+        conditioning input of the native training engine (engine_lora.py).  Differentiable: this M = B-row branch (27
+        small leaves) stays with torch autograd, the engine returns d(loss)/d(this tensor)."""
+        emb = self._embedding(timesteps, fps, timestep_cond, motion_cond)
+        return torch.cat([mod.emb_layers(emb) for mod in self.modules() if isinstance(mod, ResBlock)], dim=1).float()
+
+    def _forward_composite(self, x, timesteps, context, features_adapter, fps, timestep_cond, motion_cond):
+        """Reference-semantics torch path (openaimodel3d.py:672-740)."""
+        emb = self._embedding(timesteps, fps, timestep_cond, motion_cond)
         b, _, t, hh, ww = x.shape
         context = context.repeat_interleave(repeats=t, dim=0)
         emb = emb.repeat_interleave(repeats=t, dim=0)

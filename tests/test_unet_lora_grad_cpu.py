@@ -1,0 +1,118 @@
+"""LoRA weight gradients of the student UNet on the native engine's dataflow (CPU, emulated op backend, fp32): every
+``lora_up`` / ``lora_down`` gradient, d(loss)/d(latents) and d(loss)/d(emb_all) must match torch autograd through the
+LoRA-injected, reference-shaped module (utils/lora.py:45-50,124-129,204-209 forward; the student's backward of
+train_t2v_turbo_v1_lora.py:1190).  Pins: the un-merged LoRA branch (t = x*D, z = s t U^T as the base leaf's residual), the
+rank-r weight-gradient GEMMs (token-contracted, transposed operands, zero padding to rank / K 64), the gathered rank-r
+gradient for conv leaves (stride 1 / stride 2 / nearest-x2 / temporal), the GEGLU row permutation, grouped q/k/v leaves, the
+per-layer text K/V with their dK/dV, the 4-channel entry / exit convs, and the index maps between parameter layout, operand
+packs and gradient arena."""
+import torch
+
+from oracle.synth import synth_state_dict
+from t2v_turbo_amd import lora
+from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+from t2v_turbo_amd.unet3d import UNetModel
+from tests.emu_ops import EmuOps
+from tests.util import load, manifest, rel_l2, tiny_unet_params
+
+
+def _student(fixture, rank, **cfg):
+    m = UNetModel(**tiny_unet_params(**cfg)).eval()
+    m.load_state_dict(synth_state_dict(manifest(fixture)), strict=True)
+    m.requires_grad_(False)
+    lora.inject_trainable_lora_extended(m, r=rank)
+    params = lora.lora_parameters(m)
+    gen = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for p in params:  # lora_up is zero-initialised: draw both factors, or every lora_down gradient is zero
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.05)
+    m.eval()
+    for i, mod in enumerate(mm for mm in m.modules() if hasattr(mm, "lora_up")):
+        mod.scale = 1.0 if i % 3 else 0.5  # the scale is per leaf
+    return m, params
+
+
+def _autograd(m, params, x, ts, ctx, fps, tc, mc, r_out):
+    xg = x.clone().requires_grad_(True)
+    m.native_mode = "off"
+    for p in params:
+        p.grad = None
+    kw = {} if mc is None else {"motion_cond": mc}
+    y = m(xg, ts, context=ctx, fps=fps, timestep_cond=tc, **kw)
+    (y * r_out).sum().backward()
+    return y.detach(), xg.grad, [p.grad.clone() for p in params]
+
+
+def _engine_step(eng, m, params, x, ts, ctx, fps, tc, mc, r_out):
+    emb_all = m.conditioning_emb_all(ts, fps, tc, mc)
+    y = eng.forward_tape(x, ts, ctx, fps, tc, mc, emb_all=emb_all)
+    flat = torch.zeros(eng.lora_numel)
+    dx = eng.backward(r_out, flat_grad=flat, accumulate=False)
+    for p in params:
+        p.grad = None
+    emb_all.backward(eng.d_emb_all)  # the M = B-row conditioning branch stays with torch
+    grads, off = [], 0
+    for p in params:
+        g = flat[off:off + p.numel()].view_as(p)
+        grads.append(g if p.grad is None else g + p.grad)
+        off += p.numel()
+    return y, dx, grads
+
+
+def _compare(params, got, ref, m, tol=2e-4, max_zero=0):
+    names = {id(p): n for n, p in m.named_parameters()}
+    worst, zeros = (0.0, None), 0
+    for p, g, r in zip(params, got, ref):
+        if float(r.abs().max()) == 0:  # e.g. q / k of a one-token spatial attention: the softmax is constant
+            assert float(g.abs().max()) < 1e-7, names[id(p)]
+            zeros += 1
+            continue
+        e = rel_l2(g, r)
+        if e > worst[0]:
+            worst = (e, names[id(p)])
+    assert worst[0] < tol, worst
+    assert zeros <= max_zero, zeros
+
+
+def test_lora_gradients_match_autograd():
+    g = load("unet_tiny")
+    m, params = _student("unet_tiny", 64)
+    x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
+    eng = UNetGradEngine(m, EmuOps())
+    eng.bind_lora(params)
+    # every injected leaf is either the engine's or the conditioning branch's
+    assert len(eng.engine_leaves()) * 2 + len(eng.conditioning_parameters()) == len(params)
+    y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 16, tc, None, r_out)
+    y, dx, grads = _engine_step(eng, m, params, x, ts, ctx, 16, tc, None, r_out)
+    assert rel_l2(y, y_ref) < 2e-5
+    assert rel_l2(dx, dx_ref) < 1e-4
+    _compare(params, grads, g_ref, m, max_zero=0)
+    # an optimizer step later: the plan is replayed, the operand packs follow the parameters
+    with torch.no_grad():
+        gen = torch.Generator().manual_seed(9)
+        for p in params:
+            p.add_(torch.randn(p.shape, generator=gen) * 0.01)
+    x2 = torch.randn(x.shape, generator=torch.Generator().manual_seed(3))
+    n_plans = len(eng.plans)
+    y_ref, dx_ref, g_ref = _autograd(m, params, x2, torch.tensor([519]), ctx, 24, tc, None, r_out)
+    y, dx, grads = _engine_step(eng, m, params, x2, torch.tensor([519]), ctx, 24, tc, None, r_out)
+    assert len(eng.plans) == n_plans, "a LoRA update must not invalidate the recorded plan"
+    assert rel_l2(y, y_ref) < 2e-5
+    assert rel_l2(dx, dx_ref) < 1e-4
+    _compare(params, grads, g_ref, m, max_zero=0)
+
+
+def test_lora_gradients_rank16_two_clips_motion_cond():
+    """rank < 64 (operands zero-padded to the K granularity), two clips (per-clip text K/V and column sums), motion cond."""
+    g = load("unet_tiny_mg_b2")
+    m, params = _student("unet_tiny_mg_b2", 16, motion_cond_proj_dim=256)
+    x, ts, ctx, tc, mc = g["x"], g["ts"], g["ctx"], g["tc"], g["mc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(11))
+    eng = UNetGradEngine(m, EmuOps())
+    eng.bind_lora(params)
+    y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 8, tc, mc, r_out)
+    y, dx, grads = _engine_step(eng, m, params, x, ts, ctx, 8, tc, mc, r_out)
+    assert rel_l2(y, y_ref) < 2e-5
+    assert rel_l2(dx, dx_ref) < 1e-4
+    _compare(params, grads, g_ref, m, max_zero=8)
