@@ -116,3 +116,40 @@ def test_lora_gradients_rank16_two_clips_motion_cond():
     assert rel_l2(y, y_ref) < 2e-5
     assert rel_l2(dx, dx_ref) < 1e-4
     _compare(params, grads, g_ref, m, max_zero=8)
+
+
+def test_lora_gradients_match_the_reference_fixture():
+    """tests/golden/unet_tiny_lora_grad.npz: autograd through the REFERENCE UNetModel with the reference's own
+    ``inject_trainable_lora_extended`` (tests/golden/make_golden_lora_grad.py).  Our injection order / shapes, the
+    module's torch path and the native engine must all reproduce it."""
+    from tests.golden.make_golden_lora_grad import SEED_R, digests, draw_lora
+    g, gg = load("unet_tiny"), load("unet_tiny_lora_grad")
+    m = UNetModel(**tiny_unet_params()).eval()
+    m.load_state_dict(synth_state_dict(manifest("unet_tiny")), strict=True)
+    m.requires_grad_(False)
+    lora.inject_trainable_lora_extended(m, r=64)
+    params = lora.lora_parameters(m)
+    assert len(params) == 2 * int(gg["n_leaves"]) == 1150
+    assert [list(p.shape) + [0] * (5 - p.dim()) for p in params] == gg["shapes"].tolist()  # same leaves, same order
+    draw_lora(params)
+    m.eval()
+    x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(SEED_R))
+
+    def check(y, dx, grads, tol):
+        assert rel_l2(y, gg["out"]) < tol / 5
+        assert rel_l2(dx, gg["dx"]) < tol
+        d, ref = torch.from_numpy(digests(grads)), gg["digests"]
+        assert ref.shape == (1150, 3)
+        # norms to relative tolerance; projections against the tensor's norm (they can be near zero themselves)
+        assert float(((d[:, 0] - ref[:, 0]).abs() / ref[:, 0]).max()) < tol
+        assert float(((d[:, 1:] - ref[:, 1:]).abs() / ref[:, :1]).max()) < tol * 30
+        for k in ("g10", "g11", "g1148", "g1149"):  # the rank-4 entry / exit conv leaves in full
+            assert rel_l2(grads[int(k[1:])], gg[k]) < tol
+
+    y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 16, tc, None, r_out)
+    check(y_ref, dx_ref, g_ref, 1e-4)
+    eng = UNetGradEngine(m, EmuOps())
+    eng.bind_lora(params)
+    y, dx, grads = _engine_step(eng, m, params, x, ts, ctx, 16, tc, None, r_out)
+    check(y, dx, grads, 2e-4)
