@@ -113,3 +113,57 @@ def test_reward_branch_adds_the_reference_term():
     assert torch.allclose(info["distill_loss"], base.detach(), rtol=1e-5, atol=1e-7)
     assert torch.allclose(loss.detach(), info["distill_loss"] + info["reward_loss"], rtol=1e-6)
     assert float(info["reward_loss"]) < 0 and float(sync.flat.abs().sum()) > 0
+
+
+def test_native_student_engine_reproduces_the_torch_step():
+    """distill_step(student_engine=...) — student forward, target forward and the whole backward on the gradient engine's
+    dataflow (emulated ops on CPU) — gives the loss, the flat LoRA gradient and the updated parameters of the torch path."""
+    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+    from t2v_turbo_amd.optim import FlatAdamW
+    from tests.emu_ops import EmuOps
+    from tests.util import rel_l2
+    sd = synth_state_dict(manifest("unet_tiny"))
+    teacher = UNetModel(**tiny_unet_params(time_cond_proj_dim=None)).eval()
+    teacher.load_state_dict({k: v for k, v in sd.items() if not k.startswith("time_cond_proj")}, strict=True)
+    teacher.requires_grad_(False)
+    sched = T2VTurboScheduler()
+    solver = cd_math.DDIMSolver(sched.alphas_cumprod.numpy(), ddim_timesteps=50)
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(2, 4, 2, 8, 8, generator=g)
+    pe, ue = torch.randn(2, 77, 128, generator=g), torch.randn(2, 77, 128, generator=g)
+    rngs = [dict(index=torch.tensor([3, 40]), noise=torch.randn(lat.shape, generator=g), w=torch.tensor([6.0, 11.5])),
+            dict(index=torch.tensor([25, 9]), noise=torch.randn(lat.shape, generator=g), w=torch.tensor([14.0, 5.5]))]
+
+    def run(native):
+        student = UNetModel(**tiny_unet_params())
+        student.load_state_dict(sd, strict=True)
+        student.requires_grad_(False)
+        lora.inject_trainable_lora_extended(student, r=16)
+        student.eval()
+        student.native_mode = "off"
+        params = lora.lora_parameters(student)
+        gen = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for p in params:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.05)
+        sync = FlatGradSync(params)
+        opt = FlatAdamW(params, sync, lr=1e-3)  # parameters become views of one flat buffer: the engine reads it as it is
+        eng = None
+        if native:
+            eng = UNetGradEngine(student, EmuOps())
+            eng.bind_lora(params)
+        out = []
+        for rng in rngs:  # two steps: the second one runs on the updated LoRA tensors (replayed plan, refreshed packs)
+            sync.zero_()
+            loss, info = distill_step(student, teacher, solver, sched, lat, pe, ue, grad_sync=sync, rng=rng, student_engine=eng,
+                                      max_grad_norm=1e9, loss_type="l2")  # (the Huber gradient diff / sqrt(diff^2 + 1e-6)
+            # amplifies the two paths' 1e-6 forward round-off where |diff| ~ 1e-3: the comparison would measure that)
+            out.append((loss.detach().clone(), sync.flat.clone()))
+            opt.step()
+        return out, opt.flat_param.clone()
+
+    (ref, p_ref), (got, p_got) = run(False), run(True)
+    for (l0, g0), (l1, g1) in zip(ref, got):
+        assert abs(float(l0) - float(l1)) < 1e-5 * max(1.0, abs(float(l0)))
+        assert rel_l2(g1, g0) < 2e-4
+    assert rel_l2(p_got, p_ref) < 1e-4  # Adam's first steps move every element by ~lr * sign(g): near-zero gradients may flip
