@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--tiny", type=int, default=0, help="toy widths (plumbing check)")
     ap.add_argument("--rank-r", type=int, default=64)
+    ap.add_argument("--native-student", type=int, default=0,
+                    help="1: student forward / target forward / backward on the native gradient engine (eval mode, no dropout; "
+                         "needs T2V_UNVALIDATED_KERNELS=1 until its kernels have run on hardware)")
     a = ap.parse_args()
     import bench
     from t2v_turbo_amd import cd_math, dist as tdist, lora
@@ -57,11 +60,26 @@ def main():
     teacher.dtype = torch.bfloat16
     student.requires_grad_(False)
     lora.inject_trainable_lora_extended(student, r=a.rank_r)
-    student.train()
-    student.native_mode = "off"  # train-mode dropout + autograd: torch path
     params = lora.lora_parameters(student)
     sync = tdist.FlatGradSync(params)
-    opt = torch.optim.AdamW(params, lr=1e-5)
+    eng = None
+    if a.native_student:
+        from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+        from t2v_turbo_amd.native import HipOps
+        from t2v_turbo_amd.optim import FlatAdamW
+        student.eval()                       # the engine applies no dropout
+        student.native_mode = "off"
+        with torch.no_grad():                # lora_up starts at zero; give the down gradients something to do
+            for p in params:
+                if float(p.abs().max()) == 0.0:
+                    p.normal_(0.0, 0.01, generator=g)
+        opt = FlatAdamW(params, sync, lr=1e-5)   # parameters / gradients / moments: three flat buffers, one fused kernel
+        eng = UNetGradEngine(student, HipOps())
+        eng.bind_lora(params)
+    else:
+        student.train()
+        student.native_mode = "off"  # train-mode dropout + autograd: torch path
+        opt = torch.optim.AdamW(params, lr=1e-5)
     sched = T2VTurboScheduler()
     solver = cd_math.DDIMSolver(sched.alphas_cumprod.numpy(), ddim_timesteps=50).to(dev)
     gen = torch.Generator().manual_seed(rank)
@@ -71,7 +89,7 @@ def main():
 
     def step():
         return distill_step(student, teacher, solver, sched, lat, pe, ue, optimizer=opt, grad_sync=sync,
-                            autocast_dtype=torch.bfloat16)
+                            autocast_dtype=torch.bfloat16, student_engine=eng)
 
     for _ in range(a.warmup):
         loss, _ = step()
@@ -87,7 +105,8 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t1) / a.steps
     if rank == 0:
-        print(json.dumps({"metric": "v1 distillation steps/sec (student fwd+bwd torch path, teacher x2 native HIP)",
+        print(json.dumps({"metric": "v1 distillation steps/sec (student " + ("native gradient engine" if eng is not None else "fwd+bwd torch path")
+                          + ", teacher x2 native HIP)", "student_native": eng is not None,
                           "value": round(world / dt, 4), "unit": "samples/s", "n_gpus": world, "ms_per_step": round(dt * 1e3, 1),
                           "lora_grad_mb": round(sync.numel * 4 / 2 ** 20, 1), "loss": float(loss),
                           "teacher_native": teacher._engine_box.engine is not None, "peak_mem_gb":

@@ -9,9 +9,12 @@ mkdir -p gpurun_out
 hipcc --offload-arch=gfx950 -O3 tools/fill_rate.hip -o /tmp/fill_rate && (timeout 60 /tmp/fill_rate 16 2000; timeout 60 /tmp/fill_rate 16 2000 64) | tee gpurun_out/fill_rate.txt
 T2V_TEST_EXPERIMENTAL_TILES=1 timeout 240 python -m pytest tests/test_gpu_kernels.py -m gpu -q --tb=line -p no:cacheprovider \
     -k "linear_tiles or conv_modes or geglu_all" 2>&1 | tail -15 | tee gpurun_out/experimental_tiles.txt
-# 2b. the UNet data-gradient kernels (LayerNorm / GEGLU / temporal-attention backward, two-part GroupNorm backward ...) and the
-#     gradient engine end to end against autograd
-T2V_TEST_UNVALIDATED=1 timeout 200 python -m pytest tests/test_gpu_unet_grad.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -15 \
+# 2b. the UNet data-gradient kernels (LayerNorm / GEGLU / temporal-attention backward, two-part GroupNorm backward ...), the
+#     gradient engine end to end against autograd, and the LoRA training path (gather kernel, weight-gradient GEMM shapes,
+#     student forward + backward with all LoRA gradients)
+T2V_TEST_UNVALIDATED=1 timeout 300 python -m pytest tests/test_gpu_unet_grad.py -m gpu -q --tb=short -p no:cacheprovider 2>&1 | tail -15 \
     | tee gpurun_out/unet_grad_kernels.txt
 timeout 200 python tools/gemm_profile_graph.py --blas 0 --force-cfgs 24,25,26,27,28,29 --top 30 \
     --out gpurun_out/gemm_experimental_cfgs.csv 2>&1 | tail -3
+# 4. the distillation step with the native student (tools/distill_bench.py --native-student 1) next to the torch student
+T2V_UNVALIDATED_KERNELS=1 timeout 500 python tools/distill_bench.py --steps 3 --native-student 1 2>&1 | tail -2 | tee gpurun_out/distill_native.txt
