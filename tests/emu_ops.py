@@ -22,8 +22,9 @@ def _strided(t, rows, cols, ld, offset_elems):
 class EmuOps:
     is_native = False
 
-    def __init__(self, act_dtype=torch.float32):
+    def __init__(self, act_dtype=torch.float32, strict=False):
         self.act_dtype = act_dtype
+        self.strict = strict  # also enforce the device-side operand alignment rules of t2v_gemm (engine dataflow tests)
         self.calls = []
 
     def init(self):
@@ -38,10 +39,11 @@ class EmuOps:
              a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0):
         self._log("gemm")
         # device-side argument rules (csrc/gemm.hip, t2v_gemm): operand row strides, batch strides and base addresses
-        assert a0.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and (a1 is None or a1.stride(0) % 8 == 0), "lda/ldw % 8"
-        assert all(v % 8 == 0 for v in tuple(a_strides) + tuple(w_strides)), "batch strides % 8"
-        assert a0.storage_offset() % 8 == 0 and w.storage_offset() % 8 == 0, "operand base must be 16-byte aligned"
-        assert residual is None or residual.dtype == self.act_dtype, "residual is an activation-dtype tensor"
+        if self.strict:
+            assert a0.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and (a1 is None or a1.stride(0) % 8 == 0), "lda/ldw % 8"
+            assert all(v % 8 == 0 for v in tuple(a_strides) + tuple(w_strides)), "batch strides % 8"
+            assert a0.storage_offset() % 8 == 0 and w.storage_offset() % 8 == 0, "operand base must be 16-byte aligned"
+            assert residual is None or residual.dtype == self.act_dtype, "residual is an activation-dtype tensor"
         c0 = a0.shape[1]
         c1 = 0 if a1 is None else a1.shape[1]
         cin = c0 + c1

@@ -150,7 +150,7 @@ def test_native_student_engine_reproduces_the_torch_step():
         opt = FlatAdamW(params, sync, lr=1e-3)  # parameters become views of one flat buffer: the engine reads it as it is
         eng = None
         if native:
-            eng = UNetGradEngine(student, EmuOps())
+            eng = UNetGradEngine(student, EmuOps(strict=True))
             eng.bind_lora(params)
         out = []
         for rng in rngs:  # two steps: the second one runs on the updated LoRA tensors (replayed plan, refreshed packs)

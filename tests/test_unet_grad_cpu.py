@@ -32,7 +32,7 @@ def test_unet_grad_engine_matches_autograd():
     x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
     gen = torch.Generator().manual_seed(5)
     r_out = torch.randn(x.shape, generator=gen)
-    eng = UNetGradEngine(m, EmuOps())
+    eng = UNetGradEngine(m, EmuOps(strict=True))
     y = eng.forward_tape(x, ts, ctx, 16, tc, None)
     recorded = [a for a, _ in eng._last["probs"]]
     names = {id(mod): name for name, mod in m.named_modules()}
@@ -67,7 +67,7 @@ def test_unet_grad_engine_batch2_motion_cond():
     m.requires_grad_(False)
     x, ts, ctx, tc, mc = g["x"], g["ts"], g["ctx"], g["tc"], g["mc"]
     r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(11))
-    eng = UNetGradEngine(m, EmuOps())
+    eng = UNetGradEngine(m, EmuOps(strict=True))
     y = eng.forward_tape(x, ts, ctx, 8, tc, mc)
     assert rel_l2(y, g["y"]) < 2e-5
     xg = x.clone().requires_grad_(True)
@@ -90,7 +90,7 @@ def test_motion_prior_score_on_the_gradient_engine():
     latents, example = g["x"].clone(), torch.randn(g["x"].shape, generator=gen)
     ctx = {"context": g["ctx"], "fps": 16, "timestep_cond": g["tc"]}
     score_ref, out_ref = mp.get_motion_prior_score(m, latents.clone(), g["ts"], example, ctx, ctx, 500.0)
-    eng = UNetGradEngine(m, EmuOps())
+    eng = UNetGradEngine(m, EmuOps(strict=True))
     score, out = mp.get_motion_prior_score_native(eng, m, latents.clone(), g["ts"], example, ctx, ctx, 500.0)
     assert rel_l2(out, out_ref.detach()) < 2e-5
     assert float(score_ref.abs().max()) > 0
@@ -106,7 +106,7 @@ def test_gradients_match_the_reference_fixture():
     m.load_state_dict(synth_state_dict(manifest("unet_tiny")), strict=True)
     m.requires_grad_(False)
     m.native_mode = "off"
-    eng = UNetGradEngine(m, EmuOps())
+    eng = UNetGradEngine(m, EmuOps(strict=True))
     y = eng.forward_tape(g["x"], g["ts"], g["ctx"], 16, g["tc"], None)
     assert rel_l2(y, gg["out"]) < 2e-5
     assert rel_l2(eng.backward(gg["r_out"]), gg["dx_out"]) < 1e-4

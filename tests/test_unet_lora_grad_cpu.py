@@ -79,7 +79,7 @@ def test_lora_gradients_match_autograd():
     m, params = _student("unet_tiny", 64)
     x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
     r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
-    eng = UNetGradEngine(m, EmuOps())
+    eng = UNetGradEngine(m, EmuOps(strict=True))
     eng.bind_lora(params)
     # every injected leaf is either the engine's or the conditioning branch's
     assert len(eng.engine_leaves()) * 2 + len(eng.conditioning_parameters()) == len(params)
@@ -109,7 +109,7 @@ def test_lora_gradients_rank16_two_clips_motion_cond():
     m, params = _student("unet_tiny_mg_b2", 16, motion_cond_proj_dim=256)
     x, ts, ctx, tc, mc = g["x"], g["ts"], g["ctx"], g["tc"], g["mc"]
     r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(11))
-    eng = UNetGradEngine(m, EmuOps())
+    eng = UNetGradEngine(m, EmuOps(strict=True))
     eng.bind_lora(params)
     y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 8, tc, mc, r_out)
     y, dx, grads = _engine_step(eng, m, params, x, ts, ctx, 8, tc, mc, r_out)
@@ -149,7 +149,7 @@ def test_lora_gradients_match_the_reference_fixture():
 
     y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 16, tc, None, r_out)
     check(y_ref, dx_ref, g_ref, 1e-4)
-    eng = UNetGradEngine(m, EmuOps())
+    eng = UNetGradEngine(m, EmuOps(strict=True))
     eng.bind_lora(params)
     y, dx, grads = _engine_step(eng, m, params, x, ts, ctx, 16, tc, None, r_out)
     check(y, dx, grads, 2e-4)
