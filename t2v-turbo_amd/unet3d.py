@@ -353,6 +353,37 @@ class ResBlock(TimestepBlock):
 
 
 # =================================================================================== the UNet
+class _NativeStudent(torch.autograd.Function):
+    """UNet forward whose backward — d/d(latents), d/d(emb_all) and every token-row LoRA weight gradient — runs on the native
+    gradient engine.  Inputs: latents, the conditioning branch's output (torch keeps differentiating behind it), and the
+    LoRA tensors the engine owns (so autograd routes their gradients to the optimizer's ``.grad`` slots)."""
+
+    @staticmethod
+    def forward(ctx, x, emb_all, model, args, *leaves):
+        eng = model.native_train_engine()
+        timesteps, context, fps, tc, mc = args
+        y = eng.forward_tape(x.detach(), timesteps, context.detach(), fps, tc, mc, emb_all=emb_all.detach())
+        ctx.model, ctx.plan, ctx.fwd_id = model, eng._last, eng._last["fwd_id"]
+        ctx.leaves = leaves
+        ctx.x_dtype, ctx.e_dtype = x.dtype, emb_all.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.model.native_train_engine()
+        if ctx.plan["fwd_id"] != ctx.fwd_id:
+            raise RuntimeError("native student: another grad-mode forward of the same shape ran before this backward "
+                               "(the engine keeps one outstanding tape per input shape)")
+        eng._last = ctx.plan
+        flat = torch.empty(eng.lora_numel, dtype=torch.float32, device=dout.device)  # fresh: .grad may keep views of it
+        dx = eng.backward(dout, flat_grad=flat, accumulate=False)
+        grads = []
+        for p in ctx.leaves:
+            o = eng.lora_off[id(p)]
+            grads.append(flat[o:o + p.numel()].view_as(p).to(p.dtype))
+        return (dx.to(ctx.x_dtype), eng.d_emb_all.to(ctx.e_dtype).clone(), None, None, *grads)
+
+
 class UNetModel(nn.Module):
     """Same constructor signature as the reference (openaimodel3d.py:340-374)."""
 
@@ -468,7 +499,10 @@ class UNetModel(nn.Module):
                 motion_cond=None, **kwargs):
         if motion_cond is not None:
             assert timestep_cond is not None
-        native = getattr(self, "native_mode", "auto") != "off"  # "off": always the torch path (e.g. a train-mode student)
+        mode = getattr(self, "native_mode", "auto")
+        if mode == "train":  # LoRA student of the distillation step on the native gradient engine (opt-in, see below)
+            return self._forward_native_train(x, timesteps, context, fps, timestep_cond, motion_cond)
+        native = mode != "off"  # "off": always the torch path (e.g. a train-mode student)
         if native and x.is_cuda and not (torch.is_grad_enabled() and self._needs_grad(x, context, timestep_cond)):
             if features_adapter is not None:
                 raise NotImplementedError("features_adapter is not used by t2v-turbo and not supported natively")
@@ -486,6 +520,42 @@ class UNetModel(nn.Module):
             from .native import HipOps
             self._engine_box.engine = UNetEngine(self, HipOps())
         return self._engine_box.engine
+
+    # ---- native LoRA training (native_mode = "train") ---------------------------------------------------------------------
+    def native_train_engine(self, forward_only=False):
+        """Gradient engine with the LoRA tensors bound (engine_lora.py).  Two instances: one whose tape the backward consumes,
+        one for no-grad forwards in between (the distillation step's target forward runs between the student's forward and
+        its backward, train_t2v_turbo_v1_lora.py:1022-1190) — separate buffers, same frozen weights."""
+        slot = "enc" if forward_only else "grad"
+        if getattr(self._engine_box, slot) is None:
+            from . import lora
+            from .engine_unet_bwd import UNetGradEngine
+            make_ops = getattr(self, "_native_ops_factory", None)  # tests substitute the emulated backend
+            if make_ops is None:
+                from .native import HipOps as make_ops
+            eng = UNetGradEngine(self, make_ops())
+            eng.bind_lora(lora.lora_parameters(self))
+            setattr(self._engine_box, slot, eng)
+        return getattr(self._engine_box, slot)
+
+    def _forward_native_train(self, x, timesteps, context, fps, timestep_cond, motion_cond):
+        if not (x.is_cuda or getattr(self, "_native_ops_factory", None) is not None):
+            raise RuntimeError('native_mode = "train" needs CUDA tensors')
+        if context is None:
+            raise ValueError("native LoRA training needs the text context")
+        grad = torch.is_grad_enabled()
+        eng = self.native_train_engine(forward_only=not grad)
+        trainable = {id(p) for p in self.parameters() if p.requires_grad}
+        if trainable - eng.lora_ids:
+            raise RuntimeError('native_mode = "train": only LoRA tensors may require grad (the base weights are frozen packs)')
+        if context.requires_grad or (timestep_cond is not None and timestep_cond.requires_grad):
+            raise RuntimeError('native_mode = "train": gradients flow to the latents and the LoRA tensors only')
+        emb_all = self.conditioning_emb_all(timesteps, fps, timestep_cond, motion_cond)
+        args = (timesteps, context, fps, timestep_cond, motion_cond)
+        if not grad:
+            return eng.forward_tape(x, *args, emb_all=emb_all)
+        leaves = [p for mod in eng.engine_leaves() for p in (mod.lora_up.weight, mod.lora_down.weight)]
+        return _NativeStudent.apply(x, emb_all, self, args, *leaves)
 
     def _embedding(self, timesteps, fps, timestep_cond, motion_cond):
         """Time (+ guidance-scale, + motion) and fps embedding, one row per clip (openaimodel3d.py:683-706)."""

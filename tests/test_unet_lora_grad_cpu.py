@@ -153,3 +153,36 @@ def test_lora_gradients_match_the_reference_fixture():
     eng.bind_lora(params)
     y, dx, grads = _engine_step(eng, m, params, x, ts, ctx, 16, tc, None, r_out)
     check(y, dx, grads, 2e-4)
+
+
+def test_module_dispatch_native_train_mode():
+    """``unet.native_mode = "train"``: the module's own ``forward`` / ``loss.backward()`` (what the reference's trainer
+    calls, train_t2v_turbo_v1_lora.py:1022-1028,1190) run on the gradient engine through an autograd.Function; a no-grad
+    forward between the student's forward and its backward (the target forward, :1163-1170) does not disturb the tape."""
+    g = load("unet_tiny")
+    m, params = _student("unet_tiny", 64)
+    x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
+    y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 16, tc, None, r_out)
+    with torch.no_grad():
+        y2_ref = m(x * 0.5, torch.tensor([279]), context=ctx, fps=16, timestep_cond=tc)
+    m._native_ops_factory = lambda: EmuOps(strict=True)
+    m.native_mode = "train"
+    for p in params:
+        p.grad = None
+    xg = x.clone().requires_grad_(True)
+    y = m(xg, ts, context=ctx, fps=16, timestep_cond=tc)
+    with torch.no_grad():
+        y2 = m(x * 0.5, torch.tensor([279]), context=ctx, fps=16, timestep_cond=tc)
+    (y * r_out).sum().backward()
+    assert rel_l2(y.detach(), y_ref) < 2e-5 and rel_l2(y2, y2_ref) < 2e-5
+    assert rel_l2(xg.grad, dx_ref) < 1e-4
+    _compare(params, [p.grad for p in params], g_ref, m)
+    # a base weight that requires grad is refused (frozen packs)
+    m.out[2].conv.weight.requires_grad_(True)
+    try:
+        m(x, ts, context=ctx, fps=16, timestep_cond=tc)
+    except RuntimeError:
+        pass
+    else:
+        raise AssertionError
