@@ -258,6 +258,14 @@ int t2v_sumsq(const float* x, long long n, float* ws, float* out, void* stream);
  * train_t2v_turbo_v1_lora.py:1190). */
 int t2v_gather_f32(const float* src, const int* idx, float alpha, void* out, int dt_out, int accumulate, long long n,
                    void* stream);
+/* t2v_dropout_bf16: out[r][c] = keep(r, c) ? x[r][c] / (1 - p) : 0  (+ resid[r][c]) over rows x ncols bf16 (ncols even), where
+ * keep is a pure function of (*seed, site, r * ncols + c): splitmix64(seed + site * 0x9E3779B97F4A7C15 + pair * 0xD1B54A32D192ED03)
+ * per pair of adjacent columns, low / high 32 bits compared with p * 2^32.  The backward calls it again with the same (seed,
+ * site) on the gradient.  seed: device pointer to one uint64 (a replayed launch list follows the step's seed).  In-place is
+ * allowed (out == x).  Replaces nn.Dropout in LoraInjected*.forward (utils/lora.py:45-50,124-129) and TemporalConvBlock
+ * (openaimodel3d.py:280-297); the random stream is not torch's (train-mode parity is statistical). */
+int t2v_dropout_bf16(const void* x, int ldx, const void* resid, int ldr, void* out, int ldo, long long rows, int ncols, float p,
+                     const void* seed, unsigned site, void* stream);
 
 #ifdef __cplusplus
 }

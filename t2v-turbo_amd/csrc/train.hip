@@ -37,3 +37,81 @@ extern "C" int t2v_gather_f32(const float* src, const int* idx, float alpha, voi
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Dropout with a counter-based mask: keep(row, col) is a pure function of (seed, site, row * ncols + col), so the backward
+// regenerates the forward's mask instead of storing it (nn.Dropout in LoraInjected*.forward, utils/lora.py:45-50,124-129,
+// and in TemporalConvBlock conv2..4, openaimodel3d.py:280-297).  One splitmix64 finaliser per PAIR of adjacent columns
+// (low / high 32 bits).  out = keep ? x / (1 - p) : 0   (+ resid).  `seed` lives in device memory: a replayed launch list
+// sees the step's seed without being re-recorded.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ uint64_t dropout_bits(uint64_t seed, uint32_t site, uint64_t pair) {
+    return splitmix64(seed + (uint64_t)site * 0x9E3779B97F4A7C15ull + pair * 0xD1B54A32D192ED03ull);
+}
+
+template <bool VEC8>
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ resid, int ldr,
+                                                      bf16_t* __restrict__ out, int ldo, long long rows, int ncols,
+                                                      const uint64_t* __restrict__ seed_p, uint32_t site, uint32_t thr, float inv_keep) {
+    constexpr int W = VEC8 ? 8 : 2;
+    const int per_row = ncols / W;
+    const long long total = rows * per_row;
+    const uint64_t seed = *seed_p;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / per_row;
+        const int c = (int)(i - r * per_row) * W;
+        const uint64_t pair0 = (uint64_t)(r * ncols + c) >> 1;
+        float v[W], rs[W];
+        if constexpr (VEC8) {
+            unpack8(*(const uint4*)(x + r * ldx + c), v);
+            if (resid) unpack8(*(const uint4*)(resid + r * ldr + c), rs);
+        } else {
+            const uint32_t u = *(const uint32_t*)(x + r * ldx + c);
+            v[0] = __uint_as_float(u << 16); v[1] = __uint_as_float(u & 0xffff0000u);
+            if (resid) { const uint32_t q = *(const uint32_t*)(resid + r * ldr + c); rs[0] = __uint_as_float(q << 16); rs[1] = __uint_as_float(q & 0xffff0000u); }
+        }
+#pragma unroll
+        for (int k = 0; k < W / 2; ++k) {
+            const uint64_t b = dropout_bits(seed, site, pair0 + k);
+            v[2 * k] = ((uint32_t)b >= thr) ? v[2 * k] * inv_keep : 0.f;
+            v[2 * k + 1] = ((uint32_t)(b >> 32) >= thr) ? v[2 * k + 1] * inv_keep : 0.f;
+        }
+        if (resid) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) v[k] += rs[k];
+        }
+        if constexpr (VEC8) *(uint4*)(out + r * ldo + c) = pack8(v);
+        else *(uint32_t*)(out + r * ldo + c) = pack2bf(v[0], v[1]);
+    }
+}
+
+extern "C" int t2v_dropout_bf16(const void* x, int ldx, const void* resid, int ldr, void* out, int ldo, long long rows, int ncols,
+                                float p, const void* seed, unsigned site, void* stream) {
+    T2V_REQUIRE(x && out && seed && rows > 0 && ncols > 0, T2V_EINVAL, "t2v_dropout_bf16: null pointer / empty");
+    T2V_REQUIRE(p >= 0.f && p < 1.f, T2V_EINVAL, "t2v_dropout_bf16: p must be in [0, 1)");
+    T2V_REQUIRE(ncols % 2 == 0 && ldx % 2 == 0 && ldo % 2 == 0 && (!resid || ldr % 2 == 0) && ldx >= ncols && ldo >= ncols, T2V_ESHAPE,
+                "t2v_dropout_bf16: even column count / row strides");
+    T2V_REQUIRE((uintptr_t)x % 4 == 0 && (uintptr_t)out % 4 == 0 && (!resid || (uintptr_t)resid % 4 == 0), T2V_ESHAPE,
+                "t2v_dropout_bf16: 4-byte aligned rows");
+    const double t = (double)p * 4294967296.0;
+    const uint32_t thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    const float inv_keep = 1.0f / (1.0f - p);
+    const bool vec8 = ncols % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && (!resid || ldr % 8 == 0) && (uintptr_t)x % 16 == 0 &&
+                      (uintptr_t)out % 16 == 0 && (!resid || (uintptr_t)resid % 16 == 0);
+    const long long total = rows * (ncols / (vec8 ? 8 : 2));
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (vec8)
+        hipLaunchKernelGGL(dropout_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                           (const bf16_t*)resid, ldr, (bf16_t*)out, ldo, rows, ncols, (const uint64_t*)seed, site, thr, inv_keep);
+    else
+        hipLaunchKernelGGL(dropout_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                           (const bf16_t*)resid, ldr, (bf16_t*)out, ldo, rows, ncols, (const uint64_t*)seed, site, thr, inv_keep);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}

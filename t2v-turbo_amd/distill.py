@@ -13,8 +13,8 @@ student has two paths:
 * ``student_engine=`` a ``UNetGradEngine`` with the LoRA tensors bound (``bind_lora``) — student forward, target forward
   and the whole backward (data gradient + all token-row LoRA weight gradients) on the native engine, un-merged LoRA
   branch, operand packs refreshed from the flat parameters once per step; only the M = B-row conditioning branch
-  (time / fps / guidance MLPs + ``emb_layers``) stays in torch autograd.  Needs ``unet.eval()`` (no dropout: a stated
-  deviation from the reference's train-mode student) and a ``grad_sync`` flat buffer for the gradients to land in.
+  (time / fps / guidance MLPs + ``emb_layers``) stays in torch autograd.  A train-mode student keeps its dropouts
+  (counter-based masks, not torch's random stream).  Needs a ``grad_sync`` flat buffer for the gradients to land in.
 
 The gradient exchange is the single flat all-reduce of ``dist.FlatGradSync``."""
 import torch

@@ -20,7 +20,8 @@ parameters by ONE indexed-gather launch per step (``t2v_gather_f32``); one more 
 GEMM output layout into the flat gradient buffer (``dist.FlatGradSync``) that the all-reduce and ``optim.FlatAdamW`` work
 on.  Leaves of the conditioning branch (time / fps / guidance MLPs, ``emb_layers``: M = B rows) stay in torch autograd; the
 engine hands back d(loss)/d(emb_all), column sums of the ResBlock gradients taken as one more GEMM against a clip-indicator
-row.  Dropout on the LoRA branch / temporal convs is not applied (the engine requires ``.eval()``): DESIGN.md §0.
+row.  A train-mode student's dropouts (LoRA branch, temporal conv blocks) are counter-based masks (``t2v_dropout_bf16``):
+a function of (step seed, site, element), applied in the forward and regenerated in the backward — not torch's random stream.
 
 Status: dataflow verified on CPU against torch autograd (tests/test_unet_lora_grad_cpu.py); not yet run on hardware."""
 import torch
@@ -247,7 +248,9 @@ class LoraTrainMixin:
         return g if g is not None and g.saved is not None else None
 
     # ---- forward: z = residual + sum_i s_i (x (*) D_i) U_i^T ----------------------------------------------------------------
-    def lora_z(self, grp, x, m_out, residual=None, frames=0):
+    row_kind = "rows"  # how torch orders the rows of the current Linear leaves ("rows" | "temporal" | "ctx"): mask replay in tests
+
+    def lora_z(self, grp, x, m_out, residual=None, frames=0, kind_meta=None, kind=None):
         """x: Act (1 or 2 parts, channels padded to the group's ce).  Returns (z buffer to release, z view [m_out, sum N])."""
         ops = self.ops
         nrp = grp.n * grp.rp
@@ -258,12 +261,15 @@ class LoraTrainMixin:
             ops.gemm(x.parts[0], grp.Df, t, M=m_out, N=nrp, a1=x.p1, mode=grp.mode, n_img=x.n_img, h=x.h, wd=x.w, frames=frames)
         zf = self.buf(m_out, _pad(grp.ntot, 8))
         z = zf[:, :grp.ntot]
+        grp.drop = self.drop_site([mm.dropout for mm in grp.mods], kind or (self.row_kind if grp.mode == nt.GEMM_LINEAR else "conv"), kind_meta)
         c0 = 0
         for i in range(grp.n):
-            res = None if residual is None else residual[:, c0:c0 + grp.N[i]]
+            res = None if (residual is None or grp.drop) else residual[:, c0:c0 + grp.N[i]]
             ops.gemm(t[:, i * grp.rp:(i + 1) * grp.rp], grp.Uf[i], z[:, c0:c0 + grp.N[i]], M=m_out, N=grp.N[i],
                      alpha=grp.scale[i], residual=res)
             c0 += grp.N[i]
+        if grp.drop:  # train mode: dropout(up(down(x))) * scale (utils/lora.py:45-50), then the leaf's own residual
+            ops.dropout(z, None if residual is None else residual[:, :grp.ntot], z, grp.ntot, grp.drop[0], self.seed_t, grp.drop[1])
         self.hold(*x.parts)
         grp.saved = (x, t)
         return zf, z
@@ -290,6 +296,13 @@ class LoraTrainMixin:
         x, t = grp.saved
         m = dy.shape[0]
         mp = _pad(m, 64)
+        dy_plain = dy
+        if grp.drop:  # the LoRA branch saw dy through the forward's mask; the base leaf and the row vector see dy itself
+            dym = self.buf(m, dy.shape[1])
+            if dy.shape[1] != grp.ntot:
+                ops.fill_zero(dym)
+            ops.dropout(dy, None, dym, grp.ntot, grp.drop[0], self.seed_t, grp.drop[1])
+            dy = dym
         dyT = self.tposed(dy, m, dy.shape[1])
         tT = self.tposed(t, m, t.shape[1])
         g = self.buf(m, grp.n * grp.rp)
@@ -302,7 +315,14 @@ class LoraTrainMixin:
             c0 += grp.npad[i]
         if colsum is not None:
             ind = self.clip_indicator(m)
-            ops.gemm(ind, dyT[:grp.N[0]], colsum, M=ind.shape[0], N=grp.N[0], split_k=self.split_for(ind.shape[0], grp.N[0], mp))
+            src = dyT
+            if grp.drop:
+                src = self.tposed(dy_plain, m, dy_plain.shape[1])
+            ops.gemm(ind, src[:grp.N[0]], colsum, M=ind.shape[0], N=grp.N[0], split_k=self.split_for(ind.shape[0], grp.N[0], mp))
+            if grp.drop:
+                self.pool.put(src)
+        if grp.drop:
+            self.pool.put(dy)
         self.pool.put(dyT, tT, t)
         return g
 

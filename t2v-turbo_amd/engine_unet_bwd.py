@@ -34,20 +34,38 @@ from .unet3d import Downsample, ResBlock, SpatialTransformer, TemporalTransforme
 
 class UNetGradEngine(LoraTrainMixin, UNetEngine):
     # ---- public: forward with tape, then backward ----------------------------------------------------------------
-    def forward_tape(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None, emb_all=None):
+    def _active_dropouts(self):
+        """Number of active Dropout(p > 0) modules; in LoRA training they must all be ones the engine (or torch's conditioning
+        branch) applies: the LoRA branches' and the temporal conv blocks' (train-mode student, train_t2v_turbo_v1_lora.py:641)."""
+        m = self.model
+        active = [mod for mod in m.modules() if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training]
+        if active and self.training_lora:
+            from .unet3d import TemporalConvBlock
+            known = {id(mod.dropout) for mod in m.modules() if is_lora_leaf(mod)}
+            for blk in m.modules():
+                if isinstance(blk, TemporalConvBlock):
+                    known.update(id(l) for st in (blk.conv1, blk.conv2, blk.conv3, blk.conv4) for l in st if isinstance(l, nn.Dropout))
+            other = [mod for mod in active if id(mod) not in known]
+            if other:
+                raise RuntimeError(f"native LoRA training: {len(other)} active Dropout module(s) the engine does not apply")
+        return len(active)
+
+    def forward_tape(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None, emb_all=None, seed=None):
         """``emb_all`` (LoRA training only): the conditioning branch's output [B, sum of ResBlock widths] fp32, computed by
         the caller in torch (``conditioning_torch``) so that autograd owns that branch's 27 tiny leaves."""
         m = self.model
         assert x.dim() == 5 and context is not None
         assert (emb_all is not None) == self.training_lora, "emb_all is given exactly when LoRA tensors are bound"
         self._check_weights(m, self.lora_ids if self.training_lora else ())
-        for mod in m.modules():
-            if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training:
-                raise RuntimeError("native UNet gradient path: a Dropout(p>0) is in training mode; call .eval() first")
-        key = ("grad", tuple(x.shape), x.dtype, tuple(context.shape), context.dtype, isinstance(fps, int),
+        dropping = self._active_dropouts()
+        if dropping and not self.training_lora:
+            raise RuntimeError("native UNet gradient path: a Dropout(p>0) is in training mode; call .eval() first")
+        key = ("grad", dropping, tuple(x.shape), x.dtype, tuple(context.shape), context.dtype, isinstance(fps, int),
                None if timestep_cond is None else tuple(timestep_cond.shape),
                None if motion_cond is None else tuple(motion_cond.shape), x.device, self.training_lora)
         plan = self.plans.get(key)
+        if dropping:  # one seed per forward; the backward regenerates the same masks from it
+            self._seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
         if plan is None:
             plan = self._record_grad(x, timesteps, context, fps, timestep_cond, motion_cond, emb_all)
             self.plans[key] = plan
@@ -67,6 +85,10 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             if emb_all is not None:
                 st["emb_all"].copy_(emb_all.detach())
                 self.refresh_lora_packs()
+            if dropping:
+                st["seed"].fill_(self._seed)
+            if "seed" in st:
+                self.seed_t = st["seed"]
             self._replay(plan, "rec")
         plan["fwd_id"] = plan.get("fwd_id", 0) + 1
         self._last = plan
@@ -137,12 +159,15 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             self._lora_begin()
             st["emb_all"] = emb_all.detach().to(x.device, torch.float32).clone().contiguous()
             plan["d_emb"] = torch.zeros_like(st["emb_all"])
+            st["seed"] = torch.full((1,), getattr(self, "_seed", 0), dtype=torch.int64, device=x.device)
+            self.seed_t = st["seed"]
         self.plan = plan
         self.tape, self.refs = [], {}
 
         def fwd():
             self.tape.clear()
             self.refs.clear()
+            self.drop_sites = []
             plan["probs"].clear()
             self._forward_tape(st, out)
 
@@ -219,6 +244,18 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         return self.pk._memo((tag,) + tuple(id(mm) for mm in mods),
                              lambda: self.pk.cat_mats(mods, tag + "_fwd").t().contiguous())
 
+    def drop_site(self, drops, kind, meta=None):
+        """(p, site id) of an active dropout (None if inactive).  ``drops``: the nn.Dropout module(s) this site stands for
+        (one per leaf of a LoRA group); kind / meta describe the row order for tests that replay the masks in torch."""
+        ps = {(d.p if d.training else 0.0) for d in drops}
+        assert len(ps) == 1, "leaves of one LoRA group must share the dropout probability"
+        p = ps.pop()
+        if p <= 0:
+            return None
+        assert self.training_lora, "dropout is only applied on the LoRA training path"
+        self.drop_sites.append((drops, kind, meta))
+        return float(p), len(self.drop_sites) - 1
+
     def rel(self, *ts):
         """Forward-side release of an intermediate: kept alive while a backward closure / LoRA group still holds it."""
         for t in ts:
@@ -226,7 +263,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 self.pool.put(t)
 
     # ---- leaves: forward with the LoRA branch (training), backward with the LoRA weight gradients -----------------------
-    def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None, lora=None, perm=None):
+    def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None, lora=None, perm=None,
+               conv_geom=None):
         """``a``: tensor or two-part Act.  ``lora``: the injected leaves whose row-concatenated weights ``w`` holds (default:
         [mod]); ``perm``: packed output row j = original row perm[j] (GEGLU packing)."""
         x = a if isinstance(a, Act) else Act(a, 0, 0, 0)
@@ -234,7 +272,11 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         zf = None
         if self.training_lora and mods and all(is_lora_leaf(mm) for mm in mods):
             assert act == nt.ACT_NONE
-            zf, residual = self.lora_z(self.lgroup(mods, nt.GEMM_LINEAR, perm), x, x.M, residual)
+            meta = (self.B, self.F, x.M // (self.B * self.F)) if self.row_kind == "temporal" else (self.B, self.F, self.ctx_len)
+            if conv_geom is not None:  # a 1x1 conv run as a linear layer: torch sees (n, C, h, w)
+                meta = conv_geom
+            zf, residual = self.lora_z(self.lgroup(mods, nt.GEMM_LINEAR, perm), x, x.M, residual, kind_meta=meta,
+                                       kind="conv" if conv_geom is not None else None)
         w = self.pk.mat(mod) if w is None else w
         bias = self.pk.bias(mod) if isinstance(bias, str) else bias
         N = w.shape[0] if N is None else N
@@ -248,12 +290,12 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         zf = None
         if w is None and self.training_lora and is_lora_leaf(mod):
             if mode == nt.GEMM_CONV3X3_S2:
-                m_out = x.n_img * ((x.h - 1) // 2 + 1) * ((x.w - 1) // 2 + 1)
+                ho, wo = (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1
             elif mode == nt.GEMM_CONV3X3_UP2:
-                m_out = x.n_img * 4 * x.h * x.w
+                ho, wo = 2 * x.h, 2 * x.w
             else:
-                m_out = x.M
-            zf, residual = self.lora_z(self.lgroup([mod], mode), x, m_out, residual, frames)
+                ho, wo = x.h, x.w
+            zf, residual = self.lora_z(self.lgroup([mod], mode), x, x.n_img * ho * wo, residual, frames, kind_meta=(x.n_img, ho, wo))
         y = super().conv(x, mod, mode, frames=frames, rowvec=rowvec, rowvec_div=rowvec_div, residual=residual,
                          out_dtype=out_dtype, w=w, bias=bias)
         if zf is not None:
@@ -351,7 +393,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             x64 = self.buf(B * F * H * W, 64)
             ops.fill_zero(x64)
             ops.ncfhw_to_tokens(x, x64)
-            zf, z = self.lora_z(self.lgroup([conv_in], nt.GEMM_CONV3X3), Act(x64, B * F, H, W), B * F * H * W)
+            zf, z = self.lora_z(self.lgroup([conv_in], nt.GEMM_CONV3X3), Act(x64, B * F, H, W), B * F * H * W, kind_meta=(B * F, H, W))
             h0b = self.add(h0, z)
             self.pool.put(h0, zf)
             h0 = h0b
@@ -477,8 +519,10 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         B, L = self.B, self.ctx_len
         inner = attn.heads * attn.dim_head
         kp = _pad(L, 64)
+        kind, self.row_kind = self.row_kind, "ctx"  # (under dropout the frames of a clip share the K / V masks: DESIGN.md)
         k = self.linear(self.ctx, attn.to_k, bias=None)
         v = self.linear(self.ctx, attn.to_v, bias=None)
+        self.row_kind = kind
         vt = self.buf(B * inner, kp)
         ops.fill_zero(vt)
         ops.transpose(v, L, inner, vt, batch=B, in_stride=L * inner, out_stride=inner * kp)
@@ -549,7 +593,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         else:
             sc = rb.skip_connection
             assert effective_weight_bias(sc)[0].shape[-1] == 1, "3x3 skip convs are not built by the VideoCrafter2 config"
-            skip = self.linear(x, sc)
+            skip = self.linear(x, sc, conv_geom=(n, x.h, x.w))
             own = True
         h2 = self.conv(Act(t2, n, x.h, x.w), rb.out_layers[3], nt.GEMM_CONV3X3, residual=skip)
         self.rel(t2)
@@ -592,16 +636,21 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         y = h2
         for i, stage in enumerate(stages):
             tt, st = self.gn_t(y, stage[0], B, F * hw, True)
+            site = self.drop_site([l for l in stage if isinstance(l, nn.Dropout)], "tconv", (B, F, h2.h, h2.w)) if len(stage) > 3 else None
+            if site is not None:  # train-mode student: Dropout between SiLU and the (3,1,1) conv (openaimodel3d.py:280-297)
+                self.ops.dropout(tt, None, tt, tt.shape[1], site[0], self.seed_t, site[1])
             ny = self.conv(Act(tt, *geom), stage[-1], nt.GEMM_TCONV3, frames=F, residual=h2.t if i == 3 else None)
             self.rel(tt)
-            saved.append((y, st))
+            saved.append((y, st, site))
             y = ny
 
         def bwd(dy):
             d = dy.t
             for i in (3, 2, 1, 0):
-                yi, st = saved[i]
+                yi, st, site = saved[i]
                 d_tt = self.conv_b(Act(d, *geom), stages[i][-1], nt.GEMM_TCONV3, geom, frames=F)
+                if site is not None:
+                    self.ops.dropout(d_tt.t, None, d_tt.t, d_tt.t.shape[1], site[0], self.seed_t, site[1])
                 if i != 3:
                     self.pool.put(d)
                 nd = self.gn_b(yi, stages[i][0], B, F * hw, True, st, d_tt.t, resid=dy.t if i == 0 else None)
@@ -649,6 +698,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         B, F = self.B, self.F
         n, hw = x.n_img, x.h * x.w
         units, rows = (B, F * hw) if temporal else (B * F, hw)
+        self.row_kind = "temporal" if temporal else "rows"
         self.hold(x.t)
         t, stats = self.gn_t(x, tr.norm, units, rows, False)
         y = self.linear(t, tr.proj_in)

@@ -108,6 +108,8 @@ _SIGS = {
     "t2v_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_longlong, C.c_void_p]),
     "t2v_sumsq": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2v_gather_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p]),
+    "t2v_dropout_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float,
+                                   C.c_void_p, C.c_uint, C.c_void_p]),
     "t2v_lcm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
@@ -375,6 +377,12 @@ class HipOps:
         """out.flat[i] = alpha * src.flat[idx[i]] (0 where idx < 0), or += with ``accumulate``; src fp32, idx int32."""
         assert src.dtype == torch.float32 and idx.dtype == torch.int32 and idx.numel() == out.numel()
         self._call("t2v_gather_f32", _p(src), _p(idx), alpha, _p(out), _DT[out.dtype], 1 if accumulate else 0, out.numel())
+
+    def dropout(self, x, resid, out, ncols, p, seed, site):
+        """out[:, :ncols] = dropout(x[:, :ncols]) (+ resid); mask = f(seed[0], site, row * ncols + col); seed: int64 device tensor."""
+        assert seed.dtype == torch.int64 and x.dtype == torch.bfloat16 and out.dtype == torch.bfloat16
+        self._call("t2v_dropout_bf16", _p(x), _row_stride(x), _p(resid), 0 if resid is None else _row_stride(resid), _p(out),
+                   _row_stride(out), x.shape[0], ncols, p, _p(seed), site)
 
     def lcm_step(self, x, eps, noise, sa_t, sb_t, c_skip, c_out, sa_p, sb_p, prev, denoised):
         self._call("t2v_lcm_step", _p(x), _p(eps), _DT[eps.dtype], _p(noise), sa_t, sb_t, c_skip, c_out, sa_p, sb_p,

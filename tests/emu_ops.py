@@ -359,6 +359,36 @@ class EmuOps:
         else:
             o.copy_(v.to(out.dtype))
 
+    @staticmethod
+    def dropout_keep(seed, site, rows, ncols, p):
+        """The device kernel's mask, bit for bit (csrc/train.hip): splitmix64 per pair of adjacent columns."""
+        import numpy as np
+        assert ncols % 2 == 0
+        m64 = np.uint64
+        with np.errstate(over="ignore"):
+            pair = np.arange(rows * ncols // 2, dtype=np.uint64)
+            z = m64(seed & 0xFFFFFFFFFFFFFFFF) + m64(site) * m64(0x9E3779B97F4A7C15) + pair * m64(0xD1B54A32D192ED03)
+            z ^= z >> m64(30)
+            z *= m64(0xBF58476D1CE4E5B9)
+            z ^= z >> m64(27)
+            z *= m64(0x94D049BB133111EB)
+            z ^= z >> m64(31)
+        t = p * 4294967296.0
+        thr = np.uint64(0xFFFFFFFF if t >= 4294967295.0 else int(t))
+        lo, hi = z & m64(0xFFFFFFFF), z >> m64(32)
+        keep = np.stack([lo >= thr, hi >= thr], axis=1).reshape(rows, ncols)
+        return torch.from_numpy(keep)
+
+    def dropout(self, x, resid, out, ncols, p, seed, site):
+        self._log("dropout")
+        keep = self.dropout_keep(int(seed.reshape(-1)[0]), site, x.shape[0], ncols, p)
+        if getattr(self, "masks", None) is not None:
+            self.masks[site] = keep
+        v = torch.where(keep, x[:, :ncols].float() / (1.0 - p), torch.zeros(()))
+        if resid is not None:
+            v = v + resid[:, :ncols].float()
+        out[:, :ncols] = v.to(out.dtype)
+
     def lcm_step(self, x, eps, noise, sa_t, sb_t, c_skip, c_out, sa_p, sb_p, prev, denoised):
         self._log("lcm_step")
         x0 = (x - sb_t * eps.float()) / sa_t

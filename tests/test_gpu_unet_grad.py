@@ -223,3 +223,25 @@ def test_lora_training_engine_on_gpu_vs_autograd(monkeypatch):
         cond = eng.conditioning_parameters()
         e = [rel_l2(p.grad.cpu(), g_ref[[id(q) for q in params].index(id(p))]) for p in cond[:6]]
         assert max(e) < 6e-2, e
+
+
+@pytest.mark.parametrize("rows,ncols,ld,p,resid", [(100, 320, 320, 0.1, True), (77, 4, 8, 0.1, True), (50, 130, 136, 0.5, False),
+                                                   (40960, 64, 192, 0.1, False)])
+def test_dropout_mask_is_the_emulated_one(ops, rows, ncols, ld, p, resid):
+    """Counter-based dropout: the device mask must be bit-identical to the emulation's (the CPU suite checks the engine's use
+    of that mask against autograd), in-place and with a residual, vector and pair paths."""
+    hip, emu = ops
+    x = _rt(rows, ld, seed=1) + 3.0          # no zeros: the mask is readable from the output
+    r = _rt(rows, ld, seed=2)
+    seed = torch.tensor([0x1234_5678_9ABC], dtype=torch.int64)
+    keep = emu.dropout_keep(int(seed[0]), 7, rows, ncols, p)
+    o_h = _dev(x)
+    hip.dropout(o_h, _dev(r) if resid else None, o_h, ncols, p, seed.cuda(), 7)
+    torch.cuda.synchronize()
+    ref = torch.where(keep, x[:, :ncols] / (1 - p), torch.zeros(())) + (r[:, :ncols] if resid else 0)
+    got = o_h.float().cpu()
+    assert torch.equal(got[:, ncols:], x[:, ncols:])   # columns beyond ncols untouched
+    assert rel_l2(got[:, :ncols], ref) < 5e-3
+    if not resid:
+        assert torch.equal(got[:, :ncols] != 0, keep)
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.02

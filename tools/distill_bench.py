@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--tiny", type=int, default=0, help="toy widths (plumbing check)")
     ap.add_argument("--rank-r", type=int, default=64)
     ap.add_argument("--native-student", type=int, default=0,
-                    help="1: student forward / target forward / backward on the native gradient engine (eval mode, no dropout; "
+                    help="1: student forward / target forward / backward on the native gradient engine (train mode, native dropout; "
                          "needs T2V_UNVALIDATED_KERNELS=1 until its kernels have run on hardware)")
     a = ap.parse_args()
     import bench
@@ -67,7 +67,7 @@ def main():
         from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
         from t2v_turbo_amd.native import HipOps
         from t2v_turbo_amd.optim import FlatAdamW
-        student.eval()                       # the engine applies no dropout
+        student.train()                      # LoRA / temporal-conv dropouts: counter-based masks on the engine
         student.native_mode = "off"
         with torch.no_grad():                # lora_up starts at zero; give the down gradients something to do
             for p in params:
