@@ -167,3 +167,47 @@ def test_native_student_engine_reproduces_the_torch_step():
         assert abs(float(l0) - float(l1)) < 1e-5 * max(1.0, abs(float(l0)))
         assert rel_l2(g1, g0) < 2e-4
     assert rel_l2(p_got, p_ref) < 1e-4  # Adam's first steps move every element by ~lr * sign(g): near-zero gradients may flip
+
+
+def test_native_student_in_train_mode_runs_the_step():
+    """The reference's student is in train mode (train_t2v_turbo_v1_lora.py:641): with the engine's own dropout masks the step
+    runs end to end — finite loss, gradients on every LoRA tensor, the no-grad target forward drawing its own masks."""
+    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+    from tests.emu_ops import EmuOps
+    sd = synth_state_dict(manifest("unet_tiny"))
+    teacher = UNetModel(**tiny_unet_params(time_cond_proj_dim=None)).eval()
+    teacher.load_state_dict({k: v for k, v in sd.items() if not k.startswith("time_cond_proj")}, strict=True)
+    teacher.requires_grad_(False)
+    student = UNetModel(**tiny_unet_params())
+    student.load_state_dict(sd, strict=True)
+    student.requires_grad_(False)
+    lora.inject_trainable_lora_extended(student, r=16)
+    student.train()
+    student.native_mode = "off"
+    params = lora.lora_parameters(student)
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in params:
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.05)
+    sync = FlatGradSync(params)
+    eng = UNetGradEngine(student, EmuOps(strict=True))
+    eng.bind_lora(params)
+    sched = T2VTurboScheduler()
+    solver = cd_math.DDIMSolver(sched.alphas_cumprod.numpy(), ddim_timesteps=50)
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(1, 4, 2, 8, 8, generator=g)
+    pe, ue = torch.randn(1, 77, 128, generator=g), torch.randn(1, 77, 128, generator=g)
+    rng = dict(index=torch.tensor([12]), noise=torch.randn(lat.shape, generator=g), w=torch.tensor([7.0]))
+    losses = []
+    for _ in range(2):
+        sync.zero_()
+        loss, info = distill_step(student, teacher, solver, sched, lat, pe, ue, grad_sync=sync, rng=rng, student_engine=eng)
+        assert torch.isfinite(loss) and torch.isfinite(sync.flat).all()
+        off, live = 0, 0
+        for p in params:
+            live += int(float(sync.flat[off:off + p.numel()].abs().max()) > 0)
+            off += p.numel()
+        assert live >= len(params) - 8  # (q / k of the one-token spatial attention at the lowest level get none)
+        losses.append(float(loss))
+    assert len(eng.drop_sites) > 100
+    assert losses[0] != losses[1]  # same inputs, new masks
