@@ -124,11 +124,32 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         return plan["dx"].clone()
 
     def _replay(self, plan, which):
+        """Replay one of the two recorded launch lists; with ``use_graph`` (T2V_HIP_GRAPH=1) each list is captured into its own
+        hipGraph after its first plain replay (thousands of launches per list: the Python / ctypes loop would otherwise set
+        the pace).  Everything that changes between steps lives in static device buffers (inputs, LoRA operand packs, seed)."""
         ops = self.ops
-        if getattr(ops, "is_native", False):
-            ops.replay(plan[which], ops.stream())
-        else:
+        if not getattr(ops, "is_native", False):
             plan["fn" if which == "rec" else "fn_bwd"]()
+            return
+        gkey, rkey = "graph_" + which, "runs_" + which
+        if plan.get(gkey) is not None:
+            plan[gkey].replay()
+            return
+        if self.use_graph and plan.get(rkey, 0) >= 1 and not plan.get("graph_failed"):
+            try:
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    ops.replay(plan[which], ops.stream())
+                plan[gkey] = g
+                g.replay()
+                return
+            except Exception as e:  # capture unsupported -> stay on plain replay, loudly
+                plan["graph_failed"] = str(e)
+                import warnings
+                warnings.warn(f"hipGraph capture of the {which} list failed, replaying launches instead: {e}")
+        ops.replay(plan[which], ops.stream())
+        plan[rkey] = plan.get(rkey, 0) + 1
 
     # ---- recording ------------------------------------------------------------------------------------------------
     def _record_grad(self, x, timesteps, context, fps, timestep_cond, motion_cond, emb_all=None):
