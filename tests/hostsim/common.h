@@ -1,0 +1,56 @@
+// Host-simulator replacement of csrc/common.h (found first on the include path): the same helpers in plain C++.
+// TEST INFRASTRUCTURE ONLY.  The bf16 conversions are the library's own code (round-to-nearest-even); pack2bf is the
+// software equivalent of v_cvt_pk_bf16_f32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "t2v_hip.h"
+
+typedef uint16_t bf16_t;
+#define T2V_WAVE 64
+
+inline float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+inline bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+inline uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+inline void unpack8(const uint4& v, float* f) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+inline uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]);
+    v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+inline float silu_f(float x) { return x * (1.0f / (1.0f + expf(-x))); }
+inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+inline float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+inline float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+inline std::string& t2v_err() { static std::string e; return e; }
+inline void t2v_set_error(const char* msg) { t2v_err() = msg; }
+inline const void* t2v_zero_page() { static char z[256] = {0}; return z; }
+#define T2V_CHECK_LAUNCH() do { } while (0)
+#define T2V_REQUIRE(cond, code, msg) \
+    do {                             \
+        if (!(cond)) {               \
+            t2v_set_error(msg);      \
+            return code;             \
+        }                            \
+    } while (0)

@@ -231,7 +231,7 @@ def test_dropout_mask_is_the_emulated_one(ops, rows, ncols, ld, p, resid):
     """Counter-based dropout: the device mask must be bit-identical to the emulation's (the CPU suite checks the engine's use
     of that mask against autograd), in-place and with a residual, vector and pair paths."""
     hip, emu = ops
-    x = _rt(rows, ld, seed=1) + 3.0          # no zeros: the mask is readable from the output
+    x = (_rt(rows, ld, seed=1) + 3.0).bfloat16().float()  # no zeros: the mask is readable from the output
     r = _rt(rows, ld, seed=2)
     seed = torch.tensor([0x1234_5678_9ABC], dtype=torch.int64)
     keep = emu.dropout_keep(int(seed[0]), 7, rows, ncols, p)

@@ -1,0 +1,209 @@
+"""The SIMT-only kernel SOURCES of the library executed on the CPU by a host SIMT simulator (tests/hostsim/: every thread of
+a workgroup is a fiber, __syncthreads / 64-lane shuffles are rendezvous points) and compared with the emulated op backend.
+
+Why: the kernels of the UNet gradient / LoRA training path (csrc/backward_unet.hip, csrc/train.hip) were written after the
+round's GPU budget was spent.  They compile for gfx950, but "compiles" says nothing about index arithmetic, reduction
+order, LDS layout or tail handling — this does: the same C-ABI entry points, the same source files, run thread by thread.
+It does not cover what only hardware shows (wave-level timing, memory model, the gfx950 code generator), and it cannot
+run MFMA / inline-asm / LDS-DMA kernels (t2v_gemm, the attention forwards).
+
+The first tests run kernels that ARE validated on hardware (transpose, sum-pool, softmax backward, single-tensor
+GroupNorm backward): they calibrate the simulator itself."""
+import ctypes as C
+import os
+import sys
+
+import pytest
+import torch
+
+from t2v_turbo_amd import native as nt
+from tests.emu_ops import EmuOps
+from tests.util import rel_l2
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim"))
+
+TOL = 6e-3  # bf16 outputs against the fp32 emulation: the tolerance of the GPU kernel tests
+
+
+class HostSimOps(nt.HipOps):
+    """The tensor-level op wrappers of ``native.HipOps`` bound to the host-simulated build of the same kernel sources."""
+
+    def __init__(self, lib_path):
+        self.lib = C.CDLL(lib_path)
+        for name, (res, args) in nt._SIGS.items():
+            if hasattr(self.lib, name):
+                fn = getattr(self.lib, name)
+                fn.restype, fn.argtypes = res, args
+        self.recording = None
+        self._keep = []
+
+    @staticmethod
+    def stream():
+        return None
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import shutil
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    import build as hostsim_build
+    return HostSimOps(hostsim_build.build()), EmuOps()
+
+
+def _rt(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).bfloat16().float()
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).contiguous()
+
+
+# ---------------------------------------------------------------------------------- simulator calibration (validated kernels)
+@pytest.mark.parametrize("rows,cols,batch", [(100, 70, 1), (64, 128, 3), (77, 320, 2)])
+def test_sim_transpose(ops, rows, cols, batch):
+    sim, emu = ops
+    src = _rt(batch * rows, cols, seed=1)
+    rp = (rows + 63) // 64 * 64
+    o_s = torch.zeros(batch * cols, rp, dtype=torch.bfloat16)
+    o_e = torch.zeros(batch * cols, rp)
+    sim.transpose(_bf(src), rows, cols, o_s, batch=batch, in_stride=rows * cols, out_stride=cols * rp)
+    emu.transpose(src, rows, cols, o_e, batch=batch, in_stride=rows * cols, out_stride=cols * rp)
+    assert torch.equal(o_s.float(), o_e)
+
+
+def test_sim_sumpool_and_softmax_bwd(ops):
+    sim, emu = ops
+    n, h, w, Cc = 2, 3, 5, 64
+    src = _rt(n * 2 * h * 2 * w, Cc, seed=1)
+    o_s, o_e = torch.zeros(n * h * w, Cc, dtype=torch.bfloat16), torch.zeros(n * h * w, Cc)
+    sim.sumpool2x2(_bf(src), n, h, w, o_s)
+    emu.sumpool2x2(src, n, h, w, o_e)
+    assert rel_l2(o_s.float(), o_e) < TOL
+    rows, nn, npad = 37, 77, 128
+    p = torch.zeros(rows, npad)
+    p[:, :nn] = torch.softmax(_rt(rows, nn, seed=2), dim=1)
+    p = p.bfloat16().float()
+    dp = _rt(rows, npad, seed=3)
+    d_s, d_e = _bf(dp), dp.clone()
+    sim.softmax_bwd_rows(_bf(p), d_s, rows, nn, npad, npad)
+    emu.softmax_bwd_rows(p, d_e, rows, nn, npad, npad)
+    assert rel_l2(d_s.float(), d_e) < TOL
+
+
+def _gn_bwd_case(sim, emu, c0, c1, units, rows, silu, resid=True):
+    Cc, G = c0 + c1, 32
+    x0, x1 = _rt(units * rows, c0, seed=1), (_rt(units * rows, c1, seed=2) if c1 else None)
+    dy, r = _rt(units * rows, Cc, seed=3), _rt(units * rows, Cc, seed=4)
+    gamma, beta = _rt(Cc, seed=5) * 0.2 + 1.0, _rt(Cc, seed=6) * 0.1
+    stats = torch.zeros(units, 2 * G)
+    emu.gn_stats(x0, x1, units, rows, 1e-5, None, stats, G)
+    o_e = torch.zeros(units * rows, Cc)
+    emu.gn_bwd(x0, units, rows, stats, gamma, beta, silu, dy, r if resid else None, None, o_e, G, x1=x1)
+    ws = torch.zeros(sim.gn_bwd_ws_floats(units, rows, G), dtype=torch.float32)
+    o_s = torch.zeros(units * rows, Cc, dtype=torch.bfloat16)
+    sim.gn_bwd(_bf(x0), units, rows, stats, gamma, beta, silu, _bf(dy), _bf(r) if resid else None, ws, o_s, G,
+               x1=None if x1 is None else _bf(x1))
+    assert rel_l2(o_s.float(), o_e) < TOL
+
+
+def test_sim_gn_bwd_single_tensor_validated_kernel(ops):
+    _gn_bwd_case(*ops, 320, 0, 2, 50, True)      # t2v_gn_bwd: ran on hardware in the VAE decode gradient
+
+
+# ---------------------------------------------------------------------------------- kernels that have not run on hardware yet
+@pytest.mark.parametrize("c0,c1,units,rows,silu", [(1280, 1280, 2, 40, True), (1280, 640, 1, 90, True), (320, 320, 3, 33, False),
+                                                   (2560, 0, 1, 64, True)])
+def test_gn_bwd_two_part(ops, c0, c1, units, rows, silu):
+    _gn_bwd_case(*ops, c0, c1, units, rows, silu)
+
+
+@pytest.mark.parametrize("M,Cc,resid", [(21, 320, True), (9, 1280, False), (6, 512, True), (5, 2048, True), (3, 64, False)])
+def test_layernorm_bwd(ops, M, Cc, resid):
+    sim, emu = ops
+    x, dy, r = _rt(M, Cc, seed=1), _rt(M, Cc, seed=2), _rt(M, Cc, seed=3)
+    gamma = _rt(Cc, seed=4) + 1.0
+    o_s, o_e = torch.zeros(M, Cc, dtype=torch.bfloat16), torch.zeros(M, Cc)
+    sim.layernorm_bwd(_bf(x), gamma, 1e-5, _bf(dy), _bf(r) if resid else None, o_s)
+    emu.layernorm_bwd(x, gamma, 1e-5, dy, r if resid else None, o_e)
+    assert rel_l2(o_s.float(), o_e) < TOL
+
+
+def test_geglu_fwd_bwd(ops):
+    sim, emu = ops
+    M, inner = 19, 256
+    h, dy = _rt(M, 2 * inner, seed=1), _rt(M, inner, seed=2)
+    o_s, o_e = torch.zeros(M, inner, dtype=torch.bfloat16), torch.zeros(M, inner)
+    sim.geglu_fwd(_bf(h), o_s)
+    emu.geglu_fwd(h, o_e)
+    d_s, d_e = torch.zeros(M, 2 * inner, dtype=torch.bfloat16), torch.zeros(M, 2 * inner)
+    sim.geglu_bwd(_bf(h), _bf(dy), d_s)
+    emu.geglu_bwd(h, dy, d_e)
+    assert rel_l2(o_s.float(), o_e) < TOL and rel_l2(d_s.float(), d_e) < TOL
+
+
+@pytest.mark.parametrize("h,w,H,W", [(5, 8, 10, 16), (3, 4, 5, 7)])
+def test_scatter2x_and_add(ops, h, w, H, W):
+    sim, emu = ops
+    n, Cc = 3, 64
+    src = _rt(n * h * w, Cc, seed=1)
+    o_s = torch.full((n * H * W, Cc), 7.0, dtype=torch.bfloat16)
+    o_e = torch.zeros(n * H * W, Cc)
+    sim.scatter2x(_bf(src), n, h, w, H, W, o_s)
+    emu.scatter2x(src, n, h, w, H, W, o_e)
+    assert torch.equal(o_s.float(), o_e)
+    a, b = _rt(50, 128, seed=2), _rt(50, 192, seed=3)
+    s_s, s_e = torch.zeros(50, 128, dtype=torch.bfloat16), torch.zeros(50, 128)
+    sim.add(_bf(a), _bf(b)[:, 64:], s_s)      # second operand: a column slice (row stride 192)
+    emu.add(a, b[:, 64:], s_e)
+    assert rel_l2(s_s.float(), s_e) < TOL
+
+
+@pytest.mark.parametrize("clips,F,hw,heads,with_dprobs", [(1, 16, 5, 5, True), (2, 4, 9, 2, False), (1, 16, 7, 1, True), (1, 7, 3, 3, True)])
+def test_attn_temporal_bwd(ops, clips, F, hw, heads, with_dprobs):
+    sim, emu = ops
+    M, inner = clips * F * hw, heads * 64
+    qkv = _rt(M, 3 * inner, seed=1, scale=0.7)
+    do = _rt(M, inner, seed=2)
+    dpr = torch.randn(clips * hw * heads, F, F, generator=torch.Generator().manual_seed(3)) if with_dprobs else None
+    g_e = torch.zeros(M, 3 * inner)
+    emu.attn_temporal_bwd(qkv[:, :inner], qkv[:, inner:2 * inner], qkv[:, 2 * inner:], do, dpr, g_e[:, :inner], g_e[:, inner:2 * inner],
+                          g_e[:, 2 * inner:], clips, F, hw, heads, 0.125)
+    qh = _bf(qkv)
+    g_s = torch.zeros(M, 3 * inner, dtype=torch.bfloat16)
+    sim.attn_temporal_bwd(qh[:, :inner], qh[:, inner:2 * inner], qh[:, 2 * inner:], _bf(do), dpr, g_s[:, :inner], g_s[:, inner:2 * inner],
+                          g_s[:, 2 * inner:], clips, F, hw, heads, 0.125)
+    assert rel_l2(g_s.float(), g_e) < TOL
+
+
+@pytest.mark.parametrize("n,out_dtype,acc", [(1000, torch.float32, False), (7001, torch.bfloat16, False), (4097, torch.float32, True),
+                                             (513, torch.bfloat16, True)])
+def test_gather(ops, n, out_dtype, acc):
+    sim, emu = ops
+    gen = torch.Generator().manual_seed(1)
+    src = torch.randn(5000, generator=gen)
+    idx = torch.randint(-1, 5000, (n,), generator=gen, dtype=torch.int32)
+    base = torch.randn(n, generator=gen).to(out_dtype)
+    o_e, o_s = base.clone(), base.clone()
+    emu.gather(src, idx, o_e, alpha=0.5, accumulate=acc)
+    sim.gather(src, idx, o_s, alpha=0.5, accumulate=acc)
+    assert torch.equal(o_s, o_e)
+
+
+@pytest.mark.parametrize("rows,ncols,ld,p,resid", [(100, 320, 320, 0.1, True), (77, 4, 8, 0.1, True), (50, 130, 136, 0.5, False),
+                                                   (33, 64, 192, 0.1, False)])
+def test_dropout_mask_is_the_emulated_one(ops, rows, ncols, ld, p, resid):
+    sim, emu = ops
+    x = (_rt(rows, ld, seed=1) + 3.0).bfloat16().float()  # no zeros: the mask is readable from the output
+    r = _rt(rows, ld, seed=2)
+    seed = torch.tensor([0x1234_5678_9ABC], dtype=torch.int64)
+    keep = emu.dropout_keep(int(seed[0]), 7, rows, ncols, p)
+    o_s = _bf(x)
+    sim.dropout(o_s, _bf(r) if resid else None, o_s, ncols, p, seed, 7)
+    ref = torch.where(keep, x[:, :ncols] / (1 - p), torch.zeros(())) + (r[:, :ncols] if resid else 0)
+    got = o_s.float()
+    assert torch.equal(got[:, ncols:], x[:, ncols:])   # columns beyond ncols untouched
+    assert rel_l2(got[:, :ncols], ref) < 5e-3
+    if not resid:
+        assert torch.equal(got[:, :ncols] != 0, keep)
