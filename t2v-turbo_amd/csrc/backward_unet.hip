@@ -1,6 +1,6 @@
 // Backward (dX) kernels of the UNet data-gradient path (engine_unet_bwd.py; include/t2v_hip.h "backward (dX) pieces of the UNet").
-// NOT yet run on hardware: written after the round's GPU budget was spent, checked against the emulated backend's definitions
-// (tests/emu_ops.py) by reading only.  Kept in a translation unit of their own so that the validated kernels of backward.hip
+// NOT yet run on hardware: written after the round's GPU budget was spent.  Executed thread by thread on the host SIMT simulator
+// (tests/hostsim, tests/test_hostsim_kernels.py) against the emulated backend's definitions (tests/emu_ops.py).  Kept in a translation unit of their own so that the validated kernels of backward.hip
 // compile to exactly the code that ran (adding kernels to that file changed the code generated for gn_bwd_apply_kernel).
 #include "common.h"
 #include "gn_bwd_common.h"
@@ -150,8 +150,8 @@ __global__ __launch_bounds__(256) void gn_bwd2_apply_kernel(const bf16_t* x, int
     }
 }
 
-// ---- UNet data-gradient pieces (engine_unet_bwd.py).  NOT yet run on hardware: written after the round's GPU budget was spent,
-// checked only against the emulated backend's definitions (tests/emu_ops.py) by reading. ------------------------------------
+// ---- UNet data-gradient pieces (engine_unet_bwd.py).  NOT yet run on hardware (see the file header); run on the host SIMT
+// simulator against the emulated backend's definitions (tests/emu_ops.py). -------------------------------------------------
 
 // dx = d/dx LayerNorm(x) . dy (+ resid): one wave per row, the row in registers (NJ 16-byte chunks per lane)
 template <int NJ>

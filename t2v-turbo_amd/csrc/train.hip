@@ -1,5 +1,6 @@
 // Kernels of the LoRA training path (weight gradients of the student UNet).  Own translation unit: what hipcc emits
 // for a kernel depends on its neighbours, and everything else in the library is hardware-validated.
+// Not yet run on hardware; executed on the host SIMT simulator (tests/hostsim) bit for bit against tests/emu_ops.py.
 #include "common.h"
 
 // out[i] = idx[i] >= 0 ? src[idx[i]] * alpha : 0      (accumulate = 0; out fp32 or bf16)

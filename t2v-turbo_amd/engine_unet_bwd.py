@@ -20,9 +20,9 @@ for the 16-frame temporal ones), everything element-wise.
   temporal attention           ``attn_temporal_bwd`` (one wave-sized problem per pixel and head; takes d(probs) as well)
   spatial self / text cross    batched GEMMs around ``softmax_rows`` / ``softmax_bwd_rows`` with bf16 transposes
 
-Status: the dataflow is verified on CPU against torch autograd (tests/test_unet_grad_cpu.py, emulated op backend).  The
-device kernels for the five new ops are written (csrc/backward.hip) but have not run on hardware yet; ``native`` use
-raises until ``T2V_UNVALIDATED_KERNELS=1`` is set."""
+Status: the dataflow is verified on CPU against torch autograd (tests/test_unet_grad_cpu.py, emulated op backend), and the
+device kernels of the new ops (csrc/backward_unet.hip, csrc/train.hip) run as real source on a host SIMT simulator
+(tests/test_hostsim_kernels.py) but have not run on hardware yet; ``native`` use raises until ``T2V_UNVALIDATED_KERNELS=1`` is set."""
 import torch
 import torch.nn as nn
 
