@@ -41,13 +41,15 @@ def _sample(i):
             torch.randn(1, 256, generator=g), torch.randn(1, 4, 2, 8, 8, generator=g))
 
 
-def _loss(m, i):
+def _loss(m, i, l2=False):
     x, ts, ctx, tc, target = _sample(i)
     pred = m(x, ts, context=ctx, fps=16, timestep_cond=tc)
+    if l2:  # (the Huber gradient amplifies 1e-6 forward differences between two implementations of the same network)
+        return torch.nn.functional.mse_loss(pred, target)
     return cd_math.huber_loss(pred, target)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, native=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
@@ -58,7 +60,11 @@ def _worker(rank, world, port, out):
     broadcast_parameters(m)
     sync = FlatGradSync(lora.lora_parameters(m))
     sync.zero_()
-    loss = _loss(m, rank)
+    if native:  # the student's forward / backward on the native gradient engine's dataflow (emulated ops), one engine per rank
+        from tests.emu_ops import EmuOps
+        m._native_ops_factory = lambda: EmuOps(strict=True)
+        m.native_mode = "train"
+    loss = _loss(m, rank, l2=native)
     loss.backward()
     sync.all_reduce_mean()
     norm = sync.clip_grad_norm_(1e9)
@@ -83,3 +89,19 @@ def test_two_rank_gradient_allreduce_matches_single_process(tmp_path):
     assert abs(float(got["norm"]) - float(ref.norm())) < 1e-4 * float(ref.norm())
     assert got["losses"].shape == (2, 3)
     assert abs(float(got["losses"][0, 0]) - float(l0)) < 1e-6 and abs(float(got["losses"][1, 0]) - float(l1)) < 1e-6
+
+
+def test_two_rank_native_student_allreduce_matches_single_process(tmp_path):
+    """Same exchange with each rank's student on the native gradient engine (``native_mode = "train"``): the engine's LoRA
+    gradients land in the flat buffer through autograd, one all-reduce averages them."""
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, True), nprocs=2, join=True)
+    got = torch.load(out)
+    m = _student()
+    m.native_mode = "off"
+    params = lora.lora_parameters(m)
+    l0, l1 = _loss(m, 0, l2=True), _loss(m, 1, l2=True)
+    ((l0 + l1) / 2).backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in params])
+    assert float((got["flat"] - ref).norm() / ref.norm()) < 2e-4
+    assert abs(float(got["losses"][0, 0]) - float(l0)) < 1e-5 and abs(float(got["losses"][1, 0]) - float(l1)) < 1e-5
