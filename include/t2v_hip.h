@@ -258,6 +258,11 @@ int t2v_sumsq(const float* x, long long n, float* ws, float* out, void* stream);
  * train_t2v_turbo_v1_lora.py:1190). */
 int t2v_gather_f32(const float* src, const int* idx, float alpha, void* out, int dt_out, int accumulate, long long n,
                    void* stream);
+/* t2v_transpose_pad_bf16: out[b][c][r] = in[b][r][c] for r < rows and 0 for rows <= r < roundup(rows, 64) — the K-contiguous,
+ * K-padded operand of the token-contracted weight-gradient GEMMs (dU = dy^T t, dD = G^T x) in one pass; 16-byte accesses on both
+ * sides: cols % 8 == 0, ld_in % 8 == 0, ld_out % 8 == 0 and >= roundup(rows, 64), 16-byte aligned bases, batch strides % 8. */
+int t2v_transpose_pad_bf16(const void* in, int ld_in, int rows, int cols, void* out, int ld_out, int batch, long long in_stride,
+                           long long out_stride, void* stream);
 /* t2v_dropout_bf16: out[r][c] = keep(r, c) ? x[r][c] / (1 - p) : 0  (+ resid[r][c]) over rows x ncols bf16 (ncols even), where
  * keep is a pure function of (*seed, site, r * ncols + c): splitmix64(seed + site * 0x9E3779B97F4A7C15 + pair * 0xD1B54A32D192ED03)
  * per pair of adjacent columns, low / high 32 bits compared with p * 2^32.  The backward calls it again with the same (seed,

@@ -116,3 +116,49 @@ extern "C" int t2v_dropout_bf16(const void* x, int ldx, const void* resid, int l
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// out[b][c][r] = in[b][r][c] for r < rows, and 0 for rows <= r < roundup(rows, 64): the K-contiguous, K-padded operand of a
+// token-contracted weight-gradient GEMM in ONE pass (t2v_transpose_bf16 + a memset before it, with 2-byte accesses, was the
+// first version).  64x64 tile through LDS, 16-byte global loads and stores on both sides: a thread loads two 8-element row
+// chunks and stores two 8-element chunks of the transposed rows.  LDS rows are padded to 66 elements (33 words: the column
+// walk of the read-out touches 8 different banks per chunk).
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __restrict__ in, int ld_in, int rows, int cols,
+                                                            bf16_t* __restrict__ out, int ld_out, long long in_stride, long long out_stride) {
+    __shared__ bf16_t tile[64][66];
+    const bf16_t* ib = in + blockIdx.z * in_stride;
+    bf16_t* ob = out + blockIdx.z * out_stride;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + 256 * i, r = q >> 3, ch = (q & 7) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + r < rows && c0 + ch < cols) v = *(const uint4*)(ib + (long long)(r0 + r) * ld_in + c0 + ch);
+        uint32_t* t = (uint32_t*)&tile[r][ch];  // (66-element rows: 4-byte aligned, not 16)
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = threadIdx.x + 256 * i, c = q >> 3, rh = (q & 7) * 8;
+        if (c0 + c >= cols) continue;
+        uint32_t w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[rh + 2 * e][c] | ((uint32_t)tile[rh + 2 * e + 1][c] << 16);
+        *(uint4*)(ob + (long long)(c0 + c) * ld_out + r0 + rh) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+extern "C" int t2v_transpose_pad_bf16(const void* in, int ld_in, int rows, int cols, void* out, int ld_out, int batch,
+                                      long long in_stride, long long out_stride, void* stream) {
+    T2V_REQUIRE(in && out && rows > 0 && cols > 0 && batch > 0 && batch <= 65535, T2V_EINVAL, "t2v_transpose_pad_bf16: bad argument");
+    const int rows_pad = (rows + 63) / 64 * 64;
+    T2V_REQUIRE(cols % 8 == 0 && ld_in % 8 == 0 && ld_in >= cols && ld_out % 8 == 0 && ld_out >= rows_pad && in_stride % 8 == 0 &&
+                out_stride % 8 == 0 && (uintptr_t)in % 16 == 0 && (uintptr_t)out % 16 == 0, T2V_ESHAPE,
+                "t2v_transpose_pad_bf16: 16-byte rows on both sides, ld_out >= roundup(rows, 64)");
+    T2V_REQUIRE((rows + 63) / 64 <= 65535, T2V_ESHAPE, "t2v_transpose_pad_bf16: too many rows");
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)in, ld_in, rows, cols, (bf16_t*)out, ld_out, in_stride, out_stride);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}

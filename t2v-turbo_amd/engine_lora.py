@@ -279,9 +279,7 @@ class LoraTrainMixin:
         """[batch][rows][cols] -> [batch][cols][rows padded to 64 with zeros] (K-contiguous GEMM operand)."""
         rp = _pad(rows, 64)
         dst = self.buf(batch * cols, rp)
-        if rp != rows:
-            self.ops.fill_zero(dst)
-        self.ops.transpose(src, rows, cols, dst, batch=batch, in_stride=in_stride, out_stride=cols * rp)
+        self.ops.transpose_pad(src, rows, cols, dst, batch=batch, in_stride=in_stride, out_stride=cols * rp)
         return dst
 
     @staticmethod

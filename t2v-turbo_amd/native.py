@@ -108,6 +108,8 @@ _SIGS = {
     "t2v_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_longlong, C.c_void_p]),
     "t2v_sumsq": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2v_gather_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p]),
+    "t2v_transpose_pad_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
+                                         C.c_longlong, C.c_void_p]),
     "t2v_dropout_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float,
                                    C.c_void_p, C.c_uint, C.c_void_p]),
     "t2v_lcm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float,
@@ -377,6 +379,11 @@ class HipOps:
         """out.flat[i] = alpha * src.flat[idx[i]] (0 where idx < 0), or += with ``accumulate``; src fp32, idx int32."""
         assert src.dtype == torch.float32 and idx.dtype == torch.int32 and idx.numel() == out.numel()
         self._call("t2v_gather_f32", _p(src), _p(idx), alpha, _p(out), _DT[out.dtype], 1 if accumulate else 0, out.numel())
+
+    def transpose_pad(self, src, rows, cols, out, batch=1, in_stride=0, out_stride=0):
+        """out[b][c][r] = src[b][r][c], zero for rows <= r < roundup(rows, 64) (16-byte accesses; see include/t2v_hip.h)."""
+        self._call("t2v_transpose_pad_bf16", _p(src), _row_stride(src), rows, cols, _p(out), _row_stride(out), batch, in_stride,
+                   out_stride)
 
     def dropout(self, x, resid, out, ncols, p, seed, site):
         """out[:, :ncols] = dropout(x[:, :ncols]) (+ resid); mask = f(seed[0], site, row * ncols + col); seed: int64 device tensor."""

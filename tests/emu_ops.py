@@ -254,6 +254,16 @@ class EmuOps:
             a = _strided(src, rows, cols, src.stride(0), b * in_stride)
             _strided(out, cols, rows, out.stride(0), b * out_stride).copy_(a.t())
 
+    def transpose_pad(self, src, rows, cols, out, batch=1, in_stride=0, out_stride=0):
+        self._log("transpose_pad")
+        rp = (rows + 63) // 64 * 64
+        assert cols % 8 == 0 and src.stride(0) % 8 == 0 and out.stride(0) % 8 == 0 and out.stride(0) >= rp
+        for b in range(batch):
+            a = _strided(src, rows, cols, src.stride(0), b * in_stride)
+            o = _strided(out, cols, rp, out.stride(0), b * out_stride)
+            o[:, :rows] = a.t()
+            o[:, rows:] = 0
+
     def sumpool2x2(self, src, n_img, h, w, out):
         self._log("sumpool2x2")
         C = src.shape[1]

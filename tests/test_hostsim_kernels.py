@@ -246,3 +246,19 @@ def test_training_engine_on_simulated_kernels_bf16():
     assert torch.isfinite(errs).all()
     # bf16 backprop through ~60 layers: measured median 5.2e-2, max 0.10 (the opt-in GPU test uses the same bounds)
     assert float(errs.median()) < 8e-2 and float(errs.max()) < 0.25, (float(errs.median()), float(errs.max()))
+
+
+@pytest.mark.parametrize("rows,cols,batch,ld_in", [(100, 72, 1, 72), (64, 128, 3, 128), (77, 320, 2, 320), (130, 64, 2, 192), (5, 8, 1, 8)])
+def test_transpose_pad(ops, rows, cols, batch, ld_in):
+    """The weight-gradient operand transpose (16-byte accesses, zero K padding in the same pass): bit-exact, padding written, and
+    nothing beyond roundup(rows, 64) touched."""
+    sim, emu = ops
+    src = _rt(batch * rows, ld_in, seed=1)
+    rp = (rows + 63) // 64 * 64
+    ld_out = rp + 8
+    o_s = torch.full((batch * cols, ld_out), 5.0, dtype=torch.bfloat16)
+    o_e = torch.full((batch * cols, ld_out), 5.0)
+    sim.transpose_pad(_bf(src)[:, :cols], rows, cols, o_s, batch=batch, in_stride=rows * ld_in, out_stride=cols * ld_out)
+    emu.transpose_pad(src[:, :cols], rows, cols, o_e, batch=batch, in_stride=rows * ld_in, out_stride=cols * ld_out)
+    assert torch.equal(o_s.float(), o_e)
+    assert float(o_e[:, rp:].min()) == 5.0 and float(o_e[:, rows:rp].abs().max() if rp > rows else 0.0) == 0.0
