@@ -246,3 +246,17 @@ def test_dropout_mask_is_the_emulated_one(ops, rows, ncols, ld, p, resid):
     if not resid:
         assert torch.equal(got[:, :ncols] != 0, keep)
     assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
+
+
+@pytest.mark.parametrize("rows,cols,batch,ld_in", [(100, 72, 1, 72), (40960, 320, 1, 320), (77, 320, 2, 320), (130, 64, 2, 192)])
+def test_transpose_pad(ops, rows, cols, batch, ld_in):
+    hip, emu = ops
+    src = _rt(batch * rows, ld_in, seed=1)
+    rp = (rows + 63) // 64 * 64
+    ld_out = rp + 8
+    o_h = torch.full((batch * cols, ld_out), 5.0, dtype=torch.bfloat16, device="cuda")
+    o_e = torch.full((batch * cols, ld_out), 5.0)
+    hip.transpose_pad(_dev(src)[:, :cols], rows, cols, o_h, batch=batch, in_stride=rows * ld_in, out_stride=cols * ld_out)
+    emu.transpose_pad(src[:, :cols], rows, cols, o_e, batch=batch, in_stride=rows * ld_in, out_stride=cols * ld_out)
+    torch.cuda.synchronize()
+    assert torch.equal(o_h.float().cpu(), o_e)
