@@ -405,3 +405,42 @@ class EmuOps:
         den = c_out * x0 + c_skip * x
         denoised.copy_(den)
         prev.copy_(den if noise is None else sa_p * den + sb_p * noise)
+
+
+class ReplayOps:
+    """TEST ONLY: the emulated ops behind the NATIVE backend's record / replay protocol (``is_native``, ``recording`` lists,
+    ``replay``): the engines then take the code path they take on the GPU — launches recorded once with their operand views
+    baked in, later calls only refresh the static input buffers and re-issue the recorded list — instead of re-running their
+    Python closures every time.  Catches what only that mode can get wrong: state that lives in Python during recording but
+    not during a replay, buffers recycled between the forward and backward lists, inputs that are not static."""
+    is_native = True
+    _PURE = ("gn_ws_floats", "gn_bwd_ws_floats", "group_norm_ws_floats", "dropout_keep", "masks", "calls", "strict")
+
+    def __init__(self, inner=None):
+        self.inner = inner or EmuOps(strict=True)
+        self.act_dtype = self.inner.act_dtype
+        self.recording = None
+        self.replays = 0
+
+    def init(self):
+        pass
+
+    @staticmethod
+    def stream():
+        return None
+
+    def replay(self, recording, stream):
+        self.replays += 1
+        for fn, a, k in recording:
+            fn(*a, **k)
+
+    def __getattr__(self, name):
+        fn = getattr(self.inner, name)
+        if name in self._PURE or not callable(fn):
+            return fn
+
+        def call(*a, **k):
+            if self.recording is not None:
+                self.recording.append((fn, a, k))
+            return fn(*a, **k)
+        return call

@@ -2,6 +2,7 @@
 denoiser output plus the recorded temporal attention probabilities must match torch autograd through the reference-shaped
 module.  Pins the tape: saved tensors, gradient routing through the skip concats, the GEMM-formulated attention
 backward (strides, transposes, padding), re-packed data-gradient weights."""
+import pytest
 import torch
 
 from oracle.synth import synth_state_dict
@@ -22,7 +23,12 @@ def _autograd_reference(m, x, ts, ctx, fps, tc, r_out, r_probs):
     return y.detach(), g
 
 
-def test_unet_grad_engine_matches_autograd():
+@pytest.mark.parametrize("protocol", ["closures", "record_replay"])
+def test_unet_grad_engine_matches_autograd(protocol, monkeypatch):
+    """``record_replay``: the same check through the native backend's protocol (launch lists recorded once, replayed with
+    refreshed static inputs) instead of re-running the engine's Python closures on every call."""
+    from tests.emu_ops import ReplayOps
+    monkeypatch.setenv("T2V_UNVALIDATED_KERNELS", "1")
     g = load("unet_tiny")
     cfg = tiny_unet_params(record_attn_probs=True)
     sd = synth_state_dict(manifest("unet_tiny"))
@@ -32,7 +38,7 @@ def test_unet_grad_engine_matches_autograd():
     x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
     gen = torch.Generator().manual_seed(5)
     r_out = torch.randn(x.shape, generator=gen)
-    eng = UNetGradEngine(m, EmuOps(strict=True))
+    eng = UNetGradEngine(m, EmuOps(strict=True) if protocol == "closures" else ReplayOps())
     y = eng.forward_tape(x, ts, ctx, 16, tc, None)
     recorded = [a for a, _ in eng._last["probs"]]
     names = {id(mod): name for name, mod in m.named_modules()}

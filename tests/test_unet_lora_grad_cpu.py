@@ -273,3 +273,49 @@ def test_train_mode_dropout_masks_and_gradients():
     y2 = eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all.detach(), seed=99)
     y3 = eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all.detach(), seed=1234)
     assert rel_l2(y2, y) > 1e-3 and torch.equal(y3, y)
+
+
+def test_record_replay_protocol_of_the_native_backend(monkeypatch):
+    """The engine on the native backend's record / replay protocol (tests.emu_ops.ReplayOps): launch lists recorded once,
+    every later step = refresh static inputs + LoRA operand packs + seed, then re-issue the lists.  Three steps with different
+    inputs and updated LoRA tensors against autograd; the third in train mode is a new plan (dropout sites) and must still
+    run."""
+    from tests.emu_ops import ReplayOps
+    monkeypatch.setenv("T2V_UNVALIDATED_KERNELS", "1")
+    g = load("unet_tiny")
+    m, params = _student("unet_tiny", 64)
+    ops = ReplayOps()
+    eng = UNetGradEngine(m, ops)
+    eng.bind_lora(params)
+    x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
+    gen = torch.Generator().manual_seed(5)
+    for step in range(3):
+        r_out = torch.randn(x.shape, generator=gen)
+        xs = x if step == 0 else torch.randn(x.shape, generator=gen)
+        tss = ts if step == 0 else torch.tensor([279 + 240 * step])
+        y_ref, dx_ref, g_ref = _autograd(m, params, xs, tss, ctx, 16 + step, tc, None, r_out)
+        m.native_mode = "auto"
+        y, dx, grads = _engine_step(eng, m, params, xs, tss, ctx, 16 + step, tc, None, r_out)
+        assert rel_l2(y, y_ref) < 2e-5, step
+        assert rel_l2(dx, dx_ref) < 1e-4, step
+        _compare(params, grads, g_ref, m)
+        with torch.no_grad():
+            for p in params:
+                p.add_(torch.randn(p.shape, generator=gen) * 0.01)
+    assert len(eng.plans) == 1 and ops.replays >= 5  # step 0: record fwd + bwd, replay fwd, replay bwd; then two lists per step
+    # forward-only use in between (the distillation step's target forward) leaves the next backward intact
+    emb_all = m.conditioning_emb_all(ts, 16, tc, None)
+    eng.forward_tape(x * 0.3, ts, ctx, 16, tc, None, emb_all=emb_all.detach())
+    r_out = torch.randn(x.shape, generator=gen)
+    y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 16, tc, None, r_out)
+    y, dx, grads = _engine_step(eng, m, params, x, ts, ctx, 16, tc, None, r_out)
+    assert rel_l2(dx, dx_ref) < 1e-4
+    _compare(params, grads, g_ref, m)
+    # train mode: a second plan (dropout sites recorded into the lists, seed read from its static buffer at replay time)
+    m.train()
+    emb_all = m.conditioning_emb_all(ts, 16, tc, None)
+    y1 = eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all.detach(), seed=11)
+    y2 = eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all.detach(), seed=12)
+    y3 = eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all.detach(), seed=11)
+    assert len(eng.plans) == 2 and torch.equal(y1, y3) and rel_l2(y2, y1) > 1e-3
+    assert torch.isfinite(eng.backward(r_out, flat_grad=torch.zeros(eng.lora_numel))).all()
