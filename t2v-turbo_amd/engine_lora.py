@@ -28,7 +28,7 @@ import torch
 import torch.nn as nn
 
 from . import native as nt
-from .engine import Act, is_lora_leaf
+from .engine import is_lora_leaf
 
 RP = 64  # rank granularity: K of a GEMM is a multiple of 64
 
@@ -38,7 +38,7 @@ def _pad(n, m):
 
 
 def _pad_to(t, shape):
-    """int64 index tensor zero^H^H^H^H -1-padded up to ``shape`` (trailing side of every dim)."""
+    """int64 index tensor padded with -1 up to ``shape`` (trailing side of every dim)."""
     out = torch.full(shape, -1, dtype=torch.int64)
     out[tuple(slice(0, s) for s in t.shape)] = t
     return out
