@@ -18,3 +18,8 @@ timeout 200 python tools/gemm_profile_graph.py --blas 0 --force-cfgs 24,25,26,27
     --out gpurun_out/gemm_experimental_cfgs.csv 2>&1 | tail -3
 # 4. the distillation step with the native student (tools/distill_bench.py --native-student 1) next to the torch student
 T2V_UNVALIDATED_KERNELS=1 timeout 500 python tools/distill_bench.py --steps 3 --native-student 1 2>&1 | tail -2 | tee gpurun_out/distill_native.txt
+# 4b. same with each launch list captured in a hipGraph, and a per-kernel profile of the eager run (copy the summary to profiles/)
+T2V_UNVALIDATED_KERNELS=1 T2V_HIP_GRAPH=1 timeout 500 python tools/distill_bench.py --steps 3 --native-student 1 2>&1 | tail -1 | tee gpurun_out/distill_native_graph.txt
+export TMPDIR=/tmp
+T2V_UNVALIDATED_KERNELS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_distill_native -- \
+    python tools/distill_bench.py --steps 2 --warmup 1 --native-student 1 > gpurun_out/prof_distill_native.log 2>&1
