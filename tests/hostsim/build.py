@@ -12,8 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "t2v-turbo_amd", "csrc")
 SOURCES = ["backward.hip", "backward_unet.hip", "train.hip"]
+GEMM_SOURCES = ["gemm.hip", "gemm_exp.hip"]   # MFMA + LDS-DMA: simulated as wave collectives (separate, slower-to-build library)
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libt2v_hostsim.so")
+GEMM_LIB = os.path.join(OUT, "libt2v_hostsim_gemm.so")
 
 
 def needs_build():
@@ -26,15 +28,54 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def patch(text):
+    """The textual differences between device source and what g++ sees: dynamic LDS, address-space casts, AMDGPU inline asm."""
+    text = re.sub(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?(\w+)\s+(\w+)\[\];",
+                  r"\1* \2 = (\1*)hostsim::dyn_shared();", text)
+    text = re.sub(r"__attribute__\(\(address_space\(\d\)\)\)", "", text)
+    # A wave runs in lockstep on the hardware: lanes may exchange data through LDS with nothing but "my LDS operations have
+    # landed" (s_waitcnt lgkmcnt(0)) or a compiler fence between the writes and the reads.  Fibers do not: those two markers
+    # become wave rendezvous points, which restores exactly that ordering.
+    text = re.sub(r'asm volatile\("s_waitcnt lgkmcnt\(0\)"[^;]*;', "hostsim::wave_rendezvous();", text)
+    text = re.sub(r'asm volatile\(""\s*:::\s*"memory"\);', "hostsim::wave_rendezvous();", text)
+    text = re.sub(r"__attribute__\(\(ext_vector_type\((\d+)\)\)\)", lambda m: f"__attribute__((vector_size({4 * int(m.group(1))})))", text)
+    text = re.sub(r'asm volatile\("s_[^"]*"[^;]*;', ";", text)                 # s_waitcnt vmcnt / s_nop: no asynchrony on the host
+    text = re.sub(r'asm volatile\(""\s*:\s*"\+v"\([^;]*;', ";", text)          # register-pinning barriers
+    text = text.replace('#include "gemm.hip"', '#include "gemm.cpp"')
+    return text
+
+
+def build_gemm(force=False):
+    """t2v_gemm (+ the experimental tile ids) on the simulator.  Minutes of g++ time: built on demand by its own test module."""
+    deps = [os.path.join(CSRC, s) for s in GEMM_SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
+                                                           os.path.abspath(__file__), os.path.join(ROOT, "include", "t2v_hip.h")]
+    if not force and os.path.exists(GEMM_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(GEMM_LIB) for d in deps):
+        return GEMM_LIB
+    os.makedirs(OUT, exist_ok=True)
+    procs, objs = [], []
+    for src in GEMM_SOURCES:
+        cpp = os.path.join(OUT, src.replace(".hip", ".cpp"))
+        open(cpp, "w").write(patch(open(os.path.join(CSRC, src)).read()))
+    for src in GEMM_SOURCES:
+        cpp = os.path.join(OUT, src.replace(".hip", ".cpp"))
+        obj = cpp.replace(".cpp", ".o")
+        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-w", "-I", HERE, "-I", OUT, "-I", os.path.join(ROOT, "include"), "-c", cpp, "-o", obj]
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError("g++ failed: " + " ".join(cmd))
+    subprocess.check_call(["g++", "-shared", "-o", GEMM_LIB] + objs)
+    return GEMM_LIB
+
+
 def build(force=False):
     if not force and not needs_build():
         return LIB
     os.makedirs(OUT, exist_ok=True)
     objs = []
     for src in SOURCES + ["gn_bwd_common.h"]:
-        text = open(os.path.join(CSRC, src)).read()
-        text = re.sub(r"extern\s+__shared__\s+(\w+)\s+(\w+)\[\];", r"\1* \2 = (\1*)hostsim::dyn_shared();", text)
-        open(os.path.join(OUT, src.replace(".hip", ".cpp")), "w").write(text)
+        open(os.path.join(OUT, src.replace(".hip", ".cpp")), "w").write(patch(open(os.path.join(CSRC, src)).read()))
     for src in SOURCES:
         cpp = os.path.join(OUT, src.replace(".hip", ".cpp"))
         obj = cpp.replace(".cpp", ".o")
@@ -48,3 +89,5 @@ def build(force=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
+    if "--gemm" in sys.argv:
+        print(build_gemm(force="--force" in sys.argv))

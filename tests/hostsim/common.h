@@ -10,6 +10,9 @@
 #include "t2v_hip.h"
 
 typedef uint16_t bf16_t;
+typedef hostsim::v8u16 bf16x8_t;   // 8 bf16 as raw bits (g++ 11 has no __bf16): the kernels only move them and feed the MFMA
+typedef hostsim::v16f f32x16_t;
+typedef float f32x4_t __attribute__((vector_size(16)));
 #define T2V_WAVE 64
 
 inline float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }

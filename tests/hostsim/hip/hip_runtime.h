@@ -157,7 +157,61 @@ inline T shfl_xor(T v, int mask) {
     return r;
 }
 
+inline float med3(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
+// LDS-DMA (global_load_lds_dwordx{1,4}): every lane copies `size` bytes from ITS global pointer to the wave-uniform LDS base
+// + lane * size (+ offset): the LDS image of one wave instruction is lane-linear.  Synchronous here (the s_waitcnt counters
+// the kernels pair it with are no-ops on the host).
+inline void glds(const void* gsrc, void* lds_wave_base, int size, int offset) {
+    State& s = st();
+    const int lane = s.fibers[s.cur].flat % 64;
+    memcpy((char*)lds_wave_base + (size_t)lane * size + offset, gsrc, size);
+}
+inline void wave_rendezvous() {
+    State& s = st();
+    const int w = s.fibers[s.cur].flat / 64;
+    arrive(s.wave_sync[w], alive_in_wave(w));
+}
+typedef uint16_t v8u16 __attribute__((vector_size(16)));
+typedef float v16f __attribute__((vector_size(64)));
+inline std::vector<v8u16>& mf_a() { static std::vector<v8u16> v; return v; }
+inline std::vector<v8u16>& mf_b() { static std::vector<v8u16> v; return v; }
+inline float bf(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
+// v_mfma_f32_32x32x16_bf16 as a wave collective: D = A (32 x 16) * B (16 x 32) + C.  Operand layout (CDNA4 ISA): lane l holds
+// A[row = l & 31][k = 8 (l >> 5) .. +7] and B[k = 8 (l >> 5) .. +7][col = l & 31]; accumulator register r of lane l is
+// D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31].  Calibrated by running the hardware-validated tile
+// configurations of t2v_gemm against the emulated backend (tests/test_hostsim_gemm.py).
+inline v16f mfma_32x32x16_bf16(v8u16 a, v8u16 b, v16f c) {
+    State& s = st();
+    const int me = s.fibers[s.cur].flat, w = me / 64, lane = me % 64;
+    if (mf_a().size() < s.fibers.size()) { mf_a().resize(s.fibers.size()); mf_b().resize(s.fibers.size()); }
+    mf_a()[me] = a;
+    mf_b()[me] = b;
+    wave_rendezvous();
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k)
+            acc += bf(mf_a()[w * 64 + row + 32 * (k >> 3)][k & 7]) * bf(mf_b()[w * 64 + col + 32 * (k >> 3)][k & 7]);
+        c[r] = acc;
+    }
+    wave_rendezvous();
+    return c;
+}
+
 }  // namespace hostsim
+
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+#define __builtin_amdgcn_readfirstlane(x) (x)  /* only ever applied to wave-uniform values */
+#define __builtin_amdgcn_fmed3f(a, b, c) hostsim::med3((a), (b), (c))
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_s_barrier() __syncthreads()
+#define __builtin_amdgcn_wave_barrier() hostsim::wave_rendezvous()
+#define __builtin_amdgcn_exp2f exp2f
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hostsim::glds((const void*)(g), (void*)(l), (size), (off))
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hostsim::mfma_32x32x16_bf16((a), (b), (c))
 
 #define threadIdx (hostsim::st().fibers[hostsim::st().cur].tid)
 #define blockIdx (hostsim::st().bid)
