@@ -17,7 +17,10 @@ SIMULATED = ("gn_bwd", "gn_bwd_ws_floats", "layernorm_bwd", "geglu_fwd", "geglu_
 
 
 class HybridOps(EmuOps):
-    def __init__(self):
+    """``real_gemm=True`` additionally runs every t2v_gemm launch of the engine as the real MFMA kernel source on the simulator
+    (minutes instead of seconds: opt-in)."""
+
+    def __init__(self, real_gemm=False):
         super().__init__(act_dtype=torch.bfloat16, strict=True)
         import build as hostsim_build
         from tests.test_hostsim_kernels import HostSimOps
@@ -25,6 +28,23 @@ class HybridOps(EmuOps):
         self.sim_calls = 0
         for name in SIMULATED:
             setattr(self, name, self._route(name))
+        if real_gemm:
+            self.gsim = HostSimOps(hostsim_build.build_gemm())
+            self.gsim.tune, self.gsim._ws = {}, {}
+            self.gemm_calls = 0
+            emu_gemm = self.gemm
+
+            def gemm(a0, w, out, **kw):
+                self.gemm_calls += 1
+                self._log("gemm")
+                if out.dtype not in (torch.bfloat16, torch.float32) or a0.dtype != torch.bfloat16:
+                    return emu_gemm(a0, w, out, **kw)
+                b, rv = kw.get("bias"), kw.get("rowvec")
+                kw["bias"] = None if b is None else b.float().contiguous()
+                if rv is not None and rv.dtype != torch.float32:
+                    kw["rowvec"] = rv.float()
+                return self.gsim.gemm(a0, w, out, **kw)
+            self.gemm = gemm
 
     def _route(self, name):
         fn = getattr(self.sim, name)
