@@ -69,6 +69,36 @@ def build_gemm(force=False):
     return GEMM_LIB
 
 
+FULL_SOURCES = ["gemm.hip", "gemm_exp.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip"]
+FULL_LIB = os.path.join(OUT, "libt2v_hostsim_full.so")
+
+
+def build_full(force=False):
+    """EVERY source of libt2v_hip.so on the simulator: the engines can then run on the real C-ABI end to end, on the CPU."""
+    deps = [os.path.join(CSRC, s) for s in FULL_SOURCES] + [os.path.join(CSRC, "gn_bwd_common.h"), os.path.join(HERE, "common.h"),
+                                                           os.path.join(HERE, "hip", "hip_runtime.h"), os.path.abspath(__file__),
+                                                           os.path.join(ROOT, "include", "t2v_hip.h")]
+    if not force and os.path.exists(FULL_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(FULL_LIB) for d in deps):
+        return FULL_LIB
+    full = os.path.join(OUT, "full")
+    os.makedirs(full, exist_ok=True)
+    for src in FULL_SOURCES + ["gn_bwd_common.h"]:
+        open(os.path.join(full, src.replace(".hip", ".cpp")), "w").write(patch(open(os.path.join(CSRC, src)).read()))
+    procs, objs = [], []
+    for src in FULL_SOURCES:
+        cpp = os.path.join(full, src.replace(".hip", ".cpp"))
+        obj = cpp.replace(".cpp", ".o")
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-w", "-DHOSTSIM_FULL", "-I", HERE, "-I", full, "-I", os.path.join(ROOT, "include"),
+               "-c", cpp, "-o", obj]
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError("g++ failed: " + " ".join(cmd))
+    subprocess.check_call(["g++", "-shared", "-o", FULL_LIB] + objs)
+    return FULL_LIB
+
+
 def build(force=False):
     if not force and not needs_build():
         return LIB
@@ -91,3 +121,5 @@ if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
     if "--gemm" in sys.argv:
         print(build_gemm(force="--force" in sys.argv))
+    if "--full" in sys.argv:
+        print(build_full(force="--force" in sys.argv))

@@ -46,9 +46,14 @@ inline float wave_max(float v) {
     return v;
 }
 
+#ifdef HOSTSIM_FULL  // the whole library: csrc/elementwise.hip brings its own definitions
+void t2v_set_error(const char* msg);
+const void* t2v_zero_page();
+#else
 inline std::string& t2v_err() { static std::string e; return e; }
 inline void t2v_set_error(const char* msg) { t2v_err() = msg; }
-inline const void* t2v_zero_page() { static char z[256] = {0}; return z; }
+inline const void* t2v_zero_page() { static char z[4096] = {0}; return z; }
+#endif
 #define T2V_CHECK_LAUNCH() do { } while (0)
 #define T2V_REQUIRE(cond, code, msg) \
     do {                             \

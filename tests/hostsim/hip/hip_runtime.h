@@ -1,12 +1,15 @@
 // Host SIMT simulator — TEST INFRASTRUCTURE ONLY (tests/hostsim/).  Stands in for <hip/hip_runtime.h> so that the library's
-// kernel SOURCES that use only plain SIMT features (threadIdx / blockIdx, __shared__, __syncthreads, __shfl_xor, vector
-// loads) compile with g++ and run on the CPU: every thread of a workgroup is a fiber (ucontext), workgroups run one after
-// the other, __syncthreads and the 64-lane shuffles are rendezvous points between fibers.  No MFMA, no inline asm, no
-// LDS-DMA: kernels using those (t2v_gemm, the attention forwards) are not simulated.  What it buys: the exact index
-// arithmetic, reductions and LDS traffic of kernels that have not run on hardware yet are executed and compared with the
-// emulated op backend in the CPU suite (tests/test_hostsim_kernels.py).
+// kernel SOURCES compile with g++ and run on the CPU: every thread of a workgroup is a fiber, workgroups run one after the
+// other, __syncthreads and the 64-lane shuffles / votes are rendezvous points between fibers, the matrix instructions
+// (v_mfma_f32_32x32x16_bf16, 16x16x32, 16x16x16) and the LDS-DMA are wave collectives with the CDNA4 lane layouts, and the
+// points where a kernel relies on a wave running in lockstep (s_waitcnt lgkmcnt(0), compiler fences, wave barriers) are wave
+// rendezvous.  What it buys: the exact index arithmetic, reductions, LDS traffic and MFMA operand placement of kernels that
+// have not run on hardware yet are executed and compared with the emulated op backend in the CPU suite.  What it cannot
+// show: asynchrony (DMA ring / counted waits), the memory model, the gfx950 code generator, speed.
+//
+// Context switches are a dozen instructions of x86-64 assembly (callee-saved registers + stack pointer): glibc's swapcontext
+// makes a sigprocmask system call per switch, and one simulated MFMA is 256 switches.
 #pragma once
-#include <ucontext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -51,11 +54,40 @@ inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return
 #define __builtin_amdgcn_rcpf(x) (1.0f / (x))
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 
+#if !defined(__x86_64__)
+#error "the host SIMT simulator's context switch is written for x86-64"
+#endif
+extern "C" void hostsim_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .weak hostsim_switch
+    .type hostsim_switch, @function
+hostsim_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hostsim_switch, .-hostsim_switch
+)");
+
 namespace hostsim {
 
 struct Sync { int count = 0; unsigned gen = 0; };
 struct Fiber {
-    ucontext_t ctx;
+    void* sp = nullptr;
+    const Sync* wait = nullptr;  // blocked on this rendezvous until its generation moves past wait_gen (scheduler skips it)
+    unsigned wait_gen = 0;
     bool done = false;
     dim3 tid;
     int flat = 0;
@@ -69,7 +101,7 @@ struct State {
     std::vector<Sync> wave_sync;
     std::vector<uint64_t> slots;      // shuffle exchange, one per thread
     int cur = -1;
-    ucontext_t sched;
+    void* sched_sp = nullptr;
     const std::function<void()>* body = nullptr;
 };
 inline State& st() { static State s; return s; }
@@ -82,7 +114,7 @@ inline int alive_in_wave(int w) {
     for (int i = w * 64; i < std::min<int>((w + 1) * 64, (int)s.fibers.size()); ++i) n += !s.fibers[i].done;
     return n;
 }
-inline void yield() { State& s = st(); swapcontext(&s.fibers[s.cur].ctx, &s.sched); }
+inline void yield() { State& s = st(); hostsim_switch(&s.fibers[s.cur].sp, s.sched_sp); }
 inline void release_if_complete(Sync& sy, int alive) {
     if (sy.count > 0 && sy.count >= alive) { sy.count = 0; ++sy.gen; }
 }
@@ -90,7 +122,11 @@ inline void arrive(Sync& sy, int alive) {
     ++sy.count;
     const unsigned g = sy.gen;
     if (sy.count >= alive) { sy.count = 0; ++sy.gen; return; }
+    Fiber& f = st().fibers[st().cur];
+    f.wait = &sy;
+    f.wait_gen = g;
     while (sy.gen == g) yield();
+    f.wait = nullptr;
 }
 inline void trampoline() {
     State& s = st();
@@ -99,7 +135,8 @@ inline void trampoline() {
     f.done = true;  // an exited thread no longer takes part in barriers / shuffles
     release_if_complete(s.block_sync, alive_in_block());
     release_if_complete(s.wave_sync[f.flat / 64], alive_in_wave(f.flat / 64));
-    swapcontext(&f.ctx, &s.sched);
+    hostsim_switch(&f.sp, s.sched_sp);  // never resumed
+    abort();
 }
 inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
     State& s = st();
@@ -118,13 +155,16 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
                 for (int i = 0; i < n; ++i) {
                     Fiber& f = s.fibers[i];
                     f.done = false;
+                    f.wait = nullptr;
                     f.flat = i;
                     f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = s.stacks.data() + (size_t)i * kStack;
-                    f.ctx.uc_stack.ss_size = kStack;
-                    f.ctx.uc_link = &s.sched;
-                    makecontext(&f.ctx, (void (*)())trampoline, 0);
+                    // initial frame: six zeroed callee-saved registers below the entry address, which sits 16-byte aligned so
+                    // that the entry sees the stack as after a call
+                    uintptr_t top = ((uintptr_t)(s.stacks.data() + (size_t)(i + 1) * kStack)) & ~(uintptr_t)15;
+                    void** sp = (void**)(top - 16);
+                    sp[0] = (void*)trampoline;
+                    for (int r = 1; r <= 6; ++r) sp[-r] = nullptr;
+                    f.sp = (void*)(sp - 6);
                 }
                 int done = 0;
                 long long rounds = 0;
@@ -132,8 +172,9 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
                     done = 0;
                     for (int i = 0; i < n; ++i) {
                         if (s.fibers[i].done) { ++done; continue; }
+                        if (s.fibers[i].wait && s.fibers[i].wait->gen == s.fibers[i].wait_gen) continue;  // still blocked
                         s.cur = i;
-                        swapcontext(&s.sched, &s.fibers[i].ctx);
+                        hostsim_switch(&s.sched_sp, s.fibers[i].sp);
                         done += s.fibers[i].done;
                     }
                     if (++rounds > 2000000) { fprintf(stderr, "hostsim: workgroup does not terminate (barrier mismatch?)\n"); abort(); }
@@ -173,9 +214,11 @@ inline void wave_rendezvous() {
 }
 typedef uint16_t v8u16 __attribute__((vector_size(16)));
 typedef float v16f __attribute__((vector_size(64)));
-inline std::vector<v8u16>& mf_a() { static std::vector<v8u16> v; return v; }
-inline std::vector<v8u16>& mf_b() { static std::vector<v8u16> v; return v; }
+struct F8 { float v[8]; };
+inline std::vector<F8>& mf_a() { static std::vector<F8> v; return v; }
+inline std::vector<F8>& mf_b() { static std::vector<F8> v; return v; }
 inline float bf(uint16_t v) { uint32_t u = (uint32_t)v << 16; float f; memcpy(&f, &u, 4); return f; }
+inline void put8(std::vector<F8>& dst, int me, v8u16 x) { for (int j = 0; j < 8; ++j) dst[me].v[j] = bf(x[j]); }
 // v_mfma_f32_32x32x16_bf16 as a wave collective: D = A (32 x 16) * B (16 x 32) + C.  Operand layout (CDNA4 ISA): lane l holds
 // A[row = l & 31][k = 8 (l >> 5) .. +7] and B[k = 8 (l >> 5) .. +7][col = l & 31]; accumulator register r of lane l is
 // D[row = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][col = l & 31].  Calibrated by running the hardware-validated tile
@@ -184,23 +227,119 @@ inline v16f mfma_32x32x16_bf16(v8u16 a, v8u16 b, v16f c) {
     State& s = st();
     const int me = s.fibers[s.cur].flat, w = me / 64, lane = me % 64;
     if (mf_a().size() < s.fibers.size()) { mf_a().resize(s.fibers.size()); mf_b().resize(s.fibers.size()); }
-    mf_a()[me] = a;
-    mf_b()[me] = b;
+    put8(mf_a(), me, a);
+    put8(mf_b(), me, b);
     wave_rendezvous();
     const int col = lane & 31, hi = lane >> 5;
+    const F8* A = mf_a().data() + w * 64;
+    const F8 &b0 = mf_b()[w * 64 + col], &b1 = mf_b()[w * 64 + col + 32];
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
         float acc = c[r];
-        for (int k = 0; k < 16; ++k)
-            acc += bf(mf_a()[w * 64 + row + 32 * (k >> 3)][k & 7]) * bf(mf_b()[w * 64 + col + 32 * (k >> 3)][k & 7]);
+        for (int k = 0; k < 8; ++k) acc += A[row].v[k] * b0.v[k];
+        for (int k = 0; k < 8; ++k) acc += A[row + 32].v[k] * b1.v[k];
         c[r] = acc;
     }
     wave_rendezvous();
     return c;
 }
 
+typedef float v4f __attribute__((vector_size(16)));
+typedef short v4s16 __attribute__((vector_size(8)));
+inline std::vector<v4s16>& mf_a4() { static std::vector<v4s16> v; return v; }
+inline std::vector<v4s16>& mf_b4() { static std::vector<v4s16> v; return v; }
+// v_mfma_f32_16x16x32_bf16: lane l holds A[row = l & 15][k = 8 (l >> 4) .. +7], B[k = 8 (l >> 4) .. +7][col = l & 15];
+// accumulator register r of lane l is D[row = 4 (l >> 4) + r][col = l & 15]  (calibrated by t2v_attn_temporal)
+inline v4f mfma_16x16x32_bf16(v8u16 a, v8u16 b, v4f c) {
+    State& s = st();
+    const int me = s.fibers[s.cur].flat, w = me / 64, lane = me % 64;
+    if (mf_a().size() < s.fibers.size()) { mf_a().resize(s.fibers.size()); mf_b().resize(s.fibers.size()); }
+    put8(mf_a(), me, a);
+    put8(mf_b(), me, b);
+    wave_rendezvous();
+    const int col = lane & 15, g = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k)
+            acc += mf_a()[w * 64 + row + 16 * (k >> 3)].v[k & 7] * mf_b()[w * 64 + col + 16 * (k >> 3)].v[k & 7];
+        c[r] = acc;
+    }
+    wave_rendezvous();
+    return c;
+}
+// v_mfma_f32_16x16x16_bf16 (_1k form): 4 bf16 per lane, k = 4 (l >> 4) .. +3; same accumulator layout
+inline v4f mfma_16x16x16_bf16(v4s16 a, v4s16 b, v4f c) {
+    State& s = st();
+    const int me = s.fibers[s.cur].flat, w = me / 64, lane = me % 64;
+    if (mf_a4().size() < s.fibers.size()) { mf_a4().resize(s.fibers.size()); mf_b4().resize(s.fibers.size()); }
+    mf_a4()[me] = a;
+    mf_b4()[me] = b;
+    wave_rendezvous();
+    const int col = lane & 15, g = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k)
+            acc += bf((uint16_t)mf_a4()[w * 64 + row + 16 * (k >> 2)][k & 3]) * bf((uint16_t)mf_b4()[w * 64 + col + 16 * (k >> 2)][k & 3]);
+        c[r] = acc;
+    }
+    wave_rendezvous();
+    return c;
+}
+
+inline bool vote_any(bool pred) {
+    State& s = st();
+    const int me = s.fibers[s.cur].flat, w = me / 64;
+    s.slots[me] = pred ? 1 : 0;
+    wave_rendezvous();
+    bool r = false;
+    for (int i = w * 64; i < std::min<int>((w + 1) * 64, (int)s.fibers.size()); ++i) r = r || (!s.fibers[i].done && s.slots[i]);
+    wave_rendezvous();
+    return r;
+}
+// IEEE half <-> float (g++ 11 on x86 has no _Float16 in C++)
+struct half_t {
+    uint16_t bits;
+    half_t() : bits(0) {}
+    half_t(float f) {
+        uint32_t x; memcpy(&x, &f, 4);
+        const uint32_t sign = (x >> 16) & 0x8000u; x &= 0x7fffffffu;
+        if (x >= 0x7f800000u) { bits = (uint16_t)(sign | 0x7c00u | ((x & 0x7fffffu) ? 0x200u : 0)); return; }
+        if (x >= 0x477ff000u) { bits = (uint16_t)(sign | 0x7c00u); return; }                       // overflow -> inf
+        if (x < 0x33000001u) { bits = (uint16_t)sign; return; }                                    // underflow -> 0
+        int e = (int)(x >> 23) - 127;
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        int shift = e < -14 ? 13 + (-14 - e) : 13;
+        uint32_t h = e < -14 ? 0u : (uint32_t)(e + 15) << 10;
+        uint32_t mant = m >> shift, rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (e >= -14) mant &= 0x3ffu;
+        h += mant;
+        if (rem > half || (rem == half && (h & 1))) ++h;
+        bits = (uint16_t)(sign | h);
+    }
+    operator float() const {
+        const uint32_t sign = (uint32_t)(bits & 0x8000u) << 16, e = (bits >> 10) & 0x1f, m = bits & 0x3ffu;
+        uint32_t x;
+        if (e == 0) {
+            if (m == 0) x = sign;
+            else { int sh = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; ++sh; } x = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3ffu) << 13); }
+        } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+        else x = sign | ((e + 112) << 23) | (m << 13);
+        float f; memcpy(&f, &x, 4); return f;
+    }
+};
+
 }  // namespace hostsim
 
+#define _Float16 hostsim::half_t
+#define __any(p) hostsim::vote_any((p))
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : 1; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hostsim::mfma_16x16x32_bf16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, x, y, z) hostsim::mfma_16x16x16_bf16((a), (b), (c))
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 #define __builtin_amdgcn_readfirstlane(x) (x)  /* only ever applied to wave-uniform values */
