@@ -499,6 +499,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         ops.cast(st["ctx"], self.ctx)
         self.ctx_len = L
         self.ctx_kv = {}
+        self._ctx_f = None
         if self.training_lora:  # the M = B-row branch belongs to torch autograd (engine_lora.py); its result is an input
             assert st["emb_all"].shape == (B, off)
             self.emb_all = st["emb_all"]
@@ -533,22 +534,38 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                          lambda: torch.cat([pk.bias(l) for l in lins]).contiguous())
         self.emb_all = self.linear(emb_s, None, w=w_all, bias=b_all, out_dtype=torch.float32)
 
-    def context_kv_t(self, attn):
+    def context_kv_t(self, attn, per_frame=False):
         """Training: K / V of ONE cross-attention layer through its own injected to_k / to_v (token-major rows of the text
-        context), V^T by a per-clip transpose.  (Inference stacks all 16 layers' projections into two GEMMs.)"""
+        context), V^T by a per-image transpose.  (Inference stacks all 16 layers' projections into two GEMMs.)
+        ``per_frame``: project the context repeated per frame, as the reference does — needed when the LoRA branches' dropout
+        is active, so that every frame draws its own masks."""
         ops = self.ops
         B, L = self.B, self.ctx_len
         inner = attn.heads * attn.dim_head
         kp = _pad(L, 64)
-        kind, self.row_kind = self.row_kind, "ctx"  # (under dropout the frames of a clip share the K / V masks: DESIGN.md)
-        k = self.linear(self.ctx, attn.to_k, bias=None)
-        v = self.linear(self.ctx, attn.to_v, bias=None)
+        src, n_sets = self.ctx, B
+        if per_frame:
+            src, n_sets = self.context_per_frame(), B * self.F
+        kind, self.row_kind = self.row_kind, ("rows" if per_frame else "ctx")
+        k = self.linear(src, attn.to_k, bias=None)
+        v = self.linear(src, attn.to_v, bias=None)
         self.row_kind = kind
-        vt = self.buf(B * inner, kp)
+        vt = self.buf(n_sets * inner, kp)
         ops.fill_zero(vt)
-        ops.transpose(v, L, inner, vt, batch=B, in_stride=L * inner, out_stride=inner * kp)
+        ops.transpose(v, L, inner, vt, batch=n_sets, in_stride=L * inner, out_stride=inner * kp)
         self.pool.put(v)
         return k, vt, kp, inner * kp
+
+    def context_per_frame(self):
+        """The text context with each clip's rows repeated for its F frames ([(b f) l, D]; context.repeat_interleave of
+        openaimodel3d.py:710), built once per forward."""
+        if getattr(self, "_ctx_f", None) is None:
+            B, F, L = self.B, self.F, self.ctx_len
+            self._ctx_f = self.buf(B * F * L, self.ctx.shape[1])
+            for b in range(B):
+                for f in range(F):
+                    self.ops.cast(self.ctx[b * L:(b + 1) * L], self._ctx_f[(b * F + f) * L:(b * F + f + 1) * L])
+        return self._ctx_f
 
     def _backward_tape(self, dout, dx_out):
         d = self.exit_bwd(dout)
@@ -866,53 +883,64 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             heads, L = attn.heads, self.ctx_len
             q = self.linear(src, attn.to_q, bias=None)
             own_kv = self.training_lora and is_lora_leaf(attn.to_k) and is_lora_leaf(attn.to_v)
-            k, vt, kp, vt_stride = self.context_kv_t(attn) if own_kv else self.context_kv(attn)
+            # The frames of a clip share the text K / V (one attention of F*hw queries over L keys per clip and head) — unless
+            # the train-mode student's dropout sits on the to_k / to_v LoRA branches: the reference projects the context
+            # REPEATED per frame (openaimodel3d.py:710), so every frame draws its own masks and has its own K / V.
+            per_frame = own_kv and any(d.training and d.p > 0 for d in (attn.to_k.dropout, attn.to_v.dropout))
+            nf = F if per_frame else 1           # K / V sets per clip
+            mq = hw if per_frame else F * hw     # queries per K / V set
+            if own_kv:
+                k, vt, kp, vt_stride = self.context_kv_t(attn, per_frame)
+            else:
+                k, vt, kp, vt_stride = self.context_kv(attn)
             o = self.buf(M, inner)
-            ops.attn_spatial(q, k, vt, kp, o, n_img, hw, L, heads, F, attn.scale, vt_stride)
-            mq = F * hw  # the frames of a clip share K / V: per clip and head, ONE attention of F*hw queries over L keys
+            ops.attn_spatial(q, k, vt, kp, o, n_img, hw, L, heads, 1 if per_frame else F, attn.scale, vt_stride)
 
             def bwd(d_o):
                 d_q = self.buf(M, inner)
                 dk = dv = None
                 if own_kv:  # the text context itself carries no gradient, its injected to_k / to_v projections do
-                    dk, dv = self.buf(B * L, inner), self.buf(B * L, inner)
+                    dk, dv = self.buf(B * nf * L, inner), self.buf(B * nf * L, inner)
                     mqp = _pad(mq, 64)
-                hb = dict(batch=heads, batch_inner=heads)
+                ldk = k.stride(0)
+                hb = dict(batch=nf * heads, batch_inner=heads)  # z0 = K / V set (frame) of the clip, z1 = head
                 for b in range(B):
-                    rows = slice(b * mq, (b + 1) * mq)
+                    rows = slice(b * F * hw, (b + 1) * F * hw)
                     qb, dob, dqb = q[rows], d_o[rows], d_q[rows]
-                    kb = k[b * L:(b + 1) * L]
-                    vtb = torch.as_strided(vt, (inner, kp), (kp, 1), vt.storage_offset() + b * vt_stride)
-                    s = self.buf(heads * mq, kp)
+                    kb = k[b * nf * L:(b + 1) * nf * L]
+                    vtb = torch.as_strided(vt, (nf * inner, kp), (kp, 1), vt.storage_offset() + b * nf * vt_stride)
+                    s = self.buf(nf * heads * mq, kp)
                     ops.fill_zero(s)
-                    ops.gemm(qb[:, :64], kb[:, :64], s, M=mq, N=L, alpha=attn.scale, a_strides=(0, 64), w_strides=(0, 64),
-                             o_strides=(0, mq * kp), **hb)
-                    ops.softmax_rows(s, heads * mq, L, kp, kp)
-                    v_tok = self.buf(heads * kp, 64)
-                    ops.transpose(vtb, 64, kp, v_tok, batch=heads, in_stride=64 * kp, out_stride=kp * 64)
-                    dp = self.buf(heads * mq, kp)
-                    ops.gemm(dob[:, :64], v_tok, dp, M=mq, N=kp, a_strides=(0, 64), w_strides=(0, kp * 64),
-                             o_strides=(0, mq * kp), **hb)
+                    so = (heads * mq * kp, mq * kp)
+                    ops.gemm(qb[:, :64], kb[:, :64], s, M=mq, N=L, alpha=attn.scale, a_strides=(mq * inner, 64), w_strides=(L * ldk, 64),
+                             o_strides=so, **hb)
+                    ops.softmax_rows(s, nf * heads * mq, L, kp, kp)
+                    v_tok = self.buf(nf * heads * kp, 64)
+                    ops.transpose(vtb, 64, kp, v_tok, batch=nf * heads, in_stride=64 * kp, out_stride=kp * 64)
+                    dp = self.buf(nf * heads * mq, kp)
+                    ops.gemm(dob[:, :64], v_tok, dp, M=mq, N=kp, a_strides=(mq * inner, 64), w_strides=(heads * kp * 64, kp * 64),
+                             o_strides=so, **hb)
                     self.pool.put(v_tok)
-                    if own_kv:  # dV[kv][c] = sum_q P[q][kv] dO[q][c], contraction over all F*hw queries of the clip
-                        pT = self.tposed(s, mq, kp, batch=heads, in_stride=mq * kp)
-                        doT = self.tposed(dob, mq, inner)
-                        ops.gemm(pT, doT, dv[b * L:(b + 1) * L][:, :64], M=L, N=64, a_strides=(0, kp * mqp),
-                                 w_strides=(0, 64 * mqp), o_strides=(0, 64), split_k=self.split_for(L * heads, 64, mqp), **hb)
+                    kv_rows = slice(b * nf * L, (b + 1) * nf * L)
+                    wg = dict(a_strides=(heads * kp * mqp, kp * mqp), w_strides=(inner * mqp, 64 * mqp), o_strides=(L * inner, 64),
+                              split_k=self.split_for(L * heads, 64, mqp), **hb) if own_kv else None
+                    if own_kv:  # dV[kv][c] = sum_q P[q][kv] dO[q][c], contraction over all queries of the K / V set
+                        pT = self.tposed(s, mq, kp, batch=nf * heads, in_stride=mq * kp)
+                        doT = self.tposed(dob, mq, inner, batch=nf, in_stride=mq * inner)
+                        ops.gemm(pT, doT, dv[kv_rows][:, :64], M=L, N=64, **wg)
                         self.pool.put(pT, doT)
-                    ops.softmax_bwd_rows(s, dp, heads * mq, L, kp, kp)
+                    ops.softmax_bwd_rows(s, dp, nf * heads * mq, L, kp, kp)
                     self.pool.put(s)
-                    kT = self.buf(inner, kp)
+                    kT = self.buf(nf * inner, kp)
                     ops.fill_zero(kT)
-                    ops.transpose(kb, L, inner, kT, batch=1, in_stride=0, out_stride=0)
-                    ops.gemm(dp, kT, dqb[:, :64], M=mq, N=64, alpha=attn.scale, a_strides=(0, mq * kp),
-                             w_strides=(0, 64 * kp), o_strides=(0, 64), **hb)
+                    ops.transpose(kb, L, inner, kT, batch=nf, in_stride=L * ldk, out_stride=inner * kp)
+                    ops.gemm(dp, kT, dqb[:, :64], M=mq, N=64, alpha=attn.scale, a_strides=so, w_strides=(inner * kp, 64 * kp),
+                             o_strides=(mq * inner, 64), **hb)
                     self.pool.put(kT)
                     if own_kv:  # dK[kv][c] = scale * sum_q dS[q][kv] Q[q][c]
-                        dsT = self.tposed(dp, mq, kp, batch=heads, in_stride=mq * kp)
-                        qT = self.tposed(qb, mq, inner)
-                        ops.gemm(dsT, qT, dk[b * L:(b + 1) * L][:, :64], M=L, N=64, alpha=attn.scale, a_strides=(0, kp * mqp),
-                                 w_strides=(0, 64 * mqp), o_strides=(0, 64), split_k=self.split_for(L * heads, 64, mqp), **hb)
+                        dsT = self.tposed(dp, mq, kp, batch=nf * heads, in_stride=mq * kp)
+                        qT = self.tposed(qb, mq, inner, batch=nf, in_stride=mq * inner)
+                        ops.gemm(dsT, qT, dk[kv_rows][:, :64], M=L, N=64, alpha=attn.scale, **wg)
                         self.pool.put(dsT, qT)
                     self.pool.put(dp)
                 self.pool.put(q, d_o)
