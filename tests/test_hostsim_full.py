@@ -90,3 +90,31 @@ def test_training_step_on_the_real_library_only(full_ops, monkeypatch):
               f"max {float(errs.max()):.2e}")
         assert rel_l2(y, y_ref) < 3e-2 and rel_l2(dx, dx_ref) < 6e-2
         assert torch.isfinite(errs).all() and float(errs.median()) < 8e-2 and float(errs.max()) < 0.25
+
+
+@pytest.mark.skipif(os.environ.get("T2V_HOSTSIM_FULL") != "1", reason="minutes of simulation: set T2V_HOSTSIM_FULL=1")
+def test_train_mode_step_on_the_real_library_only(full_ops, monkeypatch):
+    """Train-mode student (dropout kernel, per-frame text K / V) on the real library: the same seed reproduces the step bit for
+    bit (the backward regenerates the forward's masks from it), another seed does not, every gradient is finite."""
+    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+    from tests.test_unet_lora_grad_cpu import _student
+    monkeypatch.setenv("T2V_UNVALIDATED_KERNELS", "1")
+    g = load("unet_tiny")
+    m, params = _student("unet_tiny", 64)
+    m.train()
+    x, ts, ctx, tc = g["x"][:, :, :2, :8, :8].contiguous(), g["ts"], g["ctx"], g["tc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
+    eng = UNetGradEngine(m, full_ops())
+    eng.bind_lora(params)
+    with torch.no_grad():
+        emb_all = m.conditioning_emb_all(ts, 16, tc, None)
+    res = []
+    for seed in (11, 12, 11):
+        y = eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all, seed=seed)
+        flat = torch.zeros(eng.lora_numel)
+        dx = eng.backward(r_out, flat_grad=flat, accumulate=False)
+        assert torch.isfinite(y).all() and torch.isfinite(dx).all() and torch.isfinite(flat).all()
+        res.append((y, dx, flat))
+    assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1]) and torch.equal(res[0][2], res[2][2])
+    assert rel_l2(res[1][0], res[0][0]) > 1e-3 and rel_l2(res[1][2], res[0][2]) > 1e-3
+    assert len(eng.drop_sites) > 100
