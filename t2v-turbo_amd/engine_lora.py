@@ -100,7 +100,7 @@ class LoraTrainMixin:
             r, cin, n_out = down.shape[0], down.shape[1], up.shape[0]
             taps = down.numel() // (r * cin)
             rp, ce, npad = _pad(r, RP), _pad(cin, 64), _pad(n_out, 64)
-            n_lp += 2 * rp * taps * ce + n_out * rp + rp * npad
+            n_lp += 2 * rp * taps * ce + n_out * rp + rp * npad + (taps * rp) ** 2 * (taps > 1)
             n_e += n_out * rp + taps * rp * ce
         self.lp = torch.zeros(n_lp, dtype=self.adt, device=dev)
         self.lp_idx = torch.full((n_lp,), -1, dtype=torch.int32, device=dev)
@@ -236,7 +236,16 @@ class LoraTrainMixin:
             o = self.lora_off[id(down)]
             self.g_idx[o:o + down.numel()] = e.reshape(-1).to(self.device, torch.int32)
         g.Df = self._lp_alloc(torch.cat(df_rows, dim=0))
-        g.Db = self._lp_alloc(torch.cat(db_cols, dim=1))
+        if taps > 1:
+            # conv leaves: the data-gradient pack of D and the 0/1 selection pack of the gathered rank-r gradient stacked along N,
+            # so ONE launch over g yields both (the selection's ones index the constant 1.0 behind the flat parameters)
+            sel = torch.full((taps, rp, taps, rp), -1, dtype=torch.int64)
+            for tap in range(taps):
+                sel[tap, torch.arange(rp), taps - 1 - tap, torch.arange(rp)] = self.one_idx
+            g.DbSel = self._lp_alloc(torch.cat([db_cols[0], sel.reshape(taps * rp, taps * rp)], dim=0))
+            g.Db = g.DbSel[:ce]
+        else:
+            g.Db = self._lp_alloc(torch.cat(db_cols, dim=1))
         g.ntot = sum(g.N)
         self._groups[key] = g
         return g

@@ -378,11 +378,16 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         dl = None
         if grp is not None:
             g = self.lora_wgrad(grp, dy.t if dy_pad is None else dy_pad, colsum)
-            dl = run(g, grp.Db, pool=False)                      # LoRA branch's data gradient (high-res for UP2: pooled with the base)
-            G = run(g, self.sel_pack(grp.taps, grp.rp))          # rank-r gradient gathered to the input grid, per tap
-            self.pool.put(g)
-            self.lora_wgrad_down(grp, G)
-            self.pool.put(G)
+            if mode == nt.GEMM_CONV3X3_UP2:
+                dl = run(g, grp.Db, pool=False)                  # LoRA branch's data gradient, high-res: pooled with the base
+                G = run(g, self.sel_pack(grp.taps, grp.rp))      # rank-r gradient gathered to the input grid, per tap
+                self.pool.put(g)
+                self.lora_wgrad_down(grp, G)
+                self.pool.put(G)
+            else:  # both from one launch: columns [0, ce) = data gradient, [ce, ce + taps*rp) = gathered rank-r gradient
+                dl = run(g, grp.DbSel)
+                self.pool.put(g)
+                self.lora_wgrad_down(grp, dl[:, grp.ce:])
         cin = base.shape[0]
         res = None if dl is None else dl[:, :cin]
         dx = run(dy.t, base, residual=res, odt=out_dtype)
@@ -463,12 +468,11 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 ops.ncfhw_to_tokens(dout, d64)
                 g = self.lora_wgrad(grp, d64)
                 self.pool.put(d64)
-                dl = self.conv(Act(g, n_img, H, W), None, nt.GEMM_CONV3X3, w=grp.Db, bias=None).t
-                G = self.conv(Act(g, n_img, H, W), None, nt.GEMM_CONV3X3, w=self.sel_pack(9, grp.rp), bias=None).t
+                dl = self.conv(Act(g, n_img, H, W), None, nt.GEMM_CONV3X3, w=grp.DbSel, bias=None).t
                 self.pool.put(g)
-                self.lora_wgrad_down(grp, G)
-                dt2 = self.add(dt, dl)
-                self.pool.put(G, dt, dl)
+                self.lora_wgrad_down(grp, dl[:, grp.ce:])
+                dt2 = self.add(dt, dl[:, :grp.ce])
+                self.pool.put(dt, dl)
                 dt = dt2
             dx = self.gn_b(xin, m.out[0], n_img, H * W, True, st_out, dt)
             self.pool.put(dt, st_out)
