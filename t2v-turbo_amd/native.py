@@ -238,7 +238,8 @@ class HipOps:
         d.out, d.ldo = _p(out), _row_stride(out)
         d.out_f32 = 1 if out.dtype == torch.float32 else 0
         taps = {GEMM_LINEAR: 1, GEMM_TCONV3: 3}.get(mode, 9)
-        tuned = self.tune.get((mode, M, N, taps * (d.c0 + d.c1), batch)) if (tile_cfg == 0 and split_k == 0) else None
+        # a split_k argument without a tile id is a hint (the training engine's token-contracted weight gradients): a tuned entry wins
+        tuned = self.tune.get((mode, M, N, taps * (d.c0 + d.c1), batch)) if tile_cfg == 0 else None
         d.tile_cfg, d.split_k = tuned if tuned else (tile_cfg, split_k)
         ws = self.workspace(a0.device)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()

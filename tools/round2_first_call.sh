@@ -23,3 +23,5 @@ T2V_UNVALIDATED_KERNELS=1 T2V_HIP_GRAPH=1 timeout 500 python tools/distill_bench
 export TMPDIR=/tmp
 T2V_UNVALIDATED_KERNELS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_distill_native -- \
     python tools/distill_bench.py --steps 2 --warmup 1 --native-student 1 > gpurun_out/prof_distill_native.log 2>&1
+# (after the above is green) tune the student step's GEMM shapes next to the inference ones:
+#   T2V_UNVALIDATED_KERNELS=1 python tools/tune_gemm.py --train 1      (split-K candidates up to 64 for the token-contracted shapes)

@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "t2v-turbo_amd", "gemm_tune.json"))
     ap.add_argument("--widen", type=int, default=1, help="also tune the VAE encode / decode-gradient / ModelScope shapes")
     ap.add_argument("--cold", type=int, default=0, help="evict caches before every timed launch (what the UNet step sees)")
+    ap.add_argument("--train", type=int, default=0,
+                    help="also tune the shapes of the native student step (LoRA rank 64: LoRA branch, data gradients, token-contracted "
+                         "weight gradients); needs T2V_UNVALIDATED_KERNELS=1 until that path has been validated on hardware")
     args = ap.parse_args()
     os.environ["T2V_GEMM_TUNE"] = "0"  # record with the library heuristics
     import bench
@@ -152,6 +155,27 @@ def main():
                    torch.randn(1, 77, 1024, device=dev, dtype=torch.bfloat16),
                    timestep_cond=torch.randn(1, 256, device=dev, dtype=torch.bfloat16))
             recs.append(next(iter(ms.native_engine().plans.values()))["rec"])
+    if args.train:
+        from t2v_turbo_amd import lora
+        from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+        student = bench.build_model(dev, torch.float32)
+        student.requires_grad_(False)
+        lora.inject_trainable_lora_extended(student, r=64)
+        student.to(dev).eval()
+        lparams = lora.lora_parameters(student)
+        with torch.no_grad():
+            for p_ in lparams:
+                if float(p_.abs().max()) == 0.0:
+                    p_.normal_(0.0, 0.01)
+        teng = UNetGradEngine(student, nt.HipOps())
+        teng.bind_lora(lparams)
+        ts_ = torch.tensor([999], device=dev)
+        with torch.no_grad():
+            emb_all = student.conditioning_emb_all(ts_, 16, tc.float())
+        teng.forward_tape(x.float(), ts_, ctx.float(), 16, tc.float(), None, emb_all=emb_all)
+        teng.backward(torch.randn_like(x.float()), flat_grad=torch.zeros(teng.lora_numel, device=dev))
+        tp = next(iter(teng.plans.values()))
+        recs += [tp["rec"], tp["rec_bwd"]]
     lib = nt.load()
     ncfg = lib.t2v_gemm_num_configs()
     cand_table = {}
@@ -175,8 +199,8 @@ def main():
             base = time_desc(lib, fn, a, stream, 0, 0, cold=bool(args.cold))
             best = (base, 0, 0)
             nk = K // 64
-            splits = [1] + [s for s in (2, 3, 4, 6, 8, 12, 16) if nk // s >= 4 and d.act != nt.ACT_GEGLU and d.N % 4 == 0
-                            and d.M * d.N * 4 * s * max(d.batch, 1) <= d.ws_bytes and d.M <= 4096]
+            splits = [1] + [s for s in (2, 3, 4, 6, 8, 12, 16, 32, 64) if nk // s >= 4 and d.act != nt.ACT_GEGLU and d.N % 4 == 0
+                            and d.M * d.N * 4 * s * max(d.batch, 1) <= d.ws_bytes and d.M <= 4096 and (s <= 16 or nk >= 256)]
             allt = {}
             ck = "/".join(str(v) for v in key)
             if not args.full and ck in cand_table:
