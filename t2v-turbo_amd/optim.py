@@ -62,6 +62,11 @@ class FlatAdamW:
             self.exp_avg_sq.mul_(b2).addcmul_(gr, gr, value=1 - b2)
             bc1, bc2 = 1 - b1 ** self.step_count, 1 - b2 ** self.step_count
             self.flat_param.addcdiv_(self.exp_avg, self.exp_avg_sq.sqrt() / bc2 ** 0.5 + self.eps, value=-self.lr / bc1)
+        # The parameters are views of flat_param through ``.data``: neither the fused kernel nor an in-place op on the flat
+        # buffer moves THEIR version counters, and the native engines key their packed (LoRA-merged) weights on those
+        # (engine.params_fingerprint).  Touch one parameter so that a later inference call re-packs instead of sampling with
+        # the weights of the previous step.
+        self.params[0].add_(0.0)
         return norm
 
     def zero_grad(self):

@@ -34,3 +34,20 @@ def test_flat_adamw_matches_torch_on_cpu():
     t, s = torch.ones(10), torch.zeros(10)
     update_ema_flat(t, s, 0.9)
     assert torch.allclose(t, torch.full((10,), 0.9))
+
+
+def test_flat_step_invalidates_the_engines_weight_fingerprint():
+    """The parameters are ``.data`` views of the flat buffer: updating the buffer in place (fused kernel or torch op) does not
+    move their version counters, which the native engines' packed-weight cache is keyed on.  A step must change the
+    fingerprint, or a later inference call would sample with the previous step's (LoRA-merged) weights."""
+    from t2v_turbo_amd.engine import params_fingerprint
+    lin = torch.nn.Linear(6, 4)
+    ps = list(lin.parameters())
+    sync = FlatGradSync(ps)
+    opt = FlatAdamW(ps, sync, lr=1e-2)
+    fp0 = params_fingerprint(lin)
+    sync.flat.normal_()
+    before = lin.weight.detach().clone()
+    opt.step()
+    assert not torch.equal(lin.weight.detach(), before)
+    assert params_fingerprint(lin) != fp0
