@@ -74,10 +74,14 @@ class FlatAdamW:
 
 
 @torch.no_grad()
-def update_ema_flat(target_flat, source_flat, rate=0.99):
-    """EMA of a flat fp32 parameter buffer (utils/common_utils.py:307-319) in one kernel."""
+def update_ema_flat(target_flat, source_flat, rate=0.99, target_params=None):
+    """EMA of a flat fp32 parameter buffer (utils/common_utils.py:307-319) in one kernel.  ``target_params``: the target
+    network's parameters if they are ``.data`` views of ``target_flat`` — one of their version counters is moved so that the
+    native engines re-pack the target's weights (see FlatAdamW.step)."""
     if target_flat.is_cuda:
         from .native import HipOps
         HipOps().ema_update(target_flat, source_flat, rate)
     else:
         target_flat.mul_(rate).add_(source_flat, alpha=1 - rate)
+    if target_params:
+        target_params[0].add_(0.0)
