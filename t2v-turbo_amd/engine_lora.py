@@ -109,7 +109,7 @@ class LoraTrainMixin:
         self.e_used = 0
         self.g_idx = torch.full((self.lora_numel,), -1, dtype=torch.int32, device=dev)
         self.src_flat = torch.empty(self.lora_numel + 1, dtype=torch.float32, device=dev)
-        self.one_idx = self.lora_numel  # src_flat[-1] == 1: constant entries of an operand (none today) can index it
+        self.one_idx = self.lora_numel  # src_flat[-1] == 1: the constant entries of an operand (the selection packs) index it
         self._groups = {}
         self._refresh_src()
 
