@@ -118,3 +118,48 @@ def test_train_mode_step_on_the_real_library_only(full_ops, monkeypatch):
     assert torch.equal(res[0][0], res[2][0]) and torch.equal(res[0][1], res[2][1]) and torch.equal(res[0][2], res[2][2])
     assert rel_l2(res[1][0], res[0][0]) > 1e-3 and rel_l2(res[1][2], res[0][2]) > 1e-3
     assert len(eng.drop_sites) > 100
+
+
+def test_vae_decode_and_encode_on_the_real_library_match_the_reference_fixtures(full_ops):
+    """The VAE engines (hardware-validated) on the simulated library against the fixtures made by running the reference: a second
+    model family through the simulator's GEMM / GroupNorm / softmax / small-channel conv models (stride-2 convs with the
+    encoder's asymmetric padding, the single-head 512-wide attention as GEMMs)."""
+    from t2v_turbo_amd.engine_vae import VAEDecodeEngine, VAEEncodeEngine
+    from t2v_turbo_amd.vae import AutoencoderKL
+    from tests.util import VAE_TINY_DD
+    g = load("vae_tiny")
+    ae = AutoencoderKL(ddconfig=VAE_TINY_DD, embed_dim=4).eval()
+    ae.load_state_dict(synth_state_dict(manifest("vae_tiny")), strict=True)
+    ae.requires_grad_(False)
+    z = g["z"][:, :, :1].contiguous()
+    v = VAEDecodeEngine(ae, full_ops()).decode_frames(z, scale=1.0 / 0.18215)
+    assert v.shape == g["video"][:, :, :1].shape
+    assert rel_l2(v, g["video"][:, :, :1]) < 3e-2
+    e = load("vae_tiny_enc")
+    img = e["x"][:1].unsqueeze(2).contiguous()                     # (b, 3, t = 1, H, W)
+    mom = VAEEncodeEngine(ae, full_ops()).encode_frames(img)      # (b, 8, 1, H/8, W/8)
+    ref = e["moments"][:1].unsqueeze(2)
+    assert mom.shape == ref.shape and rel_l2(mom.float(), ref) < 3e-2
+
+
+def test_vae_decode_gradient_engine_on_the_real_library(full_ops):
+    """d(loss)/d(latents) through the VAE decoder (reward branch, hardware-validated kernels of csrc/backward.hip in engine
+    context) on the simulated library vs torch autograd through the module."""
+    from t2v_turbo_amd.engine_vae_bwd import VAEDecodeGradEngine
+    from t2v_turbo_amd.vae import AutoencoderKL
+    from tests.util import VAE_TINY_DD
+    ae = AutoencoderKL(ddconfig=VAE_TINY_DD, embed_dim=4).eval()
+    ae.load_state_dict(synth_state_dict(manifest("vae_tiny")), strict=True)
+    ae.requires_grad_(False)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(1, 4, 8, 8, generator=g)
+    dout = torch.randn(1, 3, 64, 64, generator=g)
+    zz = z.clone().requires_grad_(True)
+    ae.native_mode = "off"
+    ref = ae.decode(zz)
+    (ref * dout).sum().backward()
+    eng = VAEDecodeGradEngine(ae, full_ops())
+    out = eng.decode_frames_tape(z.unsqueeze(2), scale=1.0).squeeze(2)
+    dz = eng.backward(dout.unsqueeze(2)).squeeze(2)
+    assert rel_l2(out, ref.detach()) < 3e-2
+    assert rel_l2(dz, zz.grad) < 5e-2
