@@ -258,6 +258,19 @@ int t2v_sumsq(const float* x, long long n, float* ws, float* out, void* stream);
  * train_t2v_turbo_v1_lora.py:1190). */
 int t2v_gather_f32(const float* src, const int* idx, float alpha, void* out, int dt_out, int accumulate, long long n,
                    void* stream);
+/* t2v_attn_spatial_bwd: flash-style backward of the spatial SELF-attention (head dim 64): dQ, dK, dV from token-major Q / K / V /
+ * dO and the forward's O, the [queries x keys] probabilities recomputed tile by tile (never written to memory).  Two launches:
+ * per query block (statistics L = log2-sum-exp and D = sum_c dO O into l2 / dsum, then dQ), per key block (dK, dV).
+ * q, k, dout, o, dq, dk, dv: bf16 [n_img*seq][ld], head h at column 64 h.  v: bf16, row r of (img, head) at
+ * v + img*v_img_stride + head*v_head_stride + r*ldv (token-major buffer or the per-head [keys][64] transpose of V^T).
+ * kt, qt, dot: K^T, Q^T, dO^T per image, [n_img][heads*64][ld] with the sequence zero-padded to a multiple of 64
+ * (t2v_transpose_pad_bf16).  l2, dsum: fp32 workspaces [n_img*heads][ld_stat], ld_stat >= seq_q.
+ * Replaces the autograd backward of CrossAttention.forward for attn1 of the spatial transformers (attention.py:102-164). */
+int t2v_attn_spatial_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, long long v_img_stride,
+                         long long v_head_stride, const void* kt, int ld_kt, const void* qt, const void* dot, int ld_qt,
+                         const void* dout, int ldo, const void* o, int ldoo, float* l2, float* dsum, int ld_stat, void* dq, int lddq,
+                         void* dk, int lddk, void* dv, int lddv, int n_img, int seq_q, int seq_kv, int heads, float scale,
+                         void* stream);
 /* t2v_transpose_pad_bf16: out[b][c][r] = in[b][r][c] for r < rows and 0 for rows <= r < roundup(rows, 64) — the K-contiguous,
  * K-padded operand of the token-contracted weight-gradient GEMMs (dU = dy^T t, dD = G^T x) in one pass; 16-byte accesses on both
  * sides: cols % 8 == 0, ld_in % 8 == 0, ld_out % 8 == 0 and >= roundup(rows, 64), 16-byte aligned bases, batch strides % 8. */

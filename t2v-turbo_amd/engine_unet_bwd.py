@@ -23,6 +23,8 @@ for the 16-frame temporal ones), everything element-wise.
 Status: the dataflow is verified on CPU against torch autograd (tests/test_unet_grad_cpu.py, emulated op backend), and the
 device kernels of the new ops (csrc/backward_unet.hip, csrc/train.hip) run as real source on a host SIMT simulator
 (tests/test_hostsim_kernels.py) but have not run on hardware yet; ``native`` use raises until ``T2V_UNVALIDATED_KERNELS=1`` is set."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -33,6 +35,10 @@ from .unet3d import Downsample, ResBlock, SpatialTransformer, TemporalTransforme
 
 
 class UNetGradEngine(LoraTrainMixin, UNetEngine):
+    # T2V_FLASH_ATTN_BWD=1: spatial self-attention backward by the flash-style kernels of csrc/attention_bwd.hip instead of the
+    # GEMM-formulated one (both unvalidated on hardware; the GEMM form is built from validated kernels and stays the default)
+    flash_attn_bwd = os.environ.get("T2V_FLASH_ATTN_BWD", "0") == "1"
+
     # ---- public: forward with tape, then backward ----------------------------------------------------------------
     def _active_dropouts(self):
         """Number of active Dropout(p > 0) modules; in LoRA training they must all be ones the engine (or torch's conditioning
@@ -823,12 +829,43 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 # out of a GEMM with the weight as the row operand)
                 v = self.linear(src, attn.to_v, bias=None)
                 ops.transpose(v, hw, inner, vt, batch=n_img, in_stride=hw * inner, out_stride=inner * kp)
-                self.pool.put(v)
+                if not self.flash_attn_bwd:
+                    self.pool.put(v)
+                    v = None
             else:
+                v = None
                 ops.gemm(pk.mat(attn.to_v), src, vt, M=inner, N=hw, batch=n_img, w_strides=(hw * src.stride(0), 0), o_strides=(inner * kp, 0))
             o = self.buf(M, inner)
             ops.attn_spatial(qk[:, :inner], qk[:, inner:], vt, kp, o, n_img, hw, hw, heads, 1, attn.scale)
             nb = n_img * heads
+            if self.flash_attn_bwd:
+                self.hold(o)  # the flash-style backward needs the forward's output (D = rowsum(dO * O))
+
+            def bwd_flash(d_o):
+                """dQ / dK / dV without the [queries x keys] matrices in memory (csrc/attention_bwd.hip): two launches + the
+                three small operand transposes, instead of 5 batched GEMMs over 2 x 1 GB matrices, 2 softmax passes and 4 large
+                transposes at the 2560-token level."""
+                q, k = qk[:, :inner], qk[:, inner:]
+                ld = qk.stride(0)
+                if v is not None:   # token-major V of the training path
+                    v_buf, vis, vhs = v, hw * inner, 64
+                else:               # per (image, head) [keys][64]: the transpose of the forward's V^T rows
+                    v_buf = self.buf(nb * kp, 64)
+                    ops.transpose(vt, 64, kp, v_buf, batch=nb, in_stride=64 * kp, out_stride=kp * 64)
+                    vis, vhs = heads * kp * 64, kp * 64
+                kT = self.tposed(k, hw, inner, batch=n_img, in_stride=hw * ld)
+                qT = self.tposed(q, hw, inner, batch=n_img, in_stride=hw * ld)
+                doT = self.tposed(d_o, hw, inner, batch=n_img, in_stride=hw * inner)
+                l2, dsum = self.buf(nb, kp, torch.float32), self.buf(nb, kp, torch.float32)
+                dqk, d_v = self.buf(M, 2 * inner), self.buf(M, inner)
+                ops.attn_spatial_bwd(q, k, v_buf, vis, vhs, kT, qT, doT, d_o, o, l2, dsum, dqk[:, :inner], dqk[:, inner:], d_v,
+                                     n_img, hw, heads, attn.scale)
+                self.pool.put(kT, qT, doT, l2, dsum, v_buf, vt, qk, d_o)
+                self.drop(o)
+                d1 = self.lin_b(dqk, self.mats_t([attn.to_q, attn.to_k], "qk_t"), lora=[attn.to_q, attn.to_k])
+                d_ln = self.lin_b(d_v, pk.mat_t(attn.to_v), residual=d1, lora=[attn.to_v])
+                self.pool.put(dqk, d_v, d1)
+                return d_ln
 
             def tposed(src2d, rows, cols, in_stride, batch):
                 """[batch][rows][cols] -> [batch][cols][kp] (rows padded with zeros up to kp)."""
@@ -881,7 +918,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 d_ln = self.lin_b(d_v, pk.mat_t(attn.to_v), residual=d1, lora=[attn.to_v])
                 self.pool.put(dqk, d_v, d1)
                 return d_ln
-            return o, bwd
+            return o, (bwd_flash if self.flash_attn_bwd else bwd)
 
         def cross_attn(attn, src):
             heads, L = attn.heads, self.ctx_len

@@ -108,6 +108,10 @@ _SIGS = {
     "t2v_ema_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_longlong, C.c_void_p]),
     "t2v_sumsq": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
     "t2v_gather_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_void_p]),
+    "t2v_attn_spatial_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_longlong,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "t2v_transpose_pad_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
                                          C.c_longlong, C.c_void_p]),
     "t2v_dropout_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float,
@@ -380,6 +384,13 @@ class HipOps:
         """out.flat[i] = alpha * src.flat[idx[i]] (0 where idx < 0), or += with ``accumulate``; src fp32, idx int32."""
         assert src.dtype == torch.float32 and idx.dtype == torch.int32 and idx.numel() == out.numel()
         self._call("t2v_gather_f32", _p(src), _p(idx), alpha, _p(out), _DT[out.dtype], 1 if accumulate else 0, out.numel())
+
+    def attn_spatial_bwd(self, q, k, v, v_img_stride, v_head_stride, kt, qt, dot, dout, o, l2, dsum, dq, dk, dv, n_img, seq, heads, scale):
+        """Flash-style backward of the spatial self-attention (see include/t2v_hip.h); kt / qt / dot: [n_img*heads*64, padded seq]."""
+        self._call("t2v_attn_spatial_bwd", _p(q), _row_stride(q), _p(k), _row_stride(k), _p(v), _row_stride(v), v_img_stride,
+                   v_head_stride, _p(kt), _row_stride(kt), _p(qt), _p(dot), _row_stride(qt), _p(dout), _row_stride(dout), _p(o),
+                   _row_stride(o), _p(l2), _p(dsum), _row_stride(l2), _p(dq), _row_stride(dq), _p(dk), _row_stride(dk), _p(dv),
+                   _row_stride(dv), n_img, seq, seq, heads, scale)
 
     def transpose_pad(self, src, rows, cols, out, batch=1, in_stride=0, out_stride=0):
         """out[b][c][r] = src[b][r][c], zero for rows <= r < roundup(rows, 64) (16-byte accesses; see include/t2v_hip.h)."""

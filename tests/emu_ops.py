@@ -254,6 +254,22 @@ class EmuOps:
             a = _strided(src, rows, cols, src.stride(0), b * in_stride)
             _strided(out, cols, rows, out.stride(0), b * out_stride).copy_(a.t())
 
+    def attn_spatial_bwd(self, q, k, v, v_img_stride, v_head_stride, kt, qt, dot, dout, o, l2, dsum, dq, dk, dv, n_img, seq, heads, scale):
+        """(dq, dk, dv) of softmax(scale q k^T) v per (image, head); the transposed operands / workspaces are the kernel's business."""
+        self._log("attn_spatial_bwd")
+        for img in range(n_img):
+            r = slice(img * seq, (img + 1) * seq)
+            for hd in range(heads):
+                c = slice(hd * 64, (hd + 1) * 64)
+                Q, Kk, dO = q[r, c].float(), k[r, c].float(), dout[r, c].float()
+                V = torch.as_strided(v, (seq, 64), (v.stride(0), 1), v.storage_offset() + img * v_img_stride + hd * v_head_stride).float()
+                P = (Q @ Kk.t() * scale).softmax(dim=1)
+                dP = dO @ V.t()
+                dS = P * (dP - (P * dP).sum(dim=1, keepdim=True))
+                dq[r, c] = (dS @ Kk * scale).to(dq.dtype)
+                dk[r, c] = (dS.t() @ Q * scale).to(dk.dtype)
+                dv[r, c] = (P.t() @ dO).to(dv.dtype)
+
     def transpose_pad(self, src, rows, cols, out, batch=1, in_stride=0, out_stride=0):
         self._log("transpose_pad")
         rp = (rows + 63) // 64 * 64

@@ -61,7 +61,8 @@ def test_unet_forward_on_the_real_library_matches_the_oracle_fixture(full_ops):
 
 
 @pytest.mark.skipif(os.environ.get("T2V_HOSTSIM_FULL") != "1", reason="minutes of simulation: set T2V_HOSTSIM_FULL=1")
-def test_training_step_on_the_real_library_only(full_ops, monkeypatch):
+@pytest.mark.parametrize("flash", [False, True])
+def test_training_step_on_the_real_library_only(full_ops, monkeypatch, flash):
     """The native student step — forward, backward, all LoRA gradients — with NOTHING emulated: every launch is real kernel
     source on the simulator, through the GPU path's record / replay protocol."""
     from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
@@ -73,6 +74,7 @@ def test_training_step_on_the_real_library_only(full_ops, monkeypatch):
     r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
     y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 16, tc, None, r_out)
     eng = UNetGradEngine(m, full_ops())
+    eng.flash_attn_bwd = flash  # spatial self-attention backward: flash-style kernels (csrc/attention_bwd.hip) or the GEMM form
     eng.bind_lora(params)
     for step in range(2):  # second pass: replayed lists, LoRA operand packs refreshed by the gather kernel
         emb_all = m.conditioning_emb_all(ts, 16, tc, None)

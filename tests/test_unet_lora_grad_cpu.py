@@ -319,3 +319,26 @@ def test_record_replay_protocol_of_the_native_backend(monkeypatch):
     y3 = eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all.detach(), seed=11)
     assert len(eng.plans) == 2 and torch.equal(y1, y3) and rel_l2(y2, y1) > 1e-3
     assert torch.isfinite(eng.backward(r_out, flat_grad=torch.zeros(eng.lora_numel))).all()
+
+
+def test_flash_attention_backward_variant_of_the_engine():
+    """``flash_attn_bwd``: the spatial self-attention backward as ONE op (csrc/attention_bwd.hip) instead of batched GEMMs around
+    materialised probabilities — same gradients, in LoRA training and with frozen weights (V^T-from-GEMM layout)."""
+    g = load("unet_tiny")
+    m, params = _student("unet_tiny", 64)
+    x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
+    y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 16, tc, None, r_out)
+    eng = UNetGradEngine(m, EmuOps(strict=True))
+    eng.flash_attn_bwd = True
+    eng.bind_lora(params)
+    y, dx, grads = _engine_step(eng, m, params, x, ts, ctx, 16, tc, None, r_out)
+    assert eng.ops.calls.count("attn_spatial_bwd") == 16 and eng.ops.calls.count("softmax_bwd_rows") == 16  # (text cross-attention keeps the GEMM form)
+    assert rel_l2(y, y_ref) < 2e-5 and rel_l2(dx, dx_ref) < 1e-4
+    _compare(params, grads, g_ref, m)
+    # frozen weights (data gradient only): V comes as V^T out of a GEMM, the kernel reads its per-head transpose
+    m.requires_grad_(False)
+    eng2 = UNetGradEngine(m, EmuOps(strict=True))
+    eng2.flash_attn_bwd = True
+    y2 = eng2.forward_tape(x, ts, ctx, 16, tc, None)
+    assert rel_l2(y2, y_ref) < 2e-5 and rel_l2(eng2.backward(r_out), dx_ref) < 1e-4
