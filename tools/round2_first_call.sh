@@ -25,3 +25,5 @@ T2V_UNVALIDATED_KERNELS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-
     python tools/distill_bench.py --steps 2 --warmup 1 --native-student 1 > gpurun_out/prof_distill_native.log 2>&1
 # (after the above is green) tune the student step's GEMM shapes next to the inference ones:
 #   T2V_UNVALIDATED_KERNELS=1 python tools/tune_gemm.py --train 1      (split-K candidates up to 64 for the token-contracted shapes)
+# 5. the same step with the flash-style spatial-attention backward (csrc/attention_bwd.hip) instead of the GEMM-formulated one
+T2V_UNVALIDATED_KERNELS=1 T2V_FLASH_ATTN_BWD=1 timeout 500 python tools/distill_bench.py --steps 3 --native-student 1 2>&1 | tail -1 | tee gpurun_out/distill_native_flash.txt
