@@ -271,6 +271,12 @@ int t2v_attn_spatial_bwd(const void* q, int ldq, const void* k, int ldk, const v
                          const void* dout, int ldo, const void* o, int ldoo, float* l2, float* dsum, int ld_stat, void* dq, int lddq,
                          void* dk, int lddk, void* dv, int lddv, int n_img, int seq_q, int seq_kv, int heads, float scale,
                          void* stream);
+/* t2v_wgrad_tn: out[R][C] (fp32, row stride ldo) = alpha * a[:, :R]^T b[:, :C] for two TOKEN-MAJOR bf16 operands a [M][lda],
+ * b [M][ldb] — the token-contracted LoRA weight gradients (dU = s dy^T t, dD = G^T x) and per-clip column sums without transposed
+ * operand copies.  The token range is split over workgroups (splits = 0: library choice); fp32 partial tiles go through the
+ * caller's workspace ws (>= splits*R*C*4 bytes, the split count shrinks to fit) and are added in a fixed order. */
+int t2v_wgrad_tn(const void* a, int lda, const void* b, int ldb, long long M, int R, int C, float alpha, float* out, int ldo, float* ws,
+                 long long ws_bytes, int splits, void* stream);
 /* t2v_transpose_pad_bf16: out[b][c][r] = in[b][r][c] for r < rows and 0 for rows <= r < roundup(rows, 64) — the K-contiguous,
  * K-padded operand of the token-contracted weight-gradient GEMMs (dU = dy^T t, dD = G^T x) in one pass; 16-byte accesses on both
  * sides: cols % 8 == 0, ld_in % 8 == 0, ld_out % 8 == 0 and >= roundup(rows, 64), 16-byte aligned bases, batch strides % 8. */

@@ -1,0 +1,117 @@
+// Token-contracted weight-gradient product  out[R][C] = alpha * sum_m a[m][r] * b[m][c]   (A^T B) for two TOKEN-MAJOR bf16 operands:
+// the LoRA weight gradients dU = s dy^T t and dD = G^T x, and the per-clip column sums, without first transposing both operands to
+// K-contiguous copies for t2v_gemm (1 954 t2v_transpose_pad_bf16 launches and 48 GB per student step in the launch census,
+// profiles/r01_student_step_census.txt).
+//
+// 64 x 64 output tile per workgroup (4 waves, 32 x 32 each), the token range split over blockIdx.z; per step 64 tokens of both operands
+// go to LDS row-major (16-byte global loads), and each lane gathers its MFMA fragments — 8 consecutive TOKENS of one column — with
+// 2-byte LDS reads down a column (row pitch 66 elements = 33 words: the 32 lanes of a half-wave read 32 consecutive columns of one
+// row).  fp32 partial tiles go to a workspace; a second kernel adds them in a fixed order (deterministic) and applies alpha.
+// First version: the column gather is what ds_read_b64_tr_b16 exists for, the loads are not overlapped with the MFMAs.
+// NOT yet run on hardware; verified on the host SIMT simulator (tests/test_hostsim_kernels.py).
+#include "common.h"
+
+namespace {
+
+constexpr int WT_TOK = 64, WT_PITCH = 66;
+
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb, long long M,
+                                                       int R, int C, long long tok_per_split, float* __restrict__ ws) {
+    __shared__ bf16_t sa[WT_TOK][WT_PITCH];
+    __shared__ bf16_t sb[WT_TOK][WT_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;  // this wave's 32 x 32 sub-tile
+    const long long m_begin = (long long)blockIdx.z * tok_per_split;
+    const long long m_end = m_begin + tok_per_split < M ? m_begin + tok_per_split : M;
+    f32x16_t acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (long long m0 = m_begin; m0 < m_end; m0 += WT_TOK) {
+        __syncthreads();
+        // 64 tokens x 64 columns of each operand: 512 16-byte chunks per operand, two per thread
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qd = tid + 256 * i, row = qd >> 3, ch = (qd & 7) * 8;
+            const long long m = m0 + row;
+            uint4 ua = make_uint4(0, 0, 0, 0), ub = make_uint4(0, 0, 0, 0);
+            if (m < m_end) {
+                if (r0 + ch + 8 <= R) ua = *(const uint4*)(a + m * lda + r0 + ch);
+                else
+                    for (int e = 0; e < 8; ++e)
+                        if (r0 + ch + e < R) ((bf16_t*)&ua)[e] = a[m * lda + r0 + ch + e];
+                if (c0 + ch + 8 <= C) ub = *(const uint4*)(b + m * ldb + c0 + ch);
+                else
+                    for (int e = 0; e < 8; ++e)
+                        if (c0 + ch + e < C) ((bf16_t*)&ub)[e] = b[m * ldb + c0 + ch + e];
+            }
+            uint32_t* pa = (uint32_t*)&sa[row][ch];
+            uint32_t* pb = (uint32_t*)&sb[row][ch];
+            pa[0] = ua.x; pa[1] = ua.y; pa[2] = ua.z; pa[3] = ua.w;
+            pb[0] = ub.x; pb[1] = ub.y; pb[2] = ub.z; pb[3] = ub.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {  // 16 tokens per MFMA: this lane's 8 are ks*16 + 8*hi + 0..7
+            const int t0 = ks * 16 + 8 * hi;
+            uint32_t wa[4], wb[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wa[e] = (uint32_t)sa[t0 + 2 * e][wr + l31] | ((uint32_t)sa[t0 + 2 * e + 1][wr + l31] << 16);
+                wb[e] = (uint32_t)sb[t0 + 2 * e][wc + l31] | ((uint32_t)sb[t0 + 2 * e + 1][wc + l31] << 16);
+            }
+            uint4 fa = make_uint4(wa[0], wa[1], wa[2], wa[3]), fb = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&fa, *(bf16x8_t*)&fb, acc, 0, 0, 0);
+        }
+    }
+    // D[row = (e & 3) + 8 (e >> 2) + 4 hi][col = l31] of the wave's sub-tile -> partial slab [split][R][C]
+    float* slab = ws + (long long)blockIdx.z * R * C;
+    const int c = c0 + wc + l31;
+    if (c < C) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = r0 + wr + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (r < R) slab[(long long)r * C + c] = acc[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_tn_reduce_kernel(const float* __restrict__ ws, int splits, int R, int C, float alpha,
+                                                              float* __restrict__ out, int ldo) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)R * C) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(long long)k * R * C + idx];
+    out[(idx / C) * ldo + idx % C] = s * alpha;
+}
+
+}  // namespace
+
+extern "C" int t2v_wgrad_tn(const void* a, int lda, const void* b, int ldb, long long M, int R, int C, float alpha, float* out, int ldo,
+                            float* ws, long long ws_bytes, int splits, void* stream) {
+    T2V_REQUIRE(a && b && out && ws && M > 0 && R > 0 && C > 0 && ldo >= C, T2V_EINVAL, "t2v_wgrad_tn: bad argument");
+    T2V_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && (uintptr_t)a % 16 == 0 && (uintptr_t)b % 16 == 0, T2V_ESHAPE,
+                "t2v_wgrad_tn: 16-byte aligned operand rows");
+    const long long steps = (M + WT_TOK - 1) / WT_TOK;
+    const long long tiles = (long long)((R + 63) / 64) * ((C + 63) / 64);
+    if (splits <= 0) {  // fill the chip (~4 workgroups per CU) without making the partial slabs larger than the operands
+        splits = (int)((1024 + tiles - 1) / tiles);
+        if (splits > 256) splits = 256;
+    }
+    if (splits > steps) splits = (int)steps;
+    const long long slab = (long long)R * C * 4;
+    if ((long long)splits * slab > ws_bytes) splits = (int)(ws_bytes / slab);
+    T2V_REQUIRE(splits >= 1, T2V_ESHAPE, "t2v_wgrad_tn: workspace smaller than one output");
+    long long tok_per_split = ((steps + splits - 1) / splits) * WT_TOK;
+    splits = (int)((M + tok_per_split - 1) / tok_per_split);
+    T2V_REQUIRE((R + 63) / 64 <= 65535 && splits <= 65535, T2V_ESHAPE, "t2v_wgrad_tn: grid");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_tn_kernel, dim3((C + 63) / 64, (R + 63) / 64, splits), dim3(256), 0, s, (const bf16_t*)a, lda, (const bf16_t*)b, ldb,
+                       M, R, C, tok_per_split, ws);
+    T2V_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wgrad_tn_reduce_kernel, dim3((unsigned)(((long long)R * C + 255) / 256)), dim3(256), 0, s, (const float*)ws, splits, R, C,
+                       alpha, out, ldo);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}

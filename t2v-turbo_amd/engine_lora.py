@@ -24,6 +24,8 @@ row.  A train-mode student's dropouts (LoRA branch, temporal conv blocks) are co
 a function of (step seed, site, element), applied in the forward and regenerated in the backward — not torch's random stream.
 
 Status: dataflow verified on CPU against torch autograd (tests/test_unet_lora_grad_cpu.py); not yet run on hardware."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -51,6 +53,9 @@ class LoraGroup:
 
 class LoraTrainMixin:
     lora_params = None
+    # T2V_TN_WGRAD=1: the token-contracted weight gradients by t2v_wgrad_tn on the token-major operands (no transposed copies)
+    # instead of t2v_transpose_pad_bf16 + t2v_gemm; opt-in until it has run on hardware
+    tn_wgrad = os.environ.get("T2V_TN_WGRAD", "0") == "1"
 
     # ---- binding ------------------------------------------------------------------------------------------------------
     def bind_lora(self, params):
@@ -177,6 +182,18 @@ class LoraTrainMixin:
                 ind[b, b * per:(b + 1) * per] = 1
             return ind.to(self.device, self.adt).contiguous()
         return self.pk._memo(("clip_ind", m_rows, self.B), make)
+
+    def clip_indicator_tok(self, m_rows):
+        """[M, 8] bf16, column b = 1 on the rows of clip b: the token-major operand of the column sums for t2v_wgrad_tn."""
+        def make():
+            B = self.B
+            assert B <= 8, "per-clip column sums through t2v_wgrad_tn: at most 8 clips per rank"
+            ind = torch.zeros(m_rows, 8)
+            per = m_rows // B
+            for b in range(B):
+                ind[b * per:(b + 1) * per, b] = 1
+            return ind.to(self.device, self.adt).contiguous()
+        return self.pk._memo(("clip_ind_tok", m_rows, self.B), make)
 
     # ---- groups -------------------------------------------------------------------------------------------------------
     def lgroup(self, mods, mode, perm=None):
@@ -310,9 +327,23 @@ class LoraTrainMixin:
                 ops.fill_zero(dym)
             ops.dropout(dy, None, dym, grp.ntot, grp.drop[0], self.seed_t, grp.drop[1])
             dy = dym
+        g = self.buf(m, grp.n * grp.rp)
+        if self.tn_wgrad:  # token-contracted kernel on the token-major operands themselves: no transposed copies
+            c0 = 0
+            for i in range(grp.n):
+                n_out, rp = grp.N[i], grp.rp
+                ops.wgrad_tn(dy[:, c0:c0 + n_out], t[:, i * rp:(i + 1) * rp], grp.EU[i], alpha=grp.scale[i])
+                ops.gemm(dy[:, c0:c0 + grp.npad[i]], grp.UT[i], g[:, i * rp:(i + 1) * rp], M=m, N=rp, alpha=grp.scale[i])
+                c0 += grp.npad[i]
+            if colsum is not None:
+                ind = self.clip_indicator_tok(m)
+                ops.wgrad_tn(ind[:, :self.B], dy_plain[:, :grp.N[0]], colsum)
+            if grp.drop:
+                self.pool.put(dy)
+            self.pool.put(t)
+            return g
         dyT = self.tposed(dy, m, dy.shape[1])
         tT = self.tposed(t, m, t.shape[1])
-        g = self.buf(m, grp.n * grp.rp)
         c0 = 0
         for i in range(grp.n):
             n_out, rp = grp.N[i], grp.rp
@@ -339,6 +370,15 @@ class LoraTrainMixin:
         x, _ = grp.saved
         m_in = x.M
         mp = _pad(m_in, 64)
+        if self.tn_wgrad:
+            c0 = 0
+            for part in x.parts:
+                c = part.shape[1]
+                ops.wgrad_tn(G, part, grp.ED[:, c0:c0 + c])
+                c0 += c
+            self.drop(*x.parts)
+            grp.saved = None
+            return
         GT = self.tposed(G, m_in, G.shape[1])
         c0 = 0
         for part in x.parts:

@@ -112,6 +112,8 @@ _SIGS = {
                                        C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "t2v_wgrad_tn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int,
+                               C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
     "t2v_transpose_pad_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
                                          C.c_longlong, C.c_void_p]),
     "t2v_dropout_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float,
@@ -391,6 +393,13 @@ class HipOps:
                    v_head_stride, _p(kt), _row_stride(kt), _p(qt), _p(dot), _row_stride(qt), _p(dout), _row_stride(dout), _p(o),
                    _row_stride(o), _p(l2), _p(dsum), _row_stride(l2), _p(dq), _row_stride(dq), _p(dk), _row_stride(dk), _p(dv),
                    _row_stride(dv), n_img, seq, seq, heads, scale)
+
+    def wgrad_tn(self, a, b, out, alpha=1.0, splits=0):
+        """out[R, C] (fp32) = alpha * a^T b for token-major bf16 a [M, R], b [M, C] (column slices allowed)."""
+        assert out.dtype == torch.float32 and a.shape[0] == b.shape[0] and out.shape == (a.shape[1], b.shape[1])
+        ws = self.workspace(a.device)
+        self._call("t2v_wgrad_tn", _p(a), _row_stride(a), _p(b), _row_stride(b), a.shape[0], a.shape[1], b.shape[1], alpha, _p(out),
+                   _row_stride(out), ws.data_ptr(), ws.numel(), splits)
 
     def transpose_pad(self, src, rows, cols, out, batch=1, in_stride=0, out_stride=0):
         """out[b][c][r] = src[b][r][c], zero for rows <= r < roundup(rows, 64) (16-byte accesses; see include/t2v_hip.h)."""

@@ -270,6 +270,12 @@ class EmuOps:
                 dk[r, c] = (dS.t() @ Q * scale).to(dk.dtype)
                 dv[r, c] = (P.t() @ dO).to(dv.dtype)
 
+    def wgrad_tn(self, a, b, out, alpha=1.0, splits=0):
+        self._log("wgrad_tn")
+        if self.strict:
+            assert a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.storage_offset() % 8 == 0 and b.storage_offset() % 8 == 0
+        out.copy_((a.float().t() @ b.float()) * alpha)
+
     def transpose_pad(self, src, rows, cols, out, batch=1, in_stride=0, out_stride=0):
         self._log("transpose_pad")
         rp = (rows + 63) // 64 * 64

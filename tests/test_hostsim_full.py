@@ -61,7 +61,7 @@ def test_unet_forward_on_the_real_library_matches_the_oracle_fixture(full_ops):
 
 
 @pytest.mark.skipif(os.environ.get("T2V_HOSTSIM_FULL") != "1", reason="minutes of simulation: set T2V_HOSTSIM_FULL=1")
-@pytest.mark.parametrize("flash", [False, True])
+@pytest.mark.parametrize("flash", [False, True])   # True also switches the weight gradients to t2v_wgrad_tn
 def test_training_step_on_the_real_library_only(full_ops, monkeypatch, flash):
     """The native student step — forward, backward, all LoRA gradients — with NOTHING emulated: every launch is real kernel
     source on the simulator, through the GPU path's record / replay protocol."""
@@ -75,6 +75,7 @@ def test_training_step_on_the_real_library_only(full_ops, monkeypatch, flash):
     y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 16, tc, None, r_out)
     eng = UNetGradEngine(m, full_ops())
     eng.flash_attn_bwd = flash  # spatial self-attention backward: flash-style kernels (csrc/attention_bwd.hip) or the GEMM form
+    eng.tn_wgrad = flash        # weight gradients: token-contracted kernel (csrc/wgrad_tn.hip) or transposes + t2v_gemm
     eng.bind_lora(params)
     for step in range(2):  # second pass: replayed lists, LoRA operand packs refreshed by the gather kernel
         emb_all = m.conditioning_emb_all(ts, 16, tc, None)

@@ -36,6 +36,7 @@ class HostSimOps(nt.HipOps):
                 fn.restype, fn.argtypes = res, args
         self.recording = None
         self._keep = []
+        self.tune, self._ws = {}, {}
 
     @staticmethod
     def stream():
@@ -209,7 +210,8 @@ def test_dropout_mask_is_the_emulated_one(ops, rows, ncols, ld, p, resid):
         assert torch.equal(got[:, :ncols] != 0, keep)
 
 
-def test_training_engine_on_simulated_kernels_bf16():
+@pytest.mark.parametrize("tn_wgrad", [False, True])
+def test_training_engine_on_simulated_kernels_bf16(tn_wgrad):
     """The whole native student step (LoRA branch, data gradient, all LoRA weight gradients, train-mode dropout) recorded against
     the hybrid backend: bf16 activations, every SIMT-only kernel as real source on the simulator, GEMMs / forward attention emulated
     with bf16 rounding.  Reference: fp32 autograd with the engine's masks replayed (as in test_unet_lora_grad_cpu).  Tolerances
@@ -228,12 +230,13 @@ def test_training_engine_on_simulated_kernels_bf16():
     y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 16, tc, None, r_out)
     ops_h = HybridOps()
     eng = UNetGradEngine(m, ops_h)
+    eng.tn_wgrad = tn_wgrad  # weight gradients by t2v_wgrad_tn on the token-major operands instead of transposes + t2v_gemm
     eng.bind_lora(params)
     emb_all = m.conditioning_emb_all(ts, 16, tc, None)
     y = eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all)
     flat = torch.zeros(eng.lora_numel)
     dx = eng.backward(r_out, flat_grad=flat, accumulate=False)
-    assert ops_h.sim_calls > 2000
+    assert ops_h.sim_calls > 1500
     assert rel_l2(y, y_ref) < 3e-2
     assert rel_l2(dx, dx_ref) < 6e-2
     mine = {id(p) for mod in eng.engine_leaves() for p in (mod.lora_up.weight, mod.lora_down.weight)}
@@ -262,3 +265,17 @@ def test_transpose_pad(ops, rows, cols, batch, ld_in):
     emu.transpose_pad(src[:, :cols], rows, cols, o_e, batch=batch, in_stride=rows * ld_in, out_stride=cols * ld_out)
     assert torch.equal(o_s.float(), o_e)
     assert float(o_e[:, rp:].min()) == 5.0 and float(o_e[:, rows:rp].abs().max() if rp > rows else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("M,R,C,lda,ldb,splits", [(200, 64, 64, 64, 64, 0), (1000, 320, 64, 384, 192, 0), (130, 4, 64, 64, 64, 3),
+                                                  (77, 576, 200, 576, 200, 0), (640, 1, 320, 8, 320, 4), (64, 100, 36, 104, 40, 1)])
+def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
+    """Token-contracted weight gradient out = alpha a^T b on token-major operands (column slices, ragged R / C / M, forced and
+    automatic token splits): fp32 result against the emulated definition."""
+    sim, emu = ops
+    sim._ws = {}
+    a, b = _rt(M, lda, seed=1, scale=0.3), _rt(M, ldb, seed=2, scale=0.3)
+    o_e, o_s = torch.zeros(R, C), torch.full((R, C + 3), 7.0)
+    emu.wgrad_tn(a[:, :R], b[:, :C], o_e, alpha=0.5)
+    sim.wgrad_tn(_bf(a)[:, :R], _bf(b)[:, :C], o_s[:, :C], alpha=0.5, splits=splits)
+    assert rel_l2(o_s[:, :C], o_e) < 1e-5 and float(o_s[:, C:].min()) == 7.0

@@ -342,3 +342,22 @@ def test_flash_attention_backward_variant_of_the_engine():
     eng2.flash_attn_bwd = True
     y2 = eng2.forward_tape(x, ts, ctx, 16, tc, None)
     assert rel_l2(y2, y_ref) < 2e-5 and rel_l2(eng2.backward(r_out), dx_ref) < 1e-4
+
+
+def test_tn_weight_gradient_variant_of_the_engine():
+    """``tn_wgrad``: every LoRA weight gradient (and the per-clip column sums) by the token-contracted op on the token-major
+    operands — no transposed copies — with and without the train-mode dropout; same gradients."""
+    g = load("unet_tiny_mg_b2")
+    m, params = _student("unet_tiny_mg_b2", 16, motion_cond_proj_dim=256)
+    x, ts, ctx, tc, mc = g["x"], g["ts"], g["ctx"], g["tc"], g["mc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(11))
+    y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 8, tc, mc, r_out)
+    eng = UNetGradEngine(m, EmuOps(strict=True))
+    eng.tn_wgrad = True
+    eng.flash_attn_bwd = True
+    eng.bind_lora(params)
+    y, dx, grads = _engine_step(eng, m, params, x, ts, ctx, 8, tc, mc, r_out)
+    calls = eng.ops.calls
+    assert calls.count("wgrad_tn") > 1000 and calls.count("transpose_pad") < 200   # (what is left: the attention backward's operands)
+    assert rel_l2(y, y_ref) < 2e-5 and rel_l2(dx, dx_ref) < 1e-4
+    _compare(params, grads, g_ref, m, max_zero=8)
