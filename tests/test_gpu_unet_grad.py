@@ -292,3 +292,17 @@ def test_attn_spatial_bwd_flash(ops, n_img, seq, heads):
     for name, a, b in zip(("dq", "dk", "dv"), g_h, g_e):
         assert torch.isfinite(a.float()).all(), name
         assert rel_l2(a.float().cpu(), b) < 1.2e-2, (name, rel_l2(a.float().cpu(), b))
+
+
+@pytest.mark.parametrize("M,R,C,lda,ldb,splits", [(200, 64, 64, 64, 64, 0), (40960, 320, 64, 384, 192, 0), (130, 4, 64, 64, 64, 3),
+                                                  (10240, 576, 640, 576, 640, 0), (40960, 1, 320, 8, 320, 0)])
+def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
+    """Token-contracted weight gradient (csrc/wgrad_tn.hip) against the emulated definition."""
+    hip, emu = ops
+    a, b = _rt(M, lda, seed=1, scale=0.3), _rt(M, ldb, seed=2, scale=0.3)
+    o_e = torch.zeros(R, C)
+    emu.wgrad_tn(a[:, :R], b[:, :C], o_e, alpha=0.5)
+    o_h = torch.full((R, C + 3), 7.0, device="cuda")
+    hip.wgrad_tn(_dev(a)[:, :R], _dev(b)[:, :C], o_h[:, :C], alpha=0.5, splits=splits)
+    torch.cuda.synchronize()
+    assert rel_l2(o_h[:, :C].cpu(), o_e) < 2e-4 and float(o_h[:, C:].min()) == 7.0

@@ -27,3 +27,5 @@ T2V_UNVALIDATED_KERNELS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-
 #   T2V_UNVALIDATED_KERNELS=1 python tools/tune_gemm.py --train 1      (split-K candidates up to 64 for the token-contracted shapes)
 # 5. the same step with the flash-style spatial-attention backward (csrc/attention_bwd.hip) instead of the GEMM-formulated one
 T2V_UNVALIDATED_KERNELS=1 T2V_FLASH_ATTN_BWD=1 timeout 500 python tools/distill_bench.py --steps 3 --native-student 1 2>&1 | tail -1 | tee gpurun_out/distill_native_flash.txt
+# 6. ... and with the token-contracted weight-gradient kernel as well (csrc/wgrad_tn.hip: no operand transposes)
+T2V_UNVALIDATED_KERNELS=1 T2V_FLASH_ATTN_BWD=1 T2V_TN_WGRAD=1 timeout 500 python tools/distill_bench.py --steps 3 --native-student 1 2>&1 | tail -1 | tee gpurun_out/distill_native_flash_tn.txt
