@@ -15,6 +15,15 @@ namespace {
 
 constexpr int WT_TOK = 64, WT_PITCH = 66;
 
+// the first `n` (< 8, possibly <= 0) elements of an 8-element chunk, zeros behind them (the last column chunk of a ragged operand)
+__device__ __forceinline__ uint4 ragged_chunk(const bf16_t* p, int n) {
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+        if (e < n) w[e >> 1] |= (uint32_t)p[e] << (16 * (e & 1));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb, long long M,
                                                        int R, int C, long long tok_per_split, float* __restrict__ ws) {
     __shared__ bf16_t sa[WT_TOK][WT_PITCH];
@@ -38,13 +47,9 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict_
             uint4 ua = make_uint4(0, 0, 0, 0), ub = make_uint4(0, 0, 0, 0);
             if (m < m_end) {
                 if (r0 + ch + 8 <= R) ua = *(const uint4*)(a + m * lda + r0 + ch);
-                else
-                    for (int e = 0; e < 8; ++e)
-                        if (r0 + ch + e < R) ((bf16_t*)&ua)[e] = a[m * lda + r0 + ch + e];
+                else ua = ragged_chunk(a + m * lda + r0 + ch, R - (r0 + ch));
                 if (c0 + ch + 8 <= C) ub = *(const uint4*)(b + m * ldb + c0 + ch);
-                else
-                    for (int e = 0; e < 8; ++e)
-                        if (c0 + ch + e < C) ((bf16_t*)&ub)[e] = b[m * ldb + c0 + ch + e];
+                else ub = ragged_chunk(b + m * ldb + c0 + ch, C - (c0 + ch));
             }
             uint32_t* pa = (uint32_t*)&sa[row][ch];
             uint32_t* pb = (uint32_t*)&sb[row][ch];

@@ -59,7 +59,7 @@ def build_gemm(force=False):
     for src in GEMM_SOURCES:
         cpp = os.path.join(OUT, src.replace(".hip", ".cpp"))
         obj = cpp.replace(".cpp", ".o")
-        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-w", "-I", HERE, "-I", OUT, "-I", os.path.join(ROOT, "include"), "-c", cpp, "-o", obj]
+        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-w", "-fno-strict-aliasing", "-I", HERE, "-I", OUT, "-I", os.path.join(ROOT, "include"), "-c", cpp, "-o", obj]
         procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
     for cmd, pr in procs:
@@ -88,7 +88,7 @@ def build_full(force=False):
     for src in FULL_SOURCES:
         cpp = os.path.join(full, src.replace(".hip", ".cpp"))
         obj = cpp.replace(".cpp", ".o")
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-w", "-DHOSTSIM_FULL", "-I", HERE, "-I", full, "-I", os.path.join(ROOT, "include"),
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-w", "-fno-strict-aliasing", "-DHOSTSIM_FULL", "-I", HERE, "-I", full, "-I", os.path.join(ROOT, "include"),
                "-c", cpp, "-o", obj]
         procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
@@ -110,7 +110,7 @@ def build(force=False):
         cpp = os.path.join(OUT, src.replace(".hip", ".cpp"))
         obj = cpp.replace(".cpp", ".o")
         # include order: the simulator's common.h / hip_runtime.h shadow the device ones; gn_bwd_common.h is the (patched) copy
-        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-w", "-I", HERE, "-I", OUT, "-I", os.path.join(ROOT, "include"), "-c", cpp, "-o", obj]
+        cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-w", "-fno-strict-aliasing", "-I", HERE, "-I", OUT, "-I", os.path.join(ROOT, "include"), "-c", cpp, "-o", obj]
         subprocess.check_call(cmd)
         objs.append(obj)
     subprocess.check_call(["g++", "-shared", "-o", LIB] + objs)
