@@ -52,7 +52,7 @@ def test_ddim_inversion_inverts_the_ddim_step():
     """x_t = reverse_step(x_prev, eps, t) must be undone by the forward DDIM step with the same eps."""
     sched = T2VTurboScheduler(linear_start=0.00085, linear_end=0.012)
     solver = cd_math.DDIMSolver(sched.alphas_cumprod.numpy(), ddim_timesteps=50)
-    x0 = torch.randn(1, 4, 4, 8, 8, dtype=torch.float64)
+    x0 = torch.randn(1, 4, 4, 8, 8, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
 
     class Eps(torch.nn.Module):  # a fixed "noise prediction" so both directions use the same eps
         def forward(self, x, ts, **kw):
@@ -66,7 +66,10 @@ def test_ddim_inversion_inverts_the_ddim_step():
     prev = (ts0 - solver.step_ratio).clip(min=0)
     a_prev = solver.alpha_cumprods[prev].double()
     x_back = a_prev.sqrt() * (lat[0] - (1 - a_t).sqrt() * eps) / a_t.sqrt() + (1 - a_prev).sqrt() * eps
-    assert torch.allclose(x_back, x0, atol=1e-9)
+    # the solver's coefficient tables are fp32 (as the reference's): sqrt(a_next / a) rounded in fp32 against sqrt(a_next) / sqrt(a)
+    # in fp64 differ by ~6e-8 relative — the identity holds to that, not to fp64 round-off (an atol of 1e-9 passed or failed with
+    # the draw of x0)
+    assert torch.allclose(x_back, x0, atol=2e-6)
 
 
 def test_motion_rank_loss_and_score():
