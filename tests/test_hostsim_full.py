@@ -155,8 +155,8 @@ def test_vae_decode_gradient_engine_on_the_real_library(full_ops):
     ae.load_state_dict(synth_state_dict(manifest("vae_tiny")), strict=True)
     ae.requires_grad_(False)
     g = torch.Generator().manual_seed(3)
-    z = torch.randn(1, 4, 8, 8, generator=g)
-    dout = torch.randn(1, 3, 64, 64, generator=g)
+    z = torch.randn(1, 4, 4, 4, generator=g)
+    dout = torch.randn(1, 3, 32, 32, generator=g)
     zz = z.clone().requires_grad_(True)
     ae.native_mode = "off"
     ref = ae.decode(zz)
