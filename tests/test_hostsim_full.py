@@ -96,7 +96,8 @@ def test_training_step_on_the_real_library_only(full_ops, monkeypatch, flash):
 
 
 @pytest.mark.skipif(os.environ.get("T2V_HOSTSIM_FULL") != "1", reason="minutes of simulation: set T2V_HOSTSIM_FULL=1")
-def test_train_mode_step_on_the_real_library_only(full_ops, monkeypatch):
+@pytest.mark.parametrize("new_kernels", [False, True])   # True: flash-style attention backward + token-contracted weight gradients
+def test_train_mode_step_on_the_real_library_only(full_ops, monkeypatch, new_kernels):
     """Train-mode student (dropout kernel, per-frame text K / V) on the real library: the same seed reproduces the step bit for
     bit (the backward regenerates the forward's masks from it), another seed does not, every gradient is finite."""
     from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
@@ -108,6 +109,7 @@ def test_train_mode_step_on_the_real_library_only(full_ops, monkeypatch):
     x, ts, ctx, tc = g["x"][:, :, :2, :8, :8].contiguous(), g["ts"], g["ctx"], g["tc"]
     r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
     eng = UNetGradEngine(m, full_ops())
+    eng.flash_attn_bwd = eng.tn_wgrad = new_kernels
     eng.bind_lora(params)
     with torch.no_grad():
         emb_all = m.conditioning_emb_all(ts, 16, tc, None)
