@@ -28,7 +28,13 @@ def main():
     ap.add_argument("--native-student", type=int, default=0,
                     help="1: student forward / target forward / backward on the native gradient engine (train mode, native dropout; "
                          "needs T2V_UNVALIDATED_KERNELS=1 until its kernels have run on hardware)")
+    ap.add_argument("--native-variants", default="",
+                    help="comma list of engine variants timed one after the other on ONE model build, e.g. "
+                         "'plain,graph,flash,flash+tn,flash+tn+graph' (flash = T2V_FLASH_ATTN_BWD, tn = T2V_TN_WGRAD, graph = hipGraph "
+                         "capture of the launch lists); implies --native-student 1")
     a = ap.parse_args()
+    if a.native_variants:
+        a.native_student = 1
     import bench
     from t2v_turbo_amd import cd_math, dist as tdist, lora
     from t2v_turbo_amd.distill import distill_step
@@ -91,26 +97,37 @@ def main():
         return distill_step(student, teacher, solver, sched, lat, pe, ue, optimizer=opt, grad_sync=sync,
                             autocast_dtype=torch.bfloat16, student_engine=eng)
 
-    for _ in range(a.warmup):
-        loss, _ = step()
-        print(f"[rank {rank}] warmup loss {float(loss):.4f} ({time.time() - t0:.1f}s)", file=sys.stderr, flush=True)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(a.steps):
-        loss, info = step()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t1) / a.steps
-    if rank == 0:
-        print(json.dumps({"metric": "v1 distillation steps/sec (student " + ("native gradient engine" if eng is not None else "fwd+bwd torch path")
-                          + ", teacher x2 native HIP)", "student_native": eng is not None,
-                          "value": round(world / dt, 4), "unit": "samples/s", "n_gpus": world, "ms_per_step": round(dt * 1e3, 1),
-                          "lora_grad_mb": round(sync.numel * 4 / 2 ** 20, 1), "loss": float(loss),
-                          "teacher_native": teacher._engine_box.engine is not None, "peak_mem_gb":
-                          round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}), flush=True)
+    variants = [v for v in a.native_variants.split(",") if v] or [None]
+    for variant in variants:
+        if variant is not None:  # a fresh engine per variant (its own packs and launch lists) on the same student
+            import gc
+            eng = None
+            gc.collect()
+            torch.cuda.empty_cache()
+            eng = UNetGradEngine(student, HipOps())
+            flags = set(variant.split("+"))
+            eng.flash_attn_bwd, eng.tn_wgrad, eng.use_graph = "flash" in flags, "tn" in flags, "graph" in flags
+            eng.bind_lora(params)
+        for _ in range(a.warmup + (2 if variant and "graph" in variant else 0)):  # graphs are captured on the second replay
+            loss, _ = step()
+            print(f"[rank {rank}] warmup loss {float(loss):.4f} ({time.time() - t0:.1f}s)", file=sys.stderr, flush=True)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            loss, info = step()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / a.steps
+        if rank == 0:
+            print(json.dumps({"metric": "v1 distillation steps/sec (student " + ("native gradient engine" if eng is not None else "fwd+bwd torch path")
+                              + ", teacher x2 native HIP)", "student_native": eng is not None, "variant": variant,
+                              "value": round(world / dt, 4), "unit": "samples/s", "n_gpus": world, "ms_per_step": round(dt * 1e3, 1),
+                              "lora_grad_mb": round(sync.numel * 4 / 2 ** 20, 1), "loss": float(loss),
+                              "teacher_native": teacher._engine_box.engine is not None, "peak_mem_gb":
+                              round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
