@@ -39,7 +39,8 @@ def _tposed(t, n_img, seq, cols):
     return out
 
 
-@pytest.mark.parametrize("n_img,seq,heads,v_layout", [(1, 64, 1, "tok"), (2, 100, 2, "tok"), (1, 200, 1, "head"), (1, 130, 3, "tok")])
+@pytest.mark.parametrize("n_img,seq,heads,v_layout", [(1, 64, 1, "tok"), (2, 100, 2, "tok"), (1, 200, 1, "head"), (1, 130, 3, "tok"),
+                                                      (2, 40, 4, "head"), (1, 160, 5, "tok"), (1, 7, 1, "tok")])  # 40 / 160: the 5x8 and 10x16 levels
 def test_attn_spatial_bwd(sim, n_img, seq, heads, v_layout):
     emu = EmuOps()
     inner, M = heads * 64, n_img * seq
