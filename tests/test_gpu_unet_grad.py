@@ -182,7 +182,8 @@ def test_weight_gradient_gemm_shapes(ops, M, N, K, split):
     assert rel_l2(o_h.cpu(), o_e) < 2e-3
 
 
-def test_lora_training_engine_on_gpu_vs_autograd(monkeypatch):
+@pytest.mark.parametrize("new_kernels", [False, True])   # True: flash-style attention backward + token-contracted weight gradients
+def test_lora_training_engine_on_gpu_vs_autograd(monkeypatch, new_kernels):
     """Student forward + backward with every LoRA weight gradient on the device against fp32 autograd on the CPU module."""
     from t2v_turbo_amd import lora
     from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
@@ -199,6 +200,7 @@ def test_lora_training_engine_on_gpu_vs_autograd(monkeypatch):
     m = m.cuda()
     params = lora.lora_parameters(m)
     eng = UNetGradEngine(m, HipOps())
+    eng.flash_attn_bwd = eng.tn_wgrad = new_kernels
     eng.bind_lora(params)
     for step in range(2):  # second pass: replayed launch lists, operand packs refreshed by the gather kernel
         emb_all = m.conditioning_emb_all(ts.cuda(), 16, tc.cuda())
