@@ -1,9 +1,11 @@
 """Data gradient of the UNet forward: d(loss)/d(latents) for a loss on the denoiser output and / or on the recorded
 temporal attention probabilities — what ``get_motion_prior_score`` asks of autograd (``motion_prior_sample.py:59-84``:
 ``latents.requires_grad_(True)`` -> UNet -> ``attn1.attention_probs`` of the output-block temporal transformers ->
-``autograd.grad(loss, latents)``), and the dX half of a native student backward.  All weights are
-frozen on this path: only data gradients are computed, never weight gradients, and the conditioning branch (time / fps /
-guidance embeddings, text K / V) carries none because it does not depend on the latents.
+``autograd.grad(loss, latents)``), and the native student backward of the distillation step.  With frozen
+weights only data gradients are computed, and the conditioning branch (time / fps / guidance embeddings, text K / V) carries
+none because it does not depend on the latents.  With the LoRA tensors bound (``bind_lora``, engine_lora.py) the same tape also
+runs the un-merged LoRA branch of every injected leaf, takes its weight gradients at the leaf's backward, applies the
+train-mode dropouts, and hands d(loss)/d(emb_all) back for the conditioning branch that stays in torch.
 
 Same construction as the VAE decoder's gradient engine: the forward is recorded together with a *tape* of closures, each
 recording its block's backward launches; forward and backward are two replayable launch lists over one buffer pool.
@@ -18,11 +20,12 @@ for the 16-frame temporal ones), everything element-wise.
   LayerNorm                    ``layernorm_bwd`` (statistics recomputed per row; residual fused)
   GEGLU                        ``geglu_bwd`` on the saved pre-activation (packed [32 value | 32 gate] column groups)
   temporal attention           ``attn_temporal_bwd`` (one wave-sized problem per pixel and head; takes d(probs) as well)
-  spatial self / text cross    batched GEMMs around ``softmax_rows`` / ``softmax_bwd_rows`` with bf16 transposes
+  spatial self / text cross    batched GEMMs around ``softmax_rows`` / ``softmax_bwd_rows`` with bf16 transposes; spatial self with
+                               ``flash_attn_bwd``: ``attn_spatial_bwd`` (csrc/attention_bwd.hip, probabilities never in memory)
 
 Status: the dataflow is verified on CPU against torch autograd (tests/test_unet_grad_cpu.py, emulated op backend), and the
-device kernels of the new ops (csrc/backward_unet.hip, csrc/train.hip) run as real source on a host SIMT simulator
-(tests/test_hostsim_kernels.py) but have not run on hardware yet; ``native`` use raises until ``T2V_UNVALIDATED_KERNELS=1`` is set."""
+device kernels of the new ops (csrc/backward_unet.hip, train.hip, attention_bwd.hip, wgrad_tn.hip) run as real source on a host SIMT
+simulator (tests/test_hostsim_*.py) but have not run on hardware yet; ``native`` use raises until ``T2V_UNVALIDATED_KERNELS=1`` is set."""
 import os
 
 import torch
