@@ -24,11 +24,23 @@ from . import cd_math
 
 
 def _teacher_solver_step(teacher_unet, solver, noisy, start_timesteps, prompt_embeds, uncond_prompt_embeds, fps, w, index,
-                         alpha_schedule, sigma_schedule):
-    """Teacher cond / uncond forwards -> CFG estimate -> one DDIM solver step (train_t2v_turbo_v1_lora.py:1100-1160)."""
+                         alpha_schedule, sigma_schedule, batch_teacher=False):
+    """Teacher cond / uncond forwards -> CFG estimate -> one DDIM solver step (train_t2v_turbo_v1_lora.py:1100-1160).
+    ``batch_teacher``: both forwards as ONE call on the 2B-clip batch [cond | uncond] (every per-sample quantity of the UNet —
+    GroupNorm units, attention, embeddings — is per clip, so the numbers are the same; the weights are read once and the small
+    5x8 / 10x16 levels get twice the tiles).  The unconditional call of the reference passes no fps (default 16): the batched
+    call carries a per-clip fps tensor."""
     tdt = next(teacher_unet.parameters()).dtype
-    cond_out = teacher_unet(noisy.to(tdt), start_timesteps, context=prompt_embeds.to(tdt), fps=fps).float()
-    uncond_out = teacher_unet(noisy.to(tdt), start_timesteps, context=uncond_prompt_embeds.to(tdt)).float()
+    if batch_teacher and prompt_embeds.shape == uncond_prompt_embeds.shape:
+        b = noisy.shape[0]
+        fps_c = fps if torch.is_tensor(fps) else torch.full((b,), int(fps), dtype=torch.long, device=noisy.device)
+        fps2 = torch.cat([fps_c.to(noisy.device).long(), torch.full((b,), 16, dtype=torch.long, device=noisy.device)])
+        out2 = teacher_unet(torch.cat([noisy, noisy]).to(tdt), torch.cat([start_timesteps, start_timesteps]),
+                            context=torch.cat([prompt_embeds, uncond_prompt_embeds]).to(tdt), fps=fps2).float()
+        cond_out, uncond_out = out2[:b], out2[b:]
+    else:
+        cond_out = teacher_unet(noisy.to(tdt), start_timesteps, context=prompt_embeds.to(tdt), fps=fps).float()
+        uncond_out = teacher_unet(noisy.to(tdt), start_timesteps, context=uncond_prompt_embeds.to(tdt)).float()
     args = (start_timesteps, noisy, "epsilon", alpha_schedule, sigma_schedule)
     cond_x0, cond_eps = cd_math.get_predicted_original_sample(cond_out, *args), cd_math.get_predicted_noise(cond_out, *args)
     unc_x0, unc_eps = cd_math.get_predicted_original_sample(uncond_out, *args), cd_math.get_predicted_noise(uncond_out, *args)
@@ -41,7 +53,8 @@ def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_em
                  optimizer=None, grad_sync=None, fps=16, topk=20, w_min=5.0, w_max=15.0, time_cond_proj_dim=256,
                  timestep_scaling_factor=10.0, loss_type="huber", huber_c=0.001, max_grad_norm=1.0,
                  num_ddim_timesteps=50, generator=None, autocast_dtype=None, rng=None, vae=None, reward_fn=None, text=None,
-                 reward_scale=0.0, reward_frame_bsz=5, reward_train_bsz=1, vae_scale_factor=0.18215, student_engine=None):
+                 reward_scale=0.0, reward_frame_bsz=5, reward_train_bsz=1, vae_scale_factor=0.18215, student_engine=None,
+                 batch_teacher=False):
     """Returns (loss, info).  ``rng`` may pin the random draws for tests: dict(index, noise, w)."""
     eng = student_engine
     if eng is not None:
@@ -89,7 +102,7 @@ def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_em
         # tape the backward consumes goes last.  Same numbers as the reference order: nothing random happens in between.
         with torch.no_grad():
             x_prev = _teacher_solver_step(teacher_unet, solver, noisy, start_timesteps, prompt_embeds, uncond_prompt_embeds, fps,
-                                          w, index, alpha_schedule, sigma_schedule)
+                                          w, index, alpha_schedule, sigma_schedule, batch_teacher)
             target_pred, _ = student_native(x_prev, timesteps, False)
         noise_pred, emb_all = student_native(noisy, start_timesteps, True)
         noise_pred.requires_grad_(True)  # leaf: loss.backward() leaves d(loss)/d(noise_pred) on it for the engine
@@ -119,7 +132,7 @@ def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_em
     with torch.no_grad():
         if target_pred is None:
             x_prev = _teacher_solver_step(teacher_unet, solver, noisy, start_timesteps, prompt_embeds, uncond_prompt_embeds, fps,
-                                          w, index, alpha_schedule, sigma_schedule)
+                                          w, index, alpha_schedule, sigma_schedule, batch_teacher)
             # 9. target: the student's own weights at (x_prev, t_n)
             with autocast():
                 target_pred = unet(x_prev.float(), timesteps, **context, timestep_cond=w_embedding)

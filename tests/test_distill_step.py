@@ -211,3 +211,26 @@ def test_native_student_in_train_mode_runs_the_step():
         losses.append(float(loss))
     assert len(eng.drop_sites) > 100
     assert losses[0] != losses[1]  # same inputs, new masks
+
+
+def test_batched_teacher_forwards_give_the_same_step():
+    """batch_teacher=True: cond and uncond teacher forwards as one 2B-clip call (per-clip fps tensor: the reference's uncond call
+    uses the default fps 16) — same loss as two calls."""
+    sd = synth_state_dict(manifest("unet_tiny"))
+    teacher = UNetModel(**tiny_unet_params(time_cond_proj_dim=None)).eval()
+    teacher.load_state_dict({k: v for k, v in sd.items() if not k.startswith("time_cond_proj")}, strict=True)
+    teacher.requires_grad_(False)
+    student = UNetModel(**tiny_unet_params())
+    student.load_state_dict(sd, strict=True)
+    student.requires_grad_(False)
+    lora.inject_trainable_lora_extended(student, r=4)
+    student.eval()
+    sched = T2VTurboScheduler()
+    solver = cd_math.DDIMSolver(sched.alphas_cumprod.numpy(), ddim_timesteps=50)
+    g = torch.Generator().manual_seed(0)
+    lat = torch.randn(2, 4, 2, 8, 8, generator=g)
+    pe, ue = torch.randn(2, 77, 128, generator=g), torch.randn(2, 77, 128, generator=g)
+    rng = dict(index=torch.tensor([3, 40]), noise=torch.randn(lat.shape, generator=g), w=torch.tensor([6.0, 11.5]))
+    l0, _ = distill_step(student, teacher, solver, sched, lat, pe, ue, rng=rng, fps=24)
+    l1, _ = distill_step(student, teacher, solver, sched, lat, pe, ue, rng=rng, fps=24, batch_teacher=True)
+    assert abs(float(l0) - float(l1)) < 1e-6 * max(1.0, abs(float(l0)))

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--native-student", type=int, default=0,
                     help="1: student forward / target forward / backward on the native gradient engine (train mode, native dropout; "
                          "needs T2V_UNVALIDATED_KERNELS=1 until its kernels have run on hardware)")
+    ap.add_argument("--batch-teacher", type=int, default=0, help="1: teacher cond + uncond forwards as one 2-clip call")
     ap.add_argument("--native-variants", default="",
                     help="comma list of engine variants timed one after the other on ONE model build, e.g. "
                          "'plain,graph,flash,flash+tn,flash+tn+graph' (flash = T2V_FLASH_ATTN_BWD, tn = T2V_TN_WGRAD, graph = hipGraph "
@@ -95,7 +96,7 @@ def main():
 
     def step():
         return distill_step(student, teacher, solver, sched, lat, pe, ue, optimizer=opt, grad_sync=sync,
-                            autocast_dtype=torch.bfloat16, student_engine=eng)
+                            autocast_dtype=torch.bfloat16, student_engine=eng, batch_teacher=bool(a.batch_teacher))
 
     variants = [v for v in a.native_variants.split(",") if v] or [None]
     for variant in variants:

@@ -11,6 +11,8 @@ mkdir -p gpurun_out
 timeout 300 python tools/distill_bench.py --steps 3 2>&1 | tail -1 | tee gpurun_out/distill_torch_student.txt
 T2V_UNVALIDATED_KERNELS=1 timeout 600 python tools/distill_bench.py --steps 3 --native-variants plain,graph,flash,flash+tn,flash+tn+graph 2>&1 \
     | grep '^{' | tee gpurun_out/distill_native_variants.txt
+T2V_UNVALIDATED_KERNELS=1 timeout 400 python tools/distill_bench.py --steps 3 --batch-teacher 1 --native-variants flash+tn+graph 2>&1 \
+    | grep '^{' | tee gpurun_out/distill_native_batched_teacher.txt
 export TMPDIR=/tmp
 T2V_UNVALIDATED_KERNELS=1 T2V_FLASH_ATTN_BWD=1 T2V_TN_WGRAD=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_distill_native -- \
     python tools/distill_bench.py --steps 2 --warmup 1 --native-student 1 > gpurun_out/prof_distill_native.log 2>&1
