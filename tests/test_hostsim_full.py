@@ -168,3 +168,39 @@ def test_vae_decode_gradient_engine_on_the_real_library(full_ops):
     dz = eng.backward(dout.unsqueeze(2)).squeeze(2)
     assert rel_l2(out, ref.detach()) < 3e-2
     assert rel_l2(dz, zz.grad) < 5e-2
+
+
+def test_optimizer_and_scheduler_kernels_on_the_real_library(full_ops):
+    """The remaining entry points of the C-ABI on the simulator: fused AdamW step (against torch.optim.AdamW), deterministic sum of
+    squares, EMA, the fused LCM scheduler step and the 3-term linear combination (against the emulated definitions)."""
+    from tests.emu_ops import EmuOps
+    ops, emu = full_ops(), EmuOps()
+    gen = torch.Generator().manual_seed(0)
+    n = 5000
+    p0, g = torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
+    p, m, v = p0.clone(), torch.zeros(n), torch.zeros(n)
+    for step in range(1, 4):
+        ref.grad = (g * step * 0.5).clone()
+        opt.step()
+        ops.adamw_step(p, g * step, m, v, 1e-2, 0.9, 0.99, 1e-8, 0.05, step, 0.5)   # grad_scale folds the clip coefficient in
+    assert torch.allclose(p, ref.detach(), rtol=2e-5, atol=2e-6)
+    ws, out = torch.zeros(1024), torch.zeros(1)
+    ops.sumsq(g, ws, out)
+    assert abs(float(out) - float((g.double() ** 2).sum())) < 1e-3 * float((g ** 2).sum())
+    tgt, src = torch.randn(n, generator=gen), torch.randn(n, generator=gen)
+    want = tgt * 0.99 + src * 0.01
+    ops.ema_update(tgt, src, 0.99)
+    assert torch.allclose(tgt, want, rtol=1e-6, atol=1e-7)
+    x, eps_, noise = (torch.randn(1, 4, 2, 8, 8, generator=gen) for _ in range(3))
+    prev_s, den_s, prev_e, den_e = (torch.zeros_like(x) for _ in range(4))
+    args = (0.8, 0.6, 0.3, 0.7, 0.9, 0.43)
+    ops.lcm_step(x, eps_, noise, *args, prev_s, den_s)
+    emu.lcm_step(x, eps_, noise, *args, prev_e, den_e)
+    assert torch.allclose(prev_s, prev_e, rtol=1e-5, atol=1e-6) and torch.allclose(den_s, den_e, rtol=1e-5, atol=1e-6)
+    y, z = torch.randn_like(x), torch.randn_like(x)
+    o_s, o_e = torch.zeros_like(x), torch.zeros_like(x)
+    ops.lincomb3(x, y, z, [0.5], [-1.5], [2.0], o_s)
+    emu.lincomb3(x, y, z, [0.5], [-1.5], [2.0], o_e)
+    assert torch.allclose(o_s, o_e, rtol=1e-6, atol=1e-6)
