@@ -168,15 +168,25 @@ inline void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void
                 }
                 int done = 0;
                 long long rounds = 0;
+                // HOSTSIM_ORDER = reverse | random: visit the runnable fibers in another order every round.  Results must not
+                // depend on it — a missing barrier (one wave restaging an LDS tile another wave still reads) shows up as a
+                // result that changes with the schedule, which the fixed round-robin order could hide.
+                const char* ord = getenv("HOSTSIM_ORDER");
+                const int mode = !ord ? 0 : (ord[0] == 'r' && ord[1] == 'e') ? 1 : 2;
+                uint64_t lcg = 0x9E3779B97F4A7C15ull;
                 while (done < n) {
                     done = 0;
-                    for (int i = 0; i < n; ++i) {
-                        if (s.fibers[i].done) { ++done; continue; }
+                    lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+                    const int start = mode == 2 ? (int)((lcg >> 33) % n) : 0;
+                    const int stride = mode == 2 ? ((int)((lcg >> 13) % n) | 1) : 1;   // odd stride: a permutation when n is a power of two
+                    for (int k = 0; k < n; ++k) {
+                        int i = mode == 1 ? n - 1 - k : mode == 2 ? (int)(((long long)start + (long long)k * stride) % n) : k;
+                        if (s.fibers[i].done) continue;
                         if (s.fibers[i].wait && s.fibers[i].wait->gen == s.fibers[i].wait_gen) continue;  // still blocked
                         s.cur = i;
                         hostsim_switch(&s.sched_sp, s.fibers[i].sp);
-                        done += s.fibers[i].done;
                     }
+                    for (int i = 0; i < n; ++i) done += s.fibers[i].done;  // (a random round may visit a fiber twice or not at all)
                     if (++rounds > 2000000) { fprintf(stderr, "hostsim: workgroup does not terminate (barrier mismatch?)\n"); abort(); }
                 }
             }

@@ -73,3 +73,41 @@ def test_attn_spatial_bwd(sim, n_img, seq, heads, v_layout):
     for name, a, b in zip(("dq", "dk", "dv"), g_s, g_e):
         assert torch.isfinite(a.float()).all(), name
         assert rel_l2(a.float(), b) < 1.2e-2, (name, rel_l2(a.float(), b))
+
+
+def test_results_do_not_depend_on_the_fiber_schedule(sim, monkeypatch):
+    """The simulator visits runnable fibers round-robin by default; HOSTSIM_ORDER = reverse / random changes the interleaving of
+    waves.  A kernel whose waves are correctly synchronised gives bit-identical results under every schedule — a missing barrier
+    (one wave restaging an LDS tile another still reads) would not.  Checked for the two MFMA kernels written against the
+    simulator, the GEMM and the LDS-transposing kernels."""
+    from t2v_turbo_amd import native as nt
+    n_img, seq, heads = 1, 130, 2
+    inner, M = heads * 64, n_img * seq
+    q, k, v, do = (_rt(M, inner, seed=s_, scale=0.8) for s_ in (1, 2, 3, 4))
+    o = torch.zeros(M, inner)
+    for hd in range(heads):
+        c = slice(hd * 64, (hd + 1) * 64)
+        o[:, c] = (q[:, c] @ k[:, c].t() * 0.125).softmax(dim=1) @ v[:, c]
+    bf = lambda t: t.bfloat16().contiguous()  # noqa: E731
+    a, b = _rt(300, 192, seed=5, scale=0.3), _rt(300, 64, seed=6, scale=0.3)
+    ga, gw = _rt(200, 128, seed=7), _rt(96, 9 * 128, seed=8, scale=0.05)
+
+    def run():
+        g = [torch.zeros(M, inner, dtype=torch.bfloat16) for _ in range(3)]
+        sp = 192
+        sim.attn_spatial_bwd(bf(q), bf(k), bf(v), seq * inner, 64, bf(_tposed(k, 1, seq, inner)), bf(_tposed(q, 1, seq, inner)),
+                             bf(_tposed(do, 1, seq, inner)), bf(do), bf(o.bfloat16().float()), torch.zeros(heads, sp), torch.zeros(heads, sp),
+                             *g, n_img, seq, heads, 0.125)
+        w_out = torch.zeros(192, 64)
+        sim.wgrad_tn(bf(a), bf(b), w_out, alpha=0.5, splits=3)
+        t_out = torch.zeros(192, 320, dtype=torch.bfloat16)
+        sim.transpose_pad(bf(a), 300, 192, t_out)
+        c_out = torch.zeros(2 * 10 * 10, 96, dtype=torch.bfloat16)
+        sim.gemm(bf(ga), bf(gw), c_out, M=200, N=96, mode=nt.GEMM_CONV3X3, n_img=2, h=10, wd=10, tile_cfg=27)
+        return [t.clone() for t in g] + [w_out, t_out, c_out]
+
+    base = run()
+    for order in ("reverse", "random"):
+        monkeypatch.setenv("HOSTSIM_ORDER", order)
+        for x, y in zip(base, run()):
+            assert torch.equal(x, y), order
