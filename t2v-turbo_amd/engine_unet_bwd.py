@@ -24,8 +24,8 @@ for the 16-frame temporal ones), everything element-wise.
                                ``flash_attn_bwd``: ``attn_spatial_bwd`` (csrc/attention_bwd.hip, probabilities never in memory)
 
 Status: the dataflow is verified on CPU against torch autograd (tests/test_unet_grad_cpu.py, emulated op backend), and the
-device kernels of the new ops (csrc/backward_unet.hip, train.hip, attention_bwd.hip, wgrad_tn.hip) run as real source on a host SIMT
-simulator (tests/test_hostsim_*.py) but have not run on hardware yet; ``native`` use raises until ``T2V_UNVALIDATED_KERNELS=1`` is set."""
+device kernels (csrc/backward_unet.hip, train.hip, attention_bwd.hip, wgrad_tn.hip) against the emulated backend and the whole engine
+against autograd on MI355X (tests/test_gpu_unet_grad.py; the same sources also run on a host SIMT simulator, tests/test_hostsim_*.py)."""
 import os
 
 import torch
@@ -164,11 +164,6 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
     def _record_grad(self, x, timesteps, context, fps, timestep_cond, motion_cond, emb_all=None):
         m, ops = self.model, self.ops
         native = getattr(ops, "is_native", False)
-        if native:
-            import os
-            if os.environ.get("T2V_UNVALIDATED_KERNELS") != "1":
-                raise nt.NativeError("the UNet gradient path's device kernels have not been validated on hardware yet "
-                                     "(set T2V_UNVALIDATED_KERNELS=1 to run them anyway)")
         self._begin(x.device)
         B, Cin, F, H, W = x.shape
         self.B, self.F = B, F

@@ -203,6 +203,62 @@ def monkeypatch_remove_lora(model):
         parent._modules[name] = new
 
 
+def monkeypatch_or_replace_lora_extended(model, loras, target_replace_module=UNET_EXTENDED_TARGET_REPLACE, r=4):
+    """Load a flat ``[up0, down0, up1, down1, ...]`` list into ``model`` (utils/lora.py:877-997): plain leaves
+    are injected, already injected leaves get fresh branches of rank ``r`` (an int, or a list consumed
+    per leaf); a leaf whose kind does not match the rank of the next tensor is skipped, as in the reference."""
+    kinds = {nn.Linear: 2, LoraInjectedLinear: 2, nn.Conv2d: 4, LoraInjectedConv2d: 4, nn.Conv3d: 5, LoraInjectedConv3d: 5}
+    for parent, name, child in find_modules(model, target_replace_module, tuple(kinds)):
+        if child.__class__ not in kinds or not loras or loras[0].dim() != kinds[child.__class__]:
+            continue
+        src = child if not isinstance(child, _INJECTED) else (getattr(child, "linear", None) or child.conv)
+        rank = r.pop(0) if isinstance(r, list) else r
+        if isinstance(src, nn.Linear):
+            new = LoraInjectedLinear(src.in_features, src.out_features, src.bias is not None, r=rank)
+            new.linear.weight, new.linear.bias = src.weight, src.bias
+        elif isinstance(src, nn.Conv2d):
+            new = LoraInjectedConv2d(src.in_channels, src.out_channels, src.kernel_size, src.stride, src.padding,
+                                     src.dilation, src.groups, src.bias is not None, r=rank)
+            new.conv.weight, new.conv.bias = src.weight, src.bias
+        else:
+            new = LoraInjectedConv3d(src.in_channels, src.out_channels, bias=src.bias is not None,
+                                     kernel_size=src.kernel_size, padding=src.padding, r=rank)
+            new.conv.weight, new.conv.bias = src.weight, src.bias
+        up, down = loras.pop(0), loras.pop(0)
+        new.lora_up.weight = nn.Parameter(up.type(src.weight.dtype))
+        new.lora_down.weight = nn.Parameter(down.type(src.weight.dtype))
+        parent._modules[name] = new.to(src.weight.device)
+
+
+class LoraHandler:
+    """The trainers' and demos' entry point to the injection (utils/lora_handler.py:46-160;
+    train_t2v_turbo_v1_lora.py:644-657, app.py:249-263).  Only the ``cloneofsimo`` flavour exists upstream.
+    As upstream, ``dropout`` is accepted and NOT forwarded to the injector (lora_handler.py:84-100 filters the
+    arguments to model / loras / target_replace_module / r), so injected leaves keep the default p = 0.1."""
+
+    def __init__(self, version="cloneofsimo", use_unet_lora=False, use_text_lora=False, save_for_webui=False,
+                 only_for_webui=False, lora_bias="none", unet_replace_modules=("UNet3DConditionModel",)):
+        assert version == "cloneofsimo"
+        self.version = version
+        self.lora_loader = monkeypatch_or_replace_lora_extended
+        self.lora_injector = inject_trainable_lora_extended
+        self.lora_bias = lora_bias
+        self.use_unet_lora = use_unet_lora
+        self.use_text_lora = use_text_lora
+        self.save_for_webui = save_for_webui
+        self.only_for_webui = only_for_webui
+        self.unet_replace_modules = list(unet_replace_modules)
+        self.use_lora = any([use_text_lora, use_unet_lora])
+
+    def add_lora_to_model(self, use_lora, model, replace_modules, dropout=0.0, lora_path=None, r=16):
+        """Returns (list of parameter iterators, child names); (model, None) when ``use_lora`` is false."""
+        if not use_lora:
+            return model, None
+        params, negation = self.lora_injector(model=model, loras=lora_path, target_replace_module=replace_modules, r=r)
+        extract_lora_ups_down(model, target_replace_module=replace_modules)  # raises if nothing was injected
+        return params, negation
+
+
 def lora_parameters(model):
     """Trainable LoRA tensors in injection order (the buffer DDP all-reduces every step)."""
     out = []

@@ -1,18 +1,13 @@
-"""-m gpu, opt-in (T2V_TEST_UNVALIDATED=1): the device kernels of the UNet data-gradient path against the emulated backend, and
-the whole gradient engine on the GPU against torch autograd.  These kernels were written after the round's GPU budget was
-spent, so they are kept out of the default suite until they have run once; the CPU suite pins the engine's dataflow
-(tests/test_unet_grad_cpu.py)."""
-import os
-
+"""-m gpu: the device kernels of the UNet data-gradient / LoRA training path against the emulated backend, and the whole gradient
+engine on the GPU against torch autograd (first hardware run: round 2, call 1 — gpurun_out/c1/unet_grad.txt; the CPU suite pins
+the engine's dataflow, tests/test_unet_grad_cpu.py)."""
 import pytest
 import torch
 
 from tests.emu_ops import EmuOps
 from tests.util import rel_l2
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("T2V_TEST_UNVALIDATED") != "1",
-                                 reason="device kernels not yet validated on hardware; set T2V_TEST_UNVALIDATED=1")]
+pytestmark = pytest.mark.gpu
 
 TOL = 6e-3
 
@@ -129,7 +124,6 @@ def test_unet_grad_engine_on_gpu_vs_autograd(monkeypatch):
     from t2v_turbo_amd.unet3d import UNetModel
     from tests.test_unet_grad_cpu import _autograd_reference
     from tests.util import load, manifest, tiny_unet_params
-    monkeypatch.setenv("T2V_UNVALIDATED_KERNELS", "1")
     g = load("unet_tiny")
     cfg = tiny_unet_params(record_attn_probs=True)
     sd = synth_state_dict(manifest("unet_tiny"))
@@ -190,7 +184,6 @@ def test_lora_training_engine_on_gpu_vs_autograd(monkeypatch, new_kernels):
     from t2v_turbo_amd.native import HipOps
     from tests.test_unet_lora_grad_cpu import _autograd, _student
     from tests.util import load
-    monkeypatch.setenv("T2V_UNVALIDATED_KERNELS", "1")
     g = load("unet_tiny")
     ref, ref_params = _student("unet_tiny", 64)
     x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
@@ -234,7 +227,7 @@ def test_dropout_mask_is_the_emulated_one(ops, rows, ncols, ld, p, resid):
     """Counter-based dropout: the device mask must be bit-identical to the emulation's (the CPU suite checks the engine's use
     of that mask against autograd), in-place and with a residual, vector and pair paths."""
     hip, emu = ops
-    x = (_rt(rows, ld, seed=1) + 3.0).bfloat16().float()  # no zeros: the mask is readable from the output
+    x = (_rt(rows, ld, seed=1).abs() + 1.0).bfloat16().float()  # strictly positive: the mask is readable from the output
     r = _rt(rows, ld, seed=2)
     seed = torch.tensor([0x1234_5678_9ABC], dtype=torch.int64)
     keep = emu.dropout_keep(int(seed[0]), 7, rows, ncols, p)
@@ -247,7 +240,7 @@ def test_dropout_mask_is_the_emulated_one(ops, rows, ncols, ld, p, resid):
     assert rel_l2(got[:, :ncols], ref) < 5e-3
     if not resid:
         assert torch.equal(got[:, :ncols] != 0, keep)
-    assert abs(float(keep.float().mean()) - (1 - p)) < 0.02
+    assert abs(float(keep.float().mean()) - (1 - p)) < 4.0 * (p * (1 - p) / keep.numel()) ** 0.5 + 1e-3   # 4 sigma
 
 
 @pytest.mark.parametrize("rows,cols,batch,ld_in", [(100, 72, 1, 72), (40960, 320, 1, 320), (77, 320, 2, 320), (130, 64, 2, 192)])

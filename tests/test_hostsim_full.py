@@ -67,7 +67,6 @@ def test_training_step_on_the_real_library_only(full_ops, monkeypatch, flash):
     source on the simulator, through the GPU path's record / replay protocol."""
     from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
     from tests.test_unet_lora_grad_cpu import _autograd, _student
-    monkeypatch.setenv("T2V_UNVALIDATED_KERNELS", "1")
     g = load("unet_tiny")
     m, params = _student("unet_tiny", 64)
     x, ts, ctx, tc = g["x"][:, :, :2, :8, :8].contiguous(), g["ts"], g["ctx"], g["tc"]
@@ -102,7 +101,6 @@ def test_train_mode_step_on_the_real_library_only(full_ops, monkeypatch, new_ker
     bit (the backward regenerates the forward's masks from it), another seed does not, every gradient is finite."""
     from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
     from tests.test_unet_lora_grad_cpu import _student
-    monkeypatch.setenv("T2V_UNVALIDATED_KERNELS", "1")
     g = load("unet_tiny")
     m, params = _student("unet_tiny", 64)
     m.train()

@@ -1,5 +1,6 @@
 """Scheduler / CD math / pipeline mirrors on CPU vs the fixtures produced by the reference's own
 scheduler, solver, helper functions and pipeline loop (tests/golden/make_golden.py)."""
+import os
 import subprocess
 import sys
 
@@ -118,6 +119,48 @@ def test_compat_install_aliases_reference_paths():
         "assert cls is u.UNetModel\n"
         "print('ok', len(made))\n") % (__import__("tests.util").util.GOLDEN.rsplit("/tests/", 1)[0],)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="needs the reference checkout")
+def test_compat_install_leaves_the_rest_of_the_reference_importable():
+    """with the checkout on sys.path, ``compat.install()`` swaps in the hot-path modules and
+    nothing else — the import blocks of predict.py:12-15 and train_t2v_turbo_v1_lora.py:46-69 must execute
+    (third-party packages absent from this image stubbed as in tests/golden/make_golden.py)."""
+    code = (
+        "import sys, types; sys.path.insert(0, %r); sys.path.insert(0, '/root/reference')\n"
+        "import torch.nn as nn\n"
+        "def mod(name, **kw):\n"
+        "    m = types.ModuleType(name); m.__dict__.update(kw); sys.modules[name] = m; return m\n"
+        "mod('cv2'); tv = mod('torchvision'); tv.transforms = mod('torchvision.transforms')\n"
+        "tv.utils = mod('torchvision.utils', make_grid=None); mod('decord', VideoReader=object); mod('wandb')\n"
+        "mod('diffusers'); mod('diffusers.models'); mod('diffusers.models.attention_processor', AttnProcessor2_0=object)\n"
+        "mod('diffusers.models.attention', BasicTransformerBlock=object)\n"
+        "import t2v_turbo_amd.compat as c; c.install()\n"
+        # predict.py:12-15
+        "from utils.common_utils import load_model_checkpoint\n"
+        "from utils.utils import instantiate_from_config\n"
+        "from scheduler.t2v_turbo_scheduler import T2VTurboScheduler\n"
+        "from pipeline.t2v_turbo_vc2_pipeline import T2VTurboVC2Pipeline\n"
+        # train_t2v_turbo_v1_lora.py:46-69, app.py:19-20
+        "from ode_solver import DDIMSolver\n"
+        "from utils.lora import save_lora_weight, collapse_lora, monkeypatch_remove_lora\n"
+        "from utils.lora_handler import LoraHandler\n"
+        "from utils.common_utils import huber_loss, scalings_for_boundary_conditions\n"
+        "import lvdm.basics, lvdm.common, utils.utils as uu\n"
+        "assert uu.__file__.startswith('/root/reference/') and lvdm.basics.__file__.startswith('/root/reference/')\n"
+        "import t2v_turbo_amd.unet3d as u, t2v_turbo_amd.scheduler as s, t2v_turbo_amd.lora as l\n"
+        "assert T2VTurboScheduler is s.T2VTurboScheduler and LoraHandler is l.LoraHandler\n"
+        # the yaml target string resolves to the MI355X class through the reference's own instantiate_from_config
+        "from tests.util import tiny_unet_params\n"
+        "m = instantiate_from_config({'target': 'lvdm.modules.networks.openaimodel3d.UNetModel', 'params': tiny_unet_params()})\n"
+        "assert type(m) is u.UNetModel\n"
+        "h = LoraHandler(version='cloneofsimo', use_unet_lora=True, save_for_webui=True, unet_replace_modules=['UNetModel'])\n"
+        "params, names = h.add_lora_to_model(True, m, h.unet_replace_modules, dropout=0.1, r=8)\n"
+        "assert len(params) == 2 * len(names) and len(names) > 50\n"
+        "c.uninstall(); assert 'utils.lora' not in sys.modules\n"
+        "print('ok')\n") % (__import__("tests.util").util.GOLDEN.rsplit("/tests/", 1)[0],)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=180)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr
 
 

@@ -28,7 +28,6 @@ def test_unet_grad_engine_matches_autograd(protocol, monkeypatch):
     """``record_replay``: the same check through the native backend's protocol (launch lists recorded once, replayed with
     refreshed static inputs) instead of re-running the engine's Python closures on every call."""
     from tests.emu_ops import ReplayOps
-    monkeypatch.setenv("T2V_UNVALIDATED_KERNELS", "1")
     g = load("unet_tiny")
     cfg = tiny_unet_params(record_attn_probs=True)
     sd = synth_state_dict(manifest("unet_tiny"))

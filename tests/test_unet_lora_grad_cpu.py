@@ -281,7 +281,6 @@ def test_record_replay_protocol_of_the_native_backend(monkeypatch):
     inputs and updated LoRA tensors against autograd; the third in train mode is a new plan (dropout sites) and must still
     run."""
     from tests.emu_ops import ReplayOps
-    monkeypatch.setenv("T2V_UNVALIDATED_KERNELS", "1")
     g = load("unet_tiny")
     m, params = _student("unet_tiny", 64)
     ops = ReplayOps()

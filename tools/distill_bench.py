@@ -26,8 +26,7 @@ def main():
     ap.add_argument("--tiny", type=int, default=0, help="toy widths (plumbing check)")
     ap.add_argument("--rank-r", type=int, default=64)
     ap.add_argument("--native-student", type=int, default=0,
-                    help="1: student forward / target forward / backward on the native gradient engine (train mode, native dropout; "
-                         "needs T2V_UNVALIDATED_KERNELS=1 until its kernels have run on hardware)")
+                    help="1: student forward / target forward / backward on the native gradient engine (train mode, native dropout)")
     ap.add_argument("--batch-teacher", type=int, default=0, help="1: teacher cond + uncond forwards as one 2-clip call")
     ap.add_argument("--native-variants", default="",
                     help="comma list of engine variants timed one after the other on ONE model build, e.g. "

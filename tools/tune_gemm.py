@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--cold", type=int, default=0, help="evict caches before every timed launch (what the UNet step sees)")
     ap.add_argument("--train", type=int, default=0,
                     help="also tune the shapes of the native student step (LoRA rank 64: LoRA branch, data gradients, token-contracted "
-                         "weight gradients); needs T2V_UNVALIDATED_KERNELS=1 until that path has been validated on hardware")
+                         "weight gradients)")
     args = ap.parse_args()
     os.environ["T2V_GEMM_TUNE"] = "0"  # record with the library heuristics
     import bench
