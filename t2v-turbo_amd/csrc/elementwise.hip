@@ -179,9 +179,26 @@ extern "C" int t2v_silu(const void* x, void* out, long long n, void* stream) {
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
+// Zero fill as a KERNEL (not hipMemsetAsync): every node of a captured launch list is then a kernel node, ordered like every
+// other launch of the chain.  16-byte stores over the aligned body, byte stores for the (at most 15 + 15) edge bytes.
+__global__ __launch_bounds__(256) void fill_zero_kernel(unsigned char* __restrict__ p, long long head, long long body16, long long nbytes) {
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, step = (long long)gridDim.x * blockDim.x;
+    uint4* b = (uint4*)(p + head);
+    for (long long i = i0; i < body16; i += step) b[i] = make_uint4(0, 0, 0, 0);
+    const long long tail0 = head + body16 * 16;
+    if (i0 < head) p[i0] = 0;
+    if (i0 < nbytes - tail0) p[tail0 + i0] = 0;
+}
 extern "C" int t2v_fill_zero(void* p, long long nbytes, void* stream) {
     T2V_REQUIRE(p && nbytes > 0, T2V_EINVAL, "t2v_fill_zero");
-    if (hipMemsetAsync(p, 0, (size_t)nbytes, (hipStream_t)stream) != hipSuccess) { t2v_set_error("hipMemsetAsync failed"); return T2V_EHIP; }
+    long long head = (16 - (long long)((uintptr_t)p & 15)) & 15;
+    if (head > nbytes) head = nbytes;
+    const long long body16 = (nbytes - head) / 16;
+    long long blocks = (body16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char*)p, head, body16, nbytes);
+    T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
 extern "C" int t2v_cast(const void* x, int dt_in, void* out, int dt_out, long long n, void* stream) {

@@ -11,18 +11,25 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(backend=None):
-    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+def init_distributed(backend=None, single_process_group=False):
+    """Initialise from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*).  The rank's GPU becomes the
+    current device whenever CUDA is available (also under gloo: every native launch goes to the current device's stream).
+    ``single_process_group``: create the group even at world size 1 (a one-rank RCCL communicator: smoke tests)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 or dist.is_initialized():
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and local < torch.cuda.device_count():
+        torch.cuda.set_device(local)
+    if dist.is_initialized() or (world == 1 and not single_process_group):
         return
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kw = {}
     if backend == "nccl":
-        local = int(os.environ.get("LOCAL_RANK", "0"))
-        torch.cuda.set_device(local)
         kw["device_id"] = torch.device("cuda", local)
+    if world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        kw.update(rank=0, world_size=1)
     dist.init_process_group(backend, **kw)
 
 
@@ -46,8 +53,9 @@ class FlatGradSync:
     def zero_(self):
         self.flat.zero_()
 
-    def all_reduce_mean(self, async_op=False):
-        if not dist.is_initialized() or dist.get_world_size() == 1:
+    def all_reduce_mean(self, async_op=False, force=False):
+        """``force``: run the collective even in a one-rank group (smoke tests of the RCCL path)."""
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
             return None
         self.flat.div_(dist.get_world_size())
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)

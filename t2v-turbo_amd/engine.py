@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import native as nt
+from .native import on_tensor_device
 from .unet3d import (Downsample, ResBlock, SpatialTransformer, TemporalTransformer, TimestepEmbedSequential,
                      Upsample)
 
@@ -310,6 +311,7 @@ class UNetEngine(_Engine):
         super().__init__(ops)
         self.model = model
 
+    @on_tensor_device
     def __call__(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None):
         m = self.model
         assert x.dim() == 5 and context is not None

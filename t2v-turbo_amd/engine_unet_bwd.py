@@ -32,6 +32,7 @@ import torch
 import torch.nn as nn
 
 from . import native as nt
+from .native import on_tensor_device
 from .engine import Act, Packer, UNetEngine, effective_weight_bias, is_lora_leaf, leaf_out_channels
 from .engine_lora import LoraTrainMixin, _pad
 from .unet3d import Downsample, ResBlock, SpatialTransformer, TemporalTransformer, TimestepEmbedSequential, Upsample
@@ -59,6 +60,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 raise RuntimeError(f"native LoRA training: {len(other)} active Dropout module(s) the engine does not apply")
         return len(active)
 
+    @on_tensor_device
     def forward_tape(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None, emb_all=None, seed=None):
         """``emb_all`` (LoRA training only): the conditioning branch's output [B, sum of ResBlock widths] fp32, computed by
         the caller in torch (``conditioning_torch``) so that autograd owns that branch's 27 tiny leaves."""
@@ -110,6 +112,9 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         LoRA training: the weight gradients land in ``flat_grad`` (fp32, ``bind_lora`` order; added to what is there
         when ``accumulate``) and ``self.d_emb_all`` holds d(loss)/d(emb_all) for the caller's torch branch."""
         plan = self._last
+        if plan["out"].is_cuda and plan["out"].device.index != torch.cuda.current_device():
+            with torch.cuda.device(plan["out"].device):
+                return self.backward(dout, dprobs, flat_grad, accumulate)
         if plan.get("bwd_id") == plan["fwd_id"]:
             raise RuntimeError("UNet gradient: backward was already run for this forward (its saved activations are gone)")
         plan["bwd_id"] = plan["fwd_id"]

@@ -5,7 +5,9 @@ the mid AttnBlock as two batched GEMMs + a row softmax).  Replaces the per-frame
 ``AutoencoderKL.decode`` (autoencoder.py:110-113) -> ``Decoder.forward`` (ae_modules.py:602-641)."""
 import torch
 
+
 from . import native as nt
+from .native import on_tensor_device
 from .engine import Act, _Engine, leaf_out_channels
 from .vae import AttnBlock
 
@@ -15,6 +17,7 @@ class VAEDecodeEngine(_Engine):
         super().__init__(ops)
         self.vae = vae
 
+    @on_tensor_device
     def decode_frames(self, z, scale):
         """z (b, zc, t, h, w) -> (b, out_ch, t, 8h, 8w) in z.dtype; z is multiplied by ``scale`` first."""
         assert z.dim() == 5
@@ -158,6 +161,7 @@ class VAEEncodeEngine(VAEDecodeEngine):
     stride-2 conv with right/bottom padding (T2V_GEMM_CONV3X3_S2_PAD01); ``quant_conv`` (1x1) is folded into
     ``conv_out`` exactly (a pointwise map after the conv)."""
 
+    @on_tensor_device
     def encode_frames(self, x):
         """x (b, 3, t, H, W) -> moments (b, 2*embed, t, H/8, W/8), fp32."""
         assert x.dim() == 5

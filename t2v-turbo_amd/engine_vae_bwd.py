@@ -13,13 +13,16 @@ attention block's q / k / V^T / probabilities — everything else is recomputed 
 Forward and backward are two replayable launch lists (hipGraph-capturable) sharing one buffer pool."""
 import torch
 
+
 from . import native as nt
+from .native import on_tensor_device
 from .engine import Act, leaf_out_channels
 from .engine_vae import VAEDecodeEngine
 from .vae import AttnBlock
 
 
 class VAEDecodeGradEngine(VAEDecodeEngine):
+    @on_tensor_device
     def decode_frames_tape(self, z, scale):
         """Forward like ``decode_frames`` but keeps what ``backward`` needs; returns the video (b, 3, t, 8h, 8w)."""
         assert z.dim() == 5
@@ -40,6 +43,7 @@ class VAEDecodeGradEngine(VAEDecodeEngine):
         self._last = plan
         return plan["out"].clone()
 
+    @on_tensor_device
     def backward(self, dout):
         """d(loss)/dz for the most recent ``decode_frames_tape`` call."""
         plan = self._last

@@ -37,8 +37,20 @@ def unpack_latent_record(blob):
     return rec
 
 
+def _parse_bool(v):
+    """The spellings ``pd.read_csv`` accepts / writes for a boolean column: 1, 1.0, True, true (anything else is False);
+    raises on text that is none of the known true / false spellings."""
+    t = str(v).strip().lower()
+    if t in ("1", "1.0", "true", "t", "yes"):
+        return True
+    if t in ("0", "0.0", "false", "f", "no"):
+        return False
+    raise ValueError(f"use_motion_guide: cannot read {v!r} as a boolean")
+
+
 class LatentRecordDataset(Dataset):
     """``MP4LatentDataset`` (data/mp4_dataset.py:87-154) over a local root instead of an S3 bucket."""
+    MAX_RETRIES = 16
 
     def __init__(self, path_to_csv, latent_root="latent_root", root_dir="."):
         self.latent_root, self.root_dir = latent_root, root_dir
@@ -54,7 +66,7 @@ class LatentRecordDataset(Dataset):
         relpath, text = row["relpath"], row["text"]
         root = row.get("latent_root") or self.latent_root
         latent_dir = f"{root}/{relpath}"
-        use_motion_guide = bool(int(row["use_motion_guide"])) if row.get("use_motion_guide") not in (None, "") else True
+        use_motion_guide = _parse_bool(row["use_motion_guide"]) if row.get("use_motion_guide") not in (None, "") else True
         short_text = row.get("short_text") or ""
         if str(short_text) == "nan":
             short_text = ""
@@ -68,7 +80,8 @@ class LatentRecordDataset(Dataset):
         return latent_dict, text, short_text, use_motion_guide
 
     def __getitem__(self, idx):
-        while True:  # a broken record is replaced by a random other one, as the reference does
+        tries = 0
+        while True:  # a broken record is replaced by a random other one, as the reference does (bounded here)
             try:
                 latent_dict, text, short_text, use_motion_guide = self.get_latent_text_pair(idx)
                 for k in latent_dict:
@@ -77,7 +90,10 @@ class LatentRecordDataset(Dataset):
                 sample = dict(txt=text, short_txt=short_text, use_motion_guide=use_motion_guide)
                 sample.update(latent_dict)
                 return sample
+            except (KeyError, AssertionError, ValueError):
+                raise  # schema / parse errors are the CSV's, not a broken record: resampling would spin forever
             except Exception:
-                if self.length <= 1:
+                tries += 1
+                if self.length <= 1 or tries >= self.MAX_RETRIES:
                     raise
                 idx = random.randint(0, self.length - 1)

@@ -161,6 +161,24 @@ def _row_stride(t):
     return t.stride(0)
 
 
+def on_tensor_device(fn):
+    """Engine entry points: make the first CUDA tensor argument's GPU the current device for the launches inside.  Streams
+    (``torch.cuda.current_stream()``), the library's zero page and the split-K workspace are all per CURRENT device: a model
+    moved to a GPU that is not the current one (``pipe.to("cuda:1")``, a gloo rank that never called ``set_device``) would
+    otherwise launch on device 0's stream against device-1 pointers."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        t = next((a for a in args if torch.is_tensor(a) and a.is_cuda), None)
+        if t is None or t.device.index == torch.cuda.current_device():
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(t.device):
+            return fn(self, *args, **kwargs)
+
+    return wrapped
+
+
 def load_tune_table(path=None):
     """(mode, M, N, K, batch) -> (tile_cfg, split_k), produced on an MI355X by tools/tune_gemm.py."""
     import json

@@ -11,6 +11,8 @@ class FlatAdamW:
         self.params = [p for p in params if p.requires_grad]
         self.sync = grad_sync
         assert sum(p.numel() for p in self.params) == grad_sync.numel
+        assert len(self.params) == len(grad_sync.params) and all(a is b for a, b in zip(self.params, grad_sync.params)), \
+            "FlatAdamW and FlatGradSync must be built from the same parameter list, in the same order"
         dev = self.params[0].device
         self.flat_param = torch.empty(grad_sync.numel, dtype=torch.float32, device=dev)
         off = 0
@@ -28,8 +30,7 @@ class FlatAdamW:
 
     def _hip(self):
         if self._ops is None:
-            from .native import HipOps
-            self._ops = HipOps()
+            self._ops = _shared_ops()
             self._ws = torch.empty(1025, dtype=torch.float32, device=self.flat_param.device)
         return self._ops
 
@@ -73,14 +74,25 @@ class FlatAdamW:
         self.sync.zero_()
 
 
+_OPS = None
+
+
+def _shared_ops():
+    """One ``HipOps`` per process for the flat-buffer kernels (its constructor parses the GEMM tune table)."""
+    global _OPS
+    if _OPS is None:
+        from .native import HipOps
+        _OPS = HipOps()
+    return _OPS
+
+
 @torch.no_grad()
 def update_ema_flat(target_flat, source_flat, rate=0.99, target_params=None):
     """EMA of a flat fp32 parameter buffer (utils/common_utils.py:307-319) in one kernel.  ``target_params``: the target
     network's parameters if they are ``.data`` views of ``target_flat`` — one of their version counters is moved so that the
     native engines re-pack the target's weights (see FlatAdamW.step)."""
     if target_flat.is_cuda:
-        from .native import HipOps
-        HipOps().ema_update(target_flat, source_flat, rate)
+        _shared_ops().ema_update(target_flat, source_flat, rate)
     else:
         target_flat.mul_(rate).add_(source_flat, alpha=1 - rate)
     if target_params:

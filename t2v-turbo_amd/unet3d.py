@@ -353,6 +353,19 @@ class ResBlock(TimestepBlock):
 
 
 # =================================================================================== the UNet
+_WARNED_ATEN = set()
+
+
+def _warn_aten_route(why):
+    """The torch composite path on a CUDA tensor is a fallback (ATen kernels, ~3x slower than the native engines): say so once
+    per reason."""
+    if why not in _WARNED_ATEN:
+        _WARNED_ATEN.add(why)
+        import warnings
+        warnings.warn(f"t2v_turbo_amd UNetModel: running the torch (ATen) path on a CUDA tensor — {why}; "
+                      'set native_mode = "off" to silence, see INTEGRATION.md', RuntimeWarning, stacklevel=3)
+
+
 class _NativeStudent(torch.autograd.Function):
     """UNet forward whose backward — d/d(latents), d/d(emb_all) and every token-row LoRA weight gradient — runs on the native
     gradient engine.  Inputs: latents, the conditioning branch's output (torch keeps differentiating behind it), and the
@@ -500,14 +513,45 @@ class UNetModel(nn.Module):
         if motion_cond is not None:
             assert timestep_cond is not None
         mode = getattr(self, "native_mode", "auto")
-        if mode == "train":  # LoRA student of the distillation step on the native gradient engine (opt-in, see below)
+        if mode == "train":  # force the native gradient engine (raises where it cannot run)
             return self._forward_native_train(x, timesteps, context, fps, timestep_cond, motion_cond)
-        native = mode != "off"  # "off": always the torch path (e.g. a train-mode student)
-        if native and x.is_cuda and not (torch.is_grad_enabled() and self._needs_grad(x, context, timestep_cond)):
-            if features_adapter is not None:
-                raise NotImplementedError("features_adapter is not used by t2v-turbo and not supported natively")
-            return self.native_engine()(x, timesteps, context, fps, timestep_cond, motion_cond)
+        if mode != "off" and x.is_cuda:  # "off": always the torch path
+            route, why = self._auto_route(x, context, timestep_cond, features_adapter)
+            if route == "infer":
+                return self.native_engine()(x, timesteps, context, fps, timestep_cond, motion_cond)
+            if route == "train":
+                return self._forward_native_train(x, timesteps, context, fps, timestep_cond, motion_cond)
+            _warn_aten_route(why)
         return self._forward_composite(x, timesteps, context, features_adapter, fps, timestep_cond, motion_cond)
+
+    def _auto_route(self, x, context, timestep_cond, features_adapter):
+        """Which engine a CUDA call lands on (``native_mode = "auto"``):
+          * no gradient wanted, no active dropout            -> "infer": inference engine (LoRA branches merged at pack time);
+          * LoRA-injected student, only LoRA tensors trainable, with or without grad, train or eval mode
+            (the student and target forwards of train_t2v_turbo_v1_lora.py:1022-1028,1161-1168)
+                                                             -> "train": gradient engine (un-merged LoRA branch, counter-based dropout);
+          * anything else (full fine-tuning, a train-mode network without LoRA, gradients w.r.t. the context, adapters)
+                                                             -> the torch composite path, with a one-time warning."""
+        grad = torch.is_grad_enabled() and self._needs_grad(x, context, timestep_cond)
+        dropping = self.training and any(isinstance(mod, nn.Dropout) and mod.p > 0 for mod in self.modules())
+        if features_adapter is not None:
+            if not grad and not dropping:
+                raise NotImplementedError("features_adapter is not used by t2v-turbo and not supported natively")
+            return "composite", "features_adapter"
+        if not grad and not dropping:
+            return "infer", None
+        from .engine import is_lora_leaf
+        lora_ids = {id(w) for mod in self.modules() if is_lora_leaf(mod) for w in (mod.lora_up.weight, mod.lora_down.weight)}
+        if not lora_ids:
+            return "composite", ("a train-mode network with active Dropout and no LoRA" if not grad else
+                                 "gradients without LoRA injection (full fine-tuning / input gradients)")
+        if context is None:
+            return "composite", "no text context"
+        if any(p.requires_grad and id(p) not in lora_ids for p in self.parameters()):
+            return "composite", "trainable parameters besides the LoRA tensors"
+        if grad and (context.requires_grad or (timestep_cond is not None and timestep_cond.requires_grad)):
+            return "composite", "gradients w.r.t. the context / guidance embedding"
+        return "train", None
 
     def _needs_grad(self, *tensors):
         if any(t is not None and t.requires_grad for t in tensors):

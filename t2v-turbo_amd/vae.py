@@ -274,6 +274,8 @@ class AutoencoderKL(nn.Module):
         return self.post_quant_conv.weight.dtype
 
     def _native_ok(self, t):
+        if getattr(self, "native_mode", "auto") == "off":  # "off": every entry point takes the torch path
+            return False
         return t.is_cuda and not (torch.is_grad_enabled() and (t.requires_grad or any(p.requires_grad for p in self.parameters())))
 
     def encode(self, x, **kwargs):
@@ -293,6 +295,8 @@ class AutoencoderKL(nn.Module):
         return torch.stack([self.quant_conv(self.encoder(x[:, :, i])) for i in range(x.shape[2])], dim=2)
 
     def decode(self, z, **kwargs):
+        if getattr(self, "native_mode", "auto") == "off":
+            return self.decoder(self.post_quant_conv(z))
         if z.is_cuda and not (torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self.parameters()))):
             return self.native_engine().decode_frames(z.unsqueeze(2), scale=1.0).squeeze(2)
         if (z.is_cuda and torch.is_grad_enabled() and z.requires_grad and not any(p.requires_grad for p in self.parameters())
@@ -318,7 +322,8 @@ class AutoencoderKL(nn.Module):
     def decode_video(self, z, scale_factor=0.18215):
         """(b,4,t,h,w) latents -> (b,3,t,8h,8w): ``LatentDiffusion.decode_first_stage_2DAE``
         (lvdm/models/ddpm3d.py:666-679) with every frame in one batched pass on the GPU."""
-        if z.is_cuda and not (torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self.parameters()))):
+        if (z.is_cuda and getattr(self, "native_mode", "auto") != "off"
+                and not (torch.is_grad_enabled() and (z.requires_grad or any(p.requires_grad for p in self.parameters())))):
             return self.native_engine().decode_frames(z, scale=1.0 / scale_factor)
         z = z / scale_factor
         return torch.cat([self.decode(z[:, :, i]).unsqueeze(2) for i in range(z.shape[2])], dim=2)

@@ -401,3 +401,44 @@ def test_gemm_fast_and_generic_epilogues_agree_with_emulation(pair, cfg):
     n, h, w = 4, 10, 16
     assert _gemm_case(pair, M=n * h * w, N=128, c0=64, c1=64, mode=1, n_img=n, h=h, w=w, rows=n * h * w, residual=True,
                       rowvec_div=h * w, cfg=cfg, seed=3) < BF16_TOL                  # conv + concat + both folded terms
+
+
+@pytest.mark.parametrize("offset,scale", [(8.0, 0.5), (-30.0, 1.0), (3.0, 0.05)])
+@pytest.mark.parametrize("C,c1,units,rows", [(320, 0, 2, 77), (960, 320, 1, 1500), (320, 0, 1, 9000)])
+def test_group_norm_inputs_with_mean_far_from_zero(pair, C, c1, units, rows, offset, scale):
+    """Real VideoCrafter2 activations are not zero-mean: |mean| >> std must not cost the E[x^2] - mean^2 statistics their
+    digits (fp32 partial sums).  The emulation works on the same bf16-rounded inputs, so the tolerance stays the bf16 one."""
+    c0 = C - c1
+    x0 = pair.act((_rt(units * rows, c0, seed=1) * scale + offset).bfloat16().float())
+    x1 = pair.act((_rt(units * rows, c1, seed=2) * scale - offset).bfloat16().float()) if c1 else (None, None)
+    gamma, beta = pair.f32(_rt(C, seed=3) * 0.1 + 1.0), pair.f32(_rt(C, seed=4) * 0.1)
+    ws = torch.zeros(pair.hip.group_norm_ws_floats(units, rows, 32, C), device="cuda")
+    out_h = torch.zeros(units * rows, C, dtype=torch.bfloat16, device="cuda")
+    out_e = torch.zeros(units * rows, C)
+    pair.run("group_norm", (x0[0], x1[0], units, rows, 1e-5, gamma[0], beta[0], False, ws, out_h),
+             (x0[1], x1[1], units, rows, 1e-5, gamma[1], beta[1], False, None, out_e))
+    assert rel_l2(out_h.float().cpu(), out_e) < BF16_TOL
+
+
+@pytest.mark.parametrize("offset,scale", [(8.0, 0.5), (-30.0, 1.0), (3.0, 0.05)])
+@pytest.mark.parametrize("M,C", [(1000, 320), (37, 1280)])
+def test_layernorm_inputs_with_mean_far_from_zero(pair, M, C, offset, scale):
+    x = pair.act((_rt(M, C, seed=1) * scale + offset).bfloat16().float())
+    gamma, beta = pair.f32(_rt(C, seed=3) * 0.1 + 1.0), pair.f32(_rt(C, seed=4) * 0.1)
+    out_h = torch.zeros(M, C, dtype=torch.bfloat16, device="cuda")
+    out_e = torch.zeros(M, C)
+    pair.run("layernorm", (x[0], gamma[0], beta[0], 1e-5, out_h), (x[1], gamma[1], beta[1], 1e-5, out_e))
+    assert rel_l2(out_h.float().cpu(), out_e) < BF16_TOL
+
+
+def test_fill_zero_edges(pair):
+    """Zero fill is a kernel (a memset node of a captured launch list did not re-execute in order on replay): unaligned head
+    and tail bytes, nothing outside the range touched."""
+    buf = torch.full((4096 + 64,), 0x5A, dtype=torch.uint8, device="cuda")
+    for off, n in ((0, 4096), (3, 1000), (17, 31), (5, 1), (16, 16), (1, 4095)):
+        buf.fill_(0x5A)
+        pair.hip._call("t2v_fill_zero", buf.data_ptr() + off, n)
+        torch.cuda.synchronize()
+        got = buf.cpu()
+        assert int(got[off:off + n].max()) == 0
+        assert bool((got[:off] == 0x5A).all()) and bool((got[off + n:] == 0x5A).all())

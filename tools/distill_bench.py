@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--rank-r", type=int, default=64)
     ap.add_argument("--native-student", type=int, default=0,
                     help="1: student forward / target forward / backward on the native gradient engine (train mode, native dropout)")
+    ap.add_argument("--module-route", type=int, default=0,
+                    help="1: no explicit engine — the student is called as a module (native_mode auto) and autograd drives the backward")
     ap.add_argument("--batch-teacher", type=int, default=0, help="1: teacher cond + uncond forwards as one 2-clip call")
     ap.add_argument("--native-variants", default="",
                     help="comma list of engine variants timed one after the other on ONE model build, e.g. "
@@ -82,6 +84,16 @@ def main():
         opt = FlatAdamW(params, sync, lr=1e-5)   # parameters / gradients / moments: three flat buffers, one fused kernel
         eng = UNetGradEngine(student, HipOps())
         eng.bind_lora(params)
+    elif a.module_route:
+        # what train_t2v_turbo_v1_lora.py does: plain module calls + loss.backward(); UNetModel.forward routes the LoRA student to
+        # the native gradient engine by itself (native_mode = "auto")
+        from t2v_turbo_amd.optim import FlatAdamW
+        student.train()
+        with torch.no_grad():
+            for p in params:
+                if float(p.abs().max()) == 0.0:
+                    p.normal_(0.0, 0.01, generator=g)
+        opt = FlatAdamW(params, sync, lr=1e-5)
     else:
         student.train()
         student.native_mode = "off"  # train-mode dropout + autograd: torch path
@@ -123,7 +135,7 @@ def main():
         dt = (time.perf_counter() - t1) / a.steps
         if rank == 0:
             print(json.dumps({"metric": "v1 distillation steps/sec (student " + ("native gradient engine" if eng is not None else "fwd+bwd torch path")
-                              + ", teacher x2 native HIP)", "student_native": eng is not None, "variant": variant,
+                              + ", teacher x2 native HIP)", "student_native": eng is not None or bool(a.module_route), "variant": variant or ("module-route" if a.module_route else None),
                               "value": round(world / dt, 4), "unit": "samples/s", "n_gpus": world, "ms_per_step": round(dt * 1e3, 1),
                               "lora_grad_mb": round(sync.numel * 4 / 2 ** 20, 1), "loss": float(loss),
                               "teacher_native": teacher._engine_box.engine is not None, "peak_mem_gb":
