@@ -62,7 +62,7 @@ GEMM_TILES = {1: (128, 128), 2: (128, 64), 3: (256, 64), 4: (128, 128), 5: (128,
               8: (64, 128), 9: (256, 64), 10: (128, 128), 11: (128, 256), 12: (256, 256), 13: (256, 128), 14: (128, 256),
               15: (256, 256), 16: (256, 128), 17: (128, 256), 18: (128, 128), 19: (256, 128), 20: (256, 256),
               21: (256, 256), 22: (160, 320), 23: (160, 320), 24: (256, 256), 25: (256, 128), 26: (128, 128),
-              27: (256, 256), 28: (160, 320), 29: (128, 256)}
+              27: (256, 256), 28: (160, 320), 29: (128, 256), 30: (128, 128), 31: (128, 128), 32: (128, 128), 33: (128, 128)}
 
 
 def gemm_operand_gbyte(d, k_total):

@@ -192,6 +192,12 @@ int t2v_lcm_step(const float* x, const void* eps, int eps_dt, const float* noise
  * compiles them out and these calls just store the value). */
 int t2v_gemm_debug(int bits);
 int t2v_attn_debug(int bits);
+/* t2v_group_norm has a ONE-launch form (registers hold the tensor, per-unit inter-workgroup barrier) for tensors that fit:
+ * t2v_gn_coop_enable(1) / environment T2V_GN_COOP=1 selects it (default off: measured slower than the three-launch form on
+ * MI355X for cache-resident tensors); t2v_gn_coop_error() returns 1 if a
+ * barrier of the one-launch form ever timed out on the current device (workgroups not co-resident), -1 on a HIP error. */
+int t2v_gn_coop_enable(int on);
+int t2v_gn_coop_error(void);
 
 /* ---------------------------------------------------------------- backward (dX) pieces of the VAE decoder
  * Reward-gradient branch (train_t2v_turbo_v1_lora.py:1047-1098: autograd through vae.decode, ae_modules.py:602-641).

@@ -236,7 +236,7 @@ extern "C" int t2v_gn_bwd(const void* x, int ldx, int C, int n_units, int rows_p
                        (const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, C, rows_per_unit, groups, slab_rows, stats, gamma, beta, silu, partial);
     T2V_CHECK_LAUNCH();
     const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / groups));
-    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(n_units), dim3(256), 0, s, (const float*)partial, nslab, groups, inv_count, bstats);
+    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(n_units), dim3(GB_FINAL_THREADS), 0, s, (const float*)partial, nslab, groups, inv_count, bstats);
     T2V_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x, ldx, (const bf16_t*)dy, ldy, C,
                        rows_per_unit, groups, slab_rows, stats, gamma, beta, silu, (const float*)bstats, (const bf16_t*)resid, ldr,

@@ -411,7 +411,7 @@ extern "C" int t2v_gn_bwd2(const void* x, int xc0, int ldx, const void* x1, int 
                        stats, gamma, beta, silu, partial);
     T2V_CHECK_LAUNCH();
     const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / groups));
-    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(n_units), dim3(256), 0, s, (const float*)partial, nslab, groups, inv_count, bstats);
+    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(n_units), dim3(GB_FINAL_THREADS), 0, s, (const float*)partial, nslab, groups, inv_count, bstats);
     T2V_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_bwd2_apply_kernel, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x, xc0, ldx, (const bf16_t*)x1, ldx1,
                        (const bf16_t*)dy, ldy, C,

@@ -899,6 +899,13 @@ int t2v_gemm_launch_experimental(int cfg, GemmParams& p, hipStream_t s) {
         case 27: return launch<256, 256, 2, 4, 2, 32, 2, true>(p, s);
         case 28: return launch<160, 320, 5, 2, 2, 32, 3, true>(p, s);
         case 29: return launch<128, 256, 1, 4, 2, 32, 2, true>(p, s);
+        // EIGHT waves on the small workgroup tiles (two waves per SIMD instead of one): the 10x16 and 5x8 levels give fewer
+        // than 256 tiles of any size, so a CU runs ONE workgroup and a 4-wave one leaves every SIMD with a single wave —
+        // nothing to issue while it waits at the hand-over barrier or for its fragments
+        case 30: return launch<128, 128, 4, 2, 3, 64, 2>(p, s);
+        case 31: return launch<128, 128, 2, 4, 3, 64, 2>(p, s);
+        case 32: return launch<128, 128, 2, 4, 4, 32, 2>(p, s);
+        case 33: return launch<128, 128, 4, 2, 4, 32, 2>(p, s);
         default: return T2V_EINVAL;
     }
 }
@@ -929,8 +936,10 @@ const TileCfg kCfg[] = {{0, 0, 0},      {128, 128, 64}, {128, 64, 32},  {256, 64
                         // register-staged twins (global -> VGPR -> ds_write_b128, two-slot ring) of 6, 1, 20, 23 and 17: the
                         // candidates for the question tools/fill_rate.hip asks (is LDS-DMA's 16 B/clk per CU the operand
                         // delivery limit).  Compile-verified only, like 24.
-                        {256, 128, 64, 64}, {128, 128, 64, 64}, {256, 256, 64, 32}, {160, 320, 32, 32}, {128, 256, 64, 32}};
-constexpr int kNumCfg = 29;  // (a 4-wave 128x128-wave-tile variant spills: 3 KB/lane scratch, 72 TF/s - dropped)
+                        {256, 128, 64, 64}, {128, 128, 64, 64}, {256, 256, 64, 32}, {160, 320, 32, 32}, {128, 256, 64, 32},
+                        // 8-wave small tiles (ids 30-33, see t2v_gemm_launch_experimental)
+                        {128, 128, 64, 64}, {128, 128, 32, 64}, {128, 128, 32, 32}, {128, 128, 64, 32}};
+constexpr int kNumCfg = 33;  // (a 4-wave 128x128-wave-tile variant spills: 3 KB/lane scratch, 72 TF/s - dropped)
 
 int dispatch(int cfg, GemmParams& p, hipStream_t s) {
     switch (cfg) {
@@ -957,7 +966,8 @@ int dispatch(int cfg, GemmParams& p, hipStream_t s) {
         case 21: return launch<256, 256, 4, 2, 4, 32, 2>(p, s);
         case 22: return launch<160, 320, 5, 2, 2, 64, 3>(p, s);
         case 23: return launch<160, 320, 5, 2, 3, 32, 3>(p, s);
-        case 24: case 25: case 26: case 27: case 28: case 29: return t2v_gemm_launch_experimental(cfg, p, s);
+        case 24: case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32: case 33:
+            return t2v_gemm_launch_experimental(cfg, p, s);
         default: return T2V_EINVAL;
     }
 }

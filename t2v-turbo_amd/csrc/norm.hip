@@ -2,6 +2,7 @@
 // All three are HBM-bandwidth bound: 16-byte (8 x bf16) per-lane accesses, fp32 math,
 // wave-shuffle (64-lane butterfly) reductions, no re-reads beyond what the algorithm needs.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -110,26 +111,43 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x0, int c
 
 // Statistics of one unit from its slab partials, in a fixed order (block-wide helper, NT threads): thread = (part, value)
 // walks slabs [part*chunk, ...), then the parts are added in order.  Leaves (mean, rstd) of group g in sm[g], sr[g].
-template <int NT, int MAXCH>
+// COHERENT: the partials were published by other workgroups of the SAME launch with agent-scope atomic stores; read them with
+// agent-scope atomic loads (served by L2 / the fabric, never by this CU's L1), so no acquire fence is needed.
+template <int NT, int MAXCH, bool COHERENT = false>
 __device__ __forceinline__ void gn_finish_unit(const float* partial, int unit, int nslab, int groups, float inv_count, float eps,
                                                double* sh /*[NT]*/, float* sm, float* sr) {
+    auto ld = [](const float* p) -> float {
+#ifndef T2V_HOSTSIM
+        if constexpr (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        return *p;
+    };
     const int tid = threadIdx.x;
     const int width = groups * 2, parts = NT / width;
     const int v = tid % width, part = tid / width;
     const float* base = partial + (long long)unit * nslab * width + v;
     const int chunk = (nslab + parts - 1) / parts;
     double acc = 0.0;
-    if (part < parts) {
+    if (COHERENT && chunk <= 16) {
+        // device-scope loads are served past the L1 (and across XCDs past the L2): a fabric round trip each, so ALL of a thread's
+        // (at most 16) loads go out before the first add
+        float t[16];
+        const int k0 = part * chunk;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t[e] = (part < parts && e < chunk && k0 + e < nslab) ? ld(base + (long long)(k0 + e) * width) : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc += (double)t[e];
+    } else if (part < parts) {
         const int k1 = min(nslab, (part + 1) * chunk);
         int k = part * chunk;
         for (; k + 8 <= k1; k += 8) {  // 8 coalesced loads in flight, then a fixed-order add
             float t[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = base[(long long)(k + e) * width];
+            for (int e = 0; e < 8; ++e) t[e] = ld(base + (long long)(k + e) * width);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc += (double)t[e];
         }
-        for (; k < k1; ++k) acc += (double)base[(long long)k * width];
+        for (; k < k1; ++k) acc += (double)ld(base + (long long)k * width);
     }
     sh[tid] = acc;
     __syncthreads();
@@ -254,6 +272,149 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0,
         }
     }
 }
+
+#ifndef T2V_HOSTSIM
+// ---- GroupNorm(+SiLU) in ONE launch (t2v_group_norm, tensors that fit the chip's registers) ---------------------------------------
+// The three-launch form reads x twice and pays three kernel boundaries for tensors that are mostly a few MB.  Here every
+// workgroup (1024 threads, at most one per CU so that all of them are resident) keeps its slice of one statistics unit IN
+// REGISTERS — thread (cx, ry) owns the 16-byte chunk cx of rows ry, ry + ty, ... (up to MAXC of them, all loads issued before
+// the first use) — reduces it to per-group (sum, sum of squares), publishes those 2*groups floats, meets the other workgroups
+// of its unit at a barrier, finishes the unit's statistics from all the partials in a fixed order (deterministic: no float
+// atomics) and normalises its registers straight into the output: x is read once and y written once.
+// Barrier (per unit): the partials travel as agent-scope atomic stores / loads on both sides (a valid hand-off form of
+// MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": no release / acquire fences, which
+// would write back and invalidate whole caches); stores drained -> arrival counter; the last arriver resets the counter and
+// bumps a generation word, the others poll the generation with relaxed agent-scope loads + s_sleep.  Every workgroup reads the generation
+// BEFORE it arrives, and the bump needs all arrivals, so nobody can miss it.  The spin is bounded: if the workgroups are not
+// co-resident after all (a shared GPU), the launch finishes with a wrong result and the error word set instead of hanging.
+constexpr int GC_NT = 1024;
+constexpr int GC_SPIN_LIMIT = 1 << 21;
+
+template <int MAXC>
+__global__ __launch_bounds__(GC_NT) void gn_coop_kernel(const bf16_t* __restrict__ x0, int c0, int ld0, const bf16_t* __restrict__ x1, int c1,
+                                                        int ld1, int rows_per_unit, int groups, int wgs_per_unit, int rows_per_wg,
+                                                        float inv_count, float eps, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int silu, float* partial, unsigned* sync_words,
+                                                        bf16_t* __restrict__ out, int ldo) {
+    extern __shared__ float sred[];  // [2][ty][C]
+    __shared__ double sh[GC_NT];
+    __shared__ float sm[128], sr[128];
+    const int C = c0 + c1, cpg = C / groups, cpr = C / 8;
+    const int tx = cpr, ty = GC_NT / tx;
+    const int tid = threadIdx.x;
+    const int unit = blockIdx.x / wgs_per_unit, wg = blockIdx.x - unit * wgs_per_unit;
+    const int cx = tid % tx, ry = tid / tx;
+    const bool active = ry < ty;
+    const int r0 = wg * rows_per_wg;
+    const int r1 = min(r0 + rows_per_wg, rows_per_unit);
+    const long long row_base = (long long)unit * rows_per_unit;
+    uint4 u[MAXC];
+    float* ssum = sred;
+    float* ssq = sred + ty * C;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int rr = r0 + ry + i * ty;
+            u[i] = rr < r1 ? *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, row_base + rr, cx * 8) : make_uint4(0, 0, 0, 0);
+        }
+        float sv[8], qv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sv[e] = 0.f; qv[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            float f[8];
+            unpack8(u[i], f);  // rows past the slice are zero chunks: they add nothing
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sv[e] += f[e]; qv[e] += f[e] * f[e]; }
+        }
+        *(float4*)(ssum + ry * C + cx * 8) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+        *(float4*)(ssum + ry * C + cx * 8 + 4) = make_float4(sv[4], sv[5], sv[6], sv[7]);
+        *(float4*)(ssq + ry * C + cx * 8) = make_float4(qv[0], qv[1], qv[2], qv[3]);
+        *(float4*)(ssq + ry * C + cx * 8 + 4) = make_float4(qv[4], qv[5], qv[6], qv[7]);
+    }
+    __syncthreads();
+    // per-group sums of this workgroup: thread = (part, value) adds the thread-rows y = part, part + parts, ... of its group's
+    // channels, the parts are then added in order
+    {
+        const int width = groups * 2, parts = GC_NT / width;
+        const int v = tid % width, part = tid / width;
+        float a = 0.f;
+        if (part < parts) {
+            const float* src = ((v & 1) ? ssq : ssum) + (v >> 1) * cpg;
+            for (int y = part; y < ty; y += parts) {
+                const float* row = src + y * C;
+                float b0 = 0.f, b1 = 0.f;
+                int c = 0;
+                for (; c + 2 <= cpg; c += 2) { b0 += row[c]; b1 += row[c + 1]; }
+                if (c < cpg) b0 += row[c];
+                a += b0 + b1;
+            }
+        }
+        sh[tid] = (double)a;
+        __syncthreads();
+        if (tid < width) {
+            double t = 0.0;
+            for (int pz = 0; pz < parts; ++pz) t += sh[pz * width + tid];
+            // write-through (agent-scope atomic) store, drained before the block barrier below: the partials are visible at the
+            // device's coherence point when thread 0 arrives at the counter, with NO release fence (a release writes back every
+            // dirty line of the XCD's L2, i.e. the producer kernel's whole output: 4-8 us measured on the first version)
+            __hip_atomic_store(partial + ((long long)unit * wgs_per_unit + wg) * width + tid, (float)t, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && wgs_per_unit > 1) {
+        unsigned* cnt = sync_words + 2 * unit;
+        unsigned* gen = cnt + 1;
+        const unsigned my_gen = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)wgs_per_unit - 1u) {
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int it = 0;
+            while (__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_gen && it < GC_SPIN_LIMIT) {
+                __builtin_amdgcn_s_sleep(2);
+                ++it;
+            }
+            if (it >= GC_SPIN_LIMIT) __hip_atomic_store(sync_words + 2 * 256, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    gn_finish_unit<GC_NT, 64, true>(partial, unit, wgs_per_unit, groups, inv_count, eps, sh, sm, sr);
+    if (!active) return;
+    float sc[8], sf[8];
+    {
+        const float4 g0 = *(const float4*)(gamma + cx * 8), g1 = *(const float4*)(gamma + cx * 8 + 4);
+        const float4 b0 = *(const float4*)(beta + cx * 8), b1 = *(const float4*)(beta + cx * 8 + 4);
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        int grp = (cx * 8) / cpg, next = (grp + 1) * cpg - cx * 8;  // channels left in the current group
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (e == next) { ++grp; next += cpg; }
+            const float a = sr[grp] * gm[e];
+            sc[e] = a;
+            sf[e] = bt[e] - sm[grp] * a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int rr = r0 + ry + i * ty;
+        if (rr < r1) {
+            float f[8];
+            unpack8(u[i], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = f[e] * sc[e] + sf[e];
+                f[e] = silu ? silu_f(v) : v;
+            }
+            *(uint4*)(out + (row_base + rr) * ldo + cx * 8) = pack8(f);
+        }
+    }
+}
+#endif  // T2V_HOSTSIM
 
 // ---- LayerNorm: a wave owns ROWS rows, each held in registers (NJ 16-byte chunks per lane, C <= 64*8*NJ);
 // all ROWS*NJ loads are issued before the first reduction so a wave keeps several rows in flight ----------
@@ -432,6 +593,83 @@ extern "C" int t2v_gn_apply(const void* x0, int c0, int ld0, const void* x1, int
     return T2V_OK;
 }
 
+#ifndef T2V_HOSTSIM
+// per-device state of the one-launch GroupNorm: 2 words per unit (arrival count, generation) + an error word, zeroed once
+static unsigned* gn_coop_sync_words(int* n_cu) {
+    static unsigned* words[64] = {nullptr};
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!words[dev]) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return nullptr;
+        void* p = nullptr;
+        if (hipMalloc(&p, (2 * 256 + 64) * sizeof(unsigned)) != hipSuccess) return nullptr;
+        if (hipMemset(p, 0, (2 * 256 + 64) * sizeof(unsigned)) != hipSuccess) return nullptr;
+        words[dev] = (unsigned*)p;
+        cus[dev] = prop.multiProcessorCount;
+    }
+    *n_cu = cus[dev];
+    return words[dev];
+}
+extern "C" int t2v_gn_coop_error(void) {  // 1 if a one-launch GroupNorm ever gave up waiting at its barrier on this device
+    int n_cu = 0;
+    unsigned* w = gn_coop_sync_words(&n_cu);
+    unsigned v = 0;
+    if (!w || hipMemcpy(&v, w + 2 * 256, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)v;
+}
+static int g_gn_coop = -1;
+extern "C" int t2v_gn_coop_enable(int on) { g_gn_coop = on ? 1 : 0; return T2V_OK; }
+
+// true (and launched) when the tensor fits the one-launch form
+static bool gn_try_coop(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units, int rows_per_unit, int groups,
+                        float eps, const float* gamma, const float* beta, int silu, float* ws, void* out, int ldo, hipStream_t s) {
+    // OFF by default: measured on MI355X (profiles/r02_gn_one_launch_vs_three.csv) the one-launch form is SLOWER than the three
+    // launches on every UNet shape (3.25-3.70 ms vs 2.67 ms per step in-graph): the tensors are L2 / Infinity-Cache resident
+    // when GroupNorm runs, so the second read the three-launch form pays is cheap, while the device-scope hand-off (atomic
+    // arrival + fabric-latency polls and partial loads) costs 8-14 us per call however small the tensor.
+    if (g_gn_coop < 0) g_gn_coop = getenv("T2V_GN_COOP") ? atoi(getenv("T2V_GN_COOP")) : 0;
+    if (!g_gn_coop) return false;
+    const int C = c0 + c1, cpr = C / 8;
+    if (cpr > GC_NT || cpr < 1 || n_units > 256 || 2 * groups > GC_NT) return false;
+    int n_cu = 0;
+    unsigned* sync_words = gn_coop_sync_words(&n_cu);
+    if (!sync_words || n_cu < n_units) return false;
+    const int ty = GC_NT / cpr;
+    int w = n_cu / n_units;                                   // one workgroup per CU: all resident
+    const int by_rows = (rows_per_unit + ty - 1) / ty;        // a workgroup wants at least one row per thread row
+    if (w > by_rows) w = by_rows;
+    const int ws_cap = (rows_per_unit + GN_RPT - 1) / GN_RPT;  // what t2v_gn_ws_floats sized the partial area for
+    if (w > ws_cap) w = ws_cap;
+    if (w > GN_MAX_SLABS) w = GN_MAX_SLABS;
+    if (w < 1) w = 1;
+    const int rows_per_wg = (rows_per_unit + w - 1) / w;
+    w = (rows_per_unit + rows_per_wg - 1) / rows_per_wg;
+    const int need = (rows_per_wg + ty - 1) / ty;             // chunks a thread keeps in registers
+    if (need > 16) return false;
+    const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / groups));
+    const size_t lds = (size_t)2 * ty * C * sizeof(float);
+#define T2V_GC_LAUNCH(MAXC)                                                                                                       \
+    do {                                                                                                                          \
+        static bool attr = false;                                                                                                 \
+        if (!attr) { hipFuncSetAttribute((const void*)gn_coop_kernel<MAXC>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr = true; } \
+        hipLaunchKernelGGL(gn_coop_kernel<MAXC>, dim3(n_units * w), dim3(GC_NT), lds, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, \
+                           c1, ld1, rows_per_unit, groups, w, rows_per_wg, inv_count, eps, gamma, beta, silu, ws, sync_words,      \
+                           (bf16_t*)out, ldo);                                                                                    \
+    } while (0)
+    if (need <= 2) T2V_GC_LAUNCH(2);
+    else if (need <= 4) T2V_GC_LAUNCH(4);
+    else if (need <= 8) T2V_GC_LAUNCH(8);
+    else T2V_GC_LAUNCH(16);
+#undef T2V_GC_LAUNCH
+    return true;
+}
+#else  // host simulator: workgroups run one after the other, a spin barrier between them cannot be simulated
+extern "C" int t2v_gn_coop_error(void) { return 0; }
+extern "C" int t2v_gn_coop_enable(int) { return T2V_OK; }
+#endif
+
 // GroupNorm(+SiLU) in one call: slab partial sums, then either [finish + per-channel affine, streaming apply] or, for
 // tensors with few slabs, an apply pass whose blocks finish the statistics themselves (2 launches instead of 3).
 extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units,
@@ -442,6 +680,12 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
     T2V_REQUIRE(ws && gamma && beta && out && ldo % 8 == 0, T2V_EINVAL, "t2v_group_norm: bad argument");
     if (!x1) { c1 = 0; ld1 = 0; }
     hipStream_t s = (hipStream_t)stream;
+#ifndef T2V_HOSTSIM
+    if (gn_try_coop(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups, eps, gamma, beta, silu, ws, out, ldo, s)) {
+        T2V_CHECK_LAUNCH();
+        return T2V_OK;
+    }
+#endif
     rc = gn_launch_partial(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups, ws, s);
     if (rc) return rc;
     const int C = c0 + c1, nslab = gn_nslab(C, rows_per_unit, groups), slab_rows = gn_slab_rows(C, rows_per_unit, groups);

@@ -7,8 +7,12 @@
 // go to LDS row-major (16-byte global loads), and each lane gathers its MFMA fragments — 8 consecutive TOKENS of one column — with
 // 2-byte LDS reads down a column (row pitch 66 elements = 33 words: the 32 lanes of a half-wave read 32 consecutive columns of one
 // row).  fp32 partial tiles go to a workspace; a second kernel adds them in a fixed order (deterministic) and applies alpha.
-// First version: the column gather is what ds_read_b64_tr_b16 exists for, the loads are not overlapped with the MFMAs.
-// NOT yet run on hardware; verified on the host SIMT simulator (tests/test_hostsim_kernels.py).
+// These products are bandwidth-bound (2 M R C FLOPs on M (R + C) 2 bytes: 1.7 GFLOP on 31 MB for dU at the 320-channel level), so
+// what matters is keeping loads in flight and the partial slabs small: the global loads of token step i+1 are issued into
+// registers BEFORE the LDS phase of step i (one workgroup then covers its own latency), the token range is split over about two
+// workgroups per CU (the partial slabs were as large as the operands when every CU got four), and the reduce kernel spreads the
+// splits over four thread groups per output (fixed assignment, fixed combine order: still deterministic).
+// The column gather is what ds_read_b64_tr_b16 exists for (not used: the LDS phase is not the bound).
 #include "common.h"
 
 namespace {
@@ -37,25 +41,34 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict_
     f32x16_t acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    for (long long m0 = m_begin; m0 < m_end; m0 += WT_TOK) {
-        __syncthreads();
-        // 64 tokens x 64 columns of each operand: 512 16-byte chunks per operand, two per thread
+    // 64 tokens x 64 columns of each operand per step: 512 16-byte chunks per operand, two per thread
+    uint4 ua[2], ub[2];
+    auto gload = [&](long long m0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int qd = tid + 256 * i, row = qd >> 3, ch = (qd & 7) * 8;
             const long long m = m0 + row;
-            uint4 ua = make_uint4(0, 0, 0, 0), ub = make_uint4(0, 0, 0, 0);
+            ua[i] = make_uint4(0, 0, 0, 0); ub[i] = make_uint4(0, 0, 0, 0);
             if (m < m_end) {
-                if (r0 + ch + 8 <= R) ua = *(const uint4*)(a + m * lda + r0 + ch);
-                else ua = ragged_chunk(a + m * lda + r0 + ch, R - (r0 + ch));
-                if (c0 + ch + 8 <= C) ub = *(const uint4*)(b + m * ldb + c0 + ch);
-                else ub = ragged_chunk(b + m * ldb + c0 + ch, C - (c0 + ch));
+                if (r0 + ch + 8 <= R) ua[i] = *(const uint4*)(a + m * lda + r0 + ch);
+                else ua[i] = ragged_chunk(a + m * lda + r0 + ch, R - (r0 + ch));
+                if (c0 + ch + 8 <= C) ub[i] = *(const uint4*)(b + m * ldb + c0 + ch);
+                else ub[i] = ragged_chunk(b + m * ldb + c0 + ch, C - (c0 + ch));
             }
+        }
+    };
+    if (m_begin < m_end) gload(m_begin);
+    for (long long m0 = m_begin; m0 < m_end; m0 += WT_TOK) {
+        __syncthreads();  // every wave is done reading the previous step's tiles
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qd = tid + 256 * i, row = qd >> 3, ch = (qd & 7) * 8;
             uint32_t* pa = (uint32_t*)&sa[row][ch];
             uint32_t* pb = (uint32_t*)&sb[row][ch];
-            pa[0] = ua.x; pa[1] = ua.y; pa[2] = ua.z; pa[3] = ua.w;
-            pb[0] = ub.x; pb[1] = ub.y; pb[2] = ub.z; pb[3] = ub.w;
+            pa[0] = ua[i].x; pa[1] = ua[i].y; pa[2] = ua[i].z; pa[3] = ua[i].w;
+            pb[0] = ub[i].x; pb[1] = ub[i].y; pb[2] = ub[i].z; pb[3] = ub[i].w;
         }
+        if (m0 + WT_TOK < m_end) gload(m0 + WT_TOK);  // next step's loads fly under this step's LDS phase
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {  // 16 tokens per MFMA: this lane's 8 are ks*16 + 8*hi + 0..7
@@ -82,13 +95,29 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict_
     }
 }
 
+// out = alpha * sum over splits, fixed order: thread (o, g) adds the splits k = g, g + 4, g + 8, ... of output o (four loads in
+// flight each), then the four group sums are combined in the order g = 0..3.
 __global__ __launch_bounds__(256) void wgrad_tn_reduce_kernel(const float* __restrict__ ws, int splits, int R, int C, float alpha,
                                                               float* __restrict__ out, int ldo) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)R * C) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(long long)k * R * C + idx];
-    out[(idx / C) * ldo + idx % C] = s * alpha;
+    __shared__ float part[4][64];
+    const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long long RC = (long long)R * C, idx = (long long)blockIdx.x * 64 + o;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < RC) {
+        const float* p = ws + idx;
+        int k = g;
+        for (; k + 12 < splits; k += 16) {
+            const float t0 = p[(long long)k * RC], t1 = p[(long long)(k + 4) * RC], t2 = p[(long long)(k + 8) * RC], t3 = p[(long long)(k + 12) * RC];
+            s0 += t0; s1 += t1; s2 += t2; s3 += t3;
+        }
+        for (; k < splits; k += 4) s0 += p[(long long)k * RC];
+    }
+    part[g][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && idx < RC) {
+        const float s = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+        out[(idx / C) * ldo + idx % C] = s * alpha;
+    }
 }
 
 }  // namespace
@@ -100,8 +129,8 @@ extern "C" int t2v_wgrad_tn(const void* a, int lda, const void* b, int ldb, long
                 "t2v_wgrad_tn: 16-byte aligned operand rows");
     const long long steps = (M + WT_TOK - 1) / WT_TOK;
     const long long tiles = (long long)((R + 63) / 64) * ((C + 63) / 64);
-    if (splits <= 0) {  // fill the chip (~4 workgroups per CU) without making the partial slabs larger than the operands
-        splits = (int)((1024 + tiles - 1) / tiles);
+    if (splits <= 0) {  // about two workgroups per CU: each covers its own load latency, and the partial slabs stay small
+        splits = (int)((512 + tiles - 1) / tiles);
         if (splits > 256) splits = 256;
     }
     if (splits > steps) splits = (int)steps;
@@ -115,7 +144,7 @@ extern "C" int t2v_wgrad_tn(const void* a, int lda, const void* b, int ldb, long
     hipLaunchKernelGGL(wgrad_tn_kernel, dim3((C + 63) / 64, (R + 63) / 64, splits), dim3(256), 0, s, (const bf16_t*)a, lda, (const bf16_t*)b, ldb,
                        M, R, C, tok_per_split, ws);
     T2V_CHECK_LAUNCH();
-    hipLaunchKernelGGL(wgrad_tn_reduce_kernel, dim3((unsigned)(((long long)R * C + 255) / 256)), dim3(256), 0, s, (const float*)ws, splits, R, C,
+    hipLaunchKernelGGL(wgrad_tn_reduce_kernel, dim3((unsigned)(((long long)R * C + 63) / 64)), dim3(256), 0, s, (const float*)ws, splits, R, C,
                        alpha, out, ldo);
     T2V_CHECK_LAUNCH();
     return T2V_OK;

@@ -227,10 +227,20 @@ class _Engine:
 
     # ---- helpers bound to the current recording -------------------------------------------------
     def _begin(self, device):
+        """Start a recording.  Every plan OWNS what its launch list points at (``_own``): the recorded arguments are raw device
+        pointers, so the buffers must outlive the plan, not just the recording (a second input signature used to free the first
+        plan's pool, and going back to the first one replayed into reused memory).  Packed weights are shared by the plans of
+        one weight version (``_check_weights`` drops all plans when a parameter changes)."""
         self.device = device
         self.pool = BufferPool(device)
-        self.pk = Packer(self.adt, device)
+        pk = getattr(self, "pk", None)
+        if not (self.plans and pk is not None and pk.device == device and pk.merge_lora and pk.wdtype == self.adt):
+            self.pk = Packer(self.adt, device)
         self.keep = []
+
+    def _own(self, plan):
+        plan["owned"] = (self.pool, self.pk, self.keep)
+        return plan
 
     def buf(self, rows, cols, dtype=None, zero=False):
         return self.pool.get(rows, cols, dtype or self.adt, zero)
@@ -326,7 +336,7 @@ class UNetEngine(_Engine):
                 if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training:
                     raise RuntimeError("native UNet path is inference-only but a Dropout(p>0) is in training mode: "
                                        "call .eval() on the model (after any LoRA injection) first")
-            plan = self._record(x, timesteps, context, fps, timestep_cond, motion_cond)
+            plan = self._own(self._record(x, timesteps, context, fps, timestep_cond, motion_cond))
             plan["training"] = m.training
             self.plans[key] = plan
         else:

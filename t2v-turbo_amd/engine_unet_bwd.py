@@ -39,9 +39,9 @@ from .unet3d import Downsample, ResBlock, SpatialTransformer, TemporalTransforme
 
 
 class UNetGradEngine(LoraTrainMixin, UNetEngine):
-    # T2V_FLASH_ATTN_BWD=1: spatial self-attention backward by the flash-style kernels of csrc/attention_bwd.hip instead of the
-    # GEMM-formulated one (both unvalidated on hardware; the GEMM form is built from validated kernels and stays the default)
-    flash_attn_bwd = os.environ.get("T2V_FLASH_ATTN_BWD", "0") == "1"
+    # spatial self-attention backward by the flash-style kernels of csrc/attention_bwd.hip (probabilities never in memory);
+    # T2V_FLASH_ATTN_BWD=0 selects the GEMM-formulated one (both validated on MI355X; 342 -> 320 ms per distillation step)
+    flash_attn_bwd = os.environ.get("T2V_FLASH_ATTN_BWD", "1") == "1"
 
     # ---- public: forward with tape, then backward ----------------------------------------------------------------
     def _active_dropouts(self):
@@ -78,7 +78,11 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         if dropping:  # one seed per forward; the backward regenerates the same masks from it
             self._seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
         if plan is None:
-            plan = self._record_grad(x, timesteps, context, fps, timestep_cond, motion_cond, emb_all)
+            if self.training_lora:
+                # the LoRA operand / gradient arenas (engine_lora._lora_begin) are per engine, not per plan: a new input signature
+                # replaces the recorded plan instead of leaving one behind whose launches point into freed arenas
+                self.plans.clear()
+            plan = self._own(self._record_grad(x, timesteps, context, fps, timestep_cond, motion_cond, emb_all))
             self.plans[key] = plan
             if getattr(self.ops, "is_native", False):
                 self._replay(plan, "rec")  # recording ran the backward once and recycled the saved buffers

@@ -25,7 +25,7 @@ class VAEDecodeEngine(_Engine):
         key = (tuple(z.shape), z.dtype, float(scale), z.device)
         plan = self.plans.get(key)
         if plan is None:
-            plan = self._record(z, scale)
+            plan = self._own(self._record(z, scale))
             self.plans[key] = plan
         else:
             plan["static"]["z"].copy_(z)
@@ -169,7 +169,7 @@ class VAEEncodeEngine(VAEDecodeEngine):
         key = ("enc", tuple(x.shape), x.dtype, x.device)
         plan = self.plans.get(key)
         if plan is None:
-            plan = self._record_enc(x)
+            plan = self._own(self._record_enc(x))
             self.plans[key] = plan
         else:
             plan["static"]["x"].copy_(x)

@@ -30,7 +30,7 @@ class VAEDecodeGradEngine(VAEDecodeEngine):
         key = ("grad", tuple(z.shape), z.dtype, float(scale), z.device)
         plan = self.plans.get(key)
         if plan is None:
-            plan = self._record_grad(z, scale)
+            plan = self._own(self._record_grad(z, scale))
             self.plans[key] = plan
             if getattr(self.ops, "is_native", False):
                 # recording executed the backward list once (on a zero gradient) and that recycled the saved forward

@@ -10,6 +10,7 @@
 // Context switches are a dozen instructions of x86-64 assembly (callee-saved registers + stack pointer): glibc's swapcontext
 // makes a sigprocmask system call per switch, and one simulated MFMA is 256 switches.
 #pragma once
+#define T2V_HOSTSIM 1  // sources may leave out what the simulator cannot run (inter-workgroup spin barriers)
 
 #include <algorithm>
 #include <cmath>

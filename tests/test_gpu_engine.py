@@ -310,3 +310,24 @@ def test_ddim_inversion_and_motion_prior_score_on_device():
     assert rel_l2(out.float().cpu(), gg["out"]) < E2E_TOL
     assert torch.isfinite(score).all()
     assert rel_l2(score.float().cpu(), gg["score"]) < 0.15   # bf16 probabilities through a top-1 selection loss (fp32 path: 1e-4, CPU suite)
+
+
+def test_alternating_input_signatures_keep_their_plans():
+    """Two recorded plans of one engine (same weights, different input signature) must both stay replayable: a plan owns the
+    buffers its launch list points at (regression: recording the second plan freed the first one's pool)."""
+    g = load("unet_tiny")
+    m = _unet(tiny_unet_params(), "unet_tiny", torch.bfloat16)
+    m.dtype = torch.bfloat16
+    x, ctx, tc = g["x"].cuda().bfloat16(), g["ctx"].cuda().bfloat16(), g["tc"].cuda().bfloat16()
+    ts = g["ts"].cuda()
+    with torch.no_grad():
+        a0 = m(x, ts, context=ctx, fps=16, timestep_cond=tc)            # plan A (recording)
+        b0 = m(x.float(), ts, context=ctx.float(), fps=16)              # plan B: fp32 inputs, no guidance embedding
+        big = [torch.randn(1 << 22, device="cuda") for _ in range(8)]  # allocator traffic in between
+        a1 = m(x, ts, context=ctx, fps=16, timestep_cond=tc)            # back to plan A (replay)
+        b1 = m(x.float(), ts, context=ctx.float(), fps=16)
+        a2 = m(x, ts, context=ctx, fps=16, timestep_cond=tc)
+    del big
+    assert len(m._engine_box.engine.plans) == 2
+    assert torch.isfinite(a1).all() and torch.equal(a0, a1) and torch.equal(a0, a2) and torch.equal(b0.float(), b1.float())
+    assert rel_l2(a1.float().cpu(), g["y"]) < E2E_TOL

@@ -16,7 +16,7 @@ BF16_TOL = 4e-3
 
 # tile ids every shape may be tuned to, all validated on hardware; T2V_TEST_EXPERIMENTAL_TILES=1 adds the ids that are so
 # far only compile-verified (24: 4-wave 256x256 with 128x128 wave tiles, 25-29: register-staged operand path)
-CFGS = list(range(1, 24)) + (list(range(24, 30)) if os.environ.get("T2V_TEST_EXPERIMENTAL_TILES") == "1" else [])
+CFGS = list(range(1, 24)) + [30, 31, 32, 33] + (list(range(24, 30)) if os.environ.get("T2V_TEST_EXPERIMENTAL_TILES") == "1" else [])
 
 
 def _rt(*shape, seed=0, scale=1.0):
@@ -442,3 +442,44 @@ def test_fill_zero_edges(pair):
         got = buf.cpu()
         assert int(got[off:off + n].max()) == 0
         assert bool((got[:off] == 0x5A).all()) and bool((got[off + n:] == 0x5A).all())
+
+
+@pytest.mark.parametrize("C,c1,units,rows", [(320, 0, 1, 40960), (640, 0, 1, 10240), (1280, 0, 1, 2560), (1280, 0, 1, 640), (320, 0, 16, 2560),
+                                             (640, 320, 16, 640), (2560, 1280, 16, 40), (960, 320, 16, 2560), (64, 0, 3, 50)])
+def test_group_norm_one_launch_form_at_unet_sizes(pair, C, c1, units, rows):
+    """The one-launch GroupNorm (registers hold the tensor, per-unit inter-workgroup barrier) at the sizes the UNet calls it with,
+    against the three-launch form of the same entry point and the emulation; 200 back-to-back calls on alternating inputs (a stale
+    partial or a missed barrier generation shows as a wrong result), bit-identical on re-run, no barrier timeout recorded."""
+    lib = pair.hip.lib
+    c0 = C - c1
+    xs = []
+    for sd, off in ((1, 0.5), (11, -2.0)):
+        x0 = pair.act((_rt(units * rows, c0, seed=sd) * 2.0 + off).bfloat16().float())
+        x1 = pair.act((_rt(units * rows, c1, seed=sd + 1) - off).bfloat16().float()) if c1 else (None, None)
+        xs.append((x0, x1))
+    gamma, beta = pair.f32(_rt(C, seed=3) * 0.1 + 1.0), pair.f32(_rt(C, seed=4) * 0.1)
+    ws = torch.zeros(pair.hip.group_norm_ws_floats(units, rows, 32, C), device="cuda")
+    outs = {}
+    try:
+        for mode in (1, 0):
+            lib.t2v_gn_coop_enable(mode)
+            for k, (x0, x1) in enumerate(xs):
+                o = torch.zeros(units * rows, C, dtype=torch.bfloat16, device="cuda")
+                pair.hip.group_norm(x0[0], x1[0], units, rows, 1e-5, gamma[0], beta[0], True, ws, o)
+                outs[(mode, k)] = o
+        torch.cuda.synchronize()
+        lib.t2v_gn_coop_enable(1)
+        o2 = [torch.zeros_like(outs[(1, 0)]) for _ in range(2)]
+        for it in range(200):
+            k = it & 1
+            pair.hip.group_norm(xs[k][0][0], xs[k][1][0], units, rows, 1e-5, gamma[0], beta[0], True, ws, o2[k])
+        torch.cuda.synchronize()
+    finally:
+        lib.t2v_gn_coop_enable(0)   # the library default (the one-launch form is opt-in: measured slower, norm.hip)
+    assert lib.t2v_gn_coop_error() == 0
+    for k, (x0, x1) in enumerate(xs):
+        ref = torch.zeros(units * rows, C)
+        pair.emu.group_norm(x0[1], x1[1], units, rows, 1e-5, gamma[1], beta[1], True, None, ref)
+        assert rel_l2(outs[(1, k)].float().cpu(), ref) < BF16_TOL
+        assert rel_l2(outs[(0, k)].float().cpu(), ref) < BF16_TOL
+        assert torch.equal(o2[k], outs[(1, k)])

@@ -126,6 +126,8 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+        marker = torch.zeros(64, device=dev)
+        torch.sinh(marker)   # brackets the timed region in a kernel trace (tools/trace_window.py); used nowhere else
         t1 = time.perf_counter()
         for _ in range(a.steps):
             loss, info = step()
@@ -133,6 +135,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t1) / a.steps
+        torch.sinh(marker)
         if rank == 0:
             print(json.dumps({"metric": "v1 distillation steps/sec (student " + ("native gradient engine" if eng is not None else "fwd+bwd torch path")
                               + ", teacher x2 native HIP)", "student_native": eng is not None or bool(a.module_route), "variant": variant or ("module-route" if a.module_route else None),

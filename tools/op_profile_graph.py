@@ -16,8 +16,8 @@ from tools.gemm_profile_graph import graph_time  # noqa: E402
 
 
 def algo_bytes(name, a):
-    if name in ("t2v_gn_stats", "t2v_gn_apply"):
-        return (1 if name == "t2v_gn_stats" else 2) * 2.0 * a[6] * a[7] * (a[1] + a[4])
+    if name in ("t2v_gn_stats", "t2v_gn_apply", "t2v_group_norm"):
+        return {"t2v_gn_stats": 1, "t2v_gn_apply": 2, "t2v_group_norm": 2}[name] * 2.0 * a[6] * a[7] * (a[1] + a[4])
     if name == "t2v_layernorm":
         return 4.0 * a[2] * a[3]
     if name == "t2v_attn_temporal":

@@ -205,6 +205,8 @@ def main():
             ck = "/".join(str(v) for v in key)
             if not args.full and ck in cand_table:
                 cands = [(c, sp) for c, sp in cand_table[ck] if c <= ncfg]
+                if d.M <= 10240:  # tile ids added since the candidate list was written (8-wave small tiles)
+                    cands += [(c, 1) for c in (30, 31, 32, 33) if c <= ncfg and (c, 1) not in cands]
             else:
                 cands = [(c, sp) for c in range(1, ncfg + 1) for sp in splits]
             screened = []
