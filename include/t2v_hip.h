@@ -94,6 +94,15 @@ typedef struct t2v_gemm_desc {
     int tile_cfg, split_k;
     void* ws;
     long long ws_bytes;
+    /* dropout between the product and the residual (0 threshold = off): out = keep ? (alpha*acc + bias) / (1 - p) : 0, then
+     * + rowvec + residual.  The mask is t2v_dropout_bf16's: one splitmix64 word per PAIR of adjacent columns of a
+     * [rows][drop_ncols] matrix in which this launch's output starts at column drop_col0 (both even), low / high 32 bits against
+     * drop_thr = p * 2^32; the 64-bit seed is read from device memory.  LoraInjected*.forward's dropout(up(down(x))) * scale
+     * (utils/lora.py:45-50) as the epilogue of the up-projection.  Not combined with GEGLU / split-K. */
+    const void* drop_seed;
+    unsigned drop_thr, drop_site;
+    float drop_inv_keep;
+    int drop_ncols, drop_col0;
 } t2v_gemm_desc;
 
 int t2v_gemm(const t2v_gemm_desc* d, void* stream);

@@ -54,6 +54,18 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// counter-based dropout bits: one splitmix64 finaliser per PAIR of adjacent columns (low / high 32 bits); shared by
+// t2v_dropout_bf16 (train.hip) and the dropout epilogue of t2v_gemm
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+__device__ __forceinline__ uint64_t dropout_bits(uint64_t seed, uint32_t site, uint64_t pair) {
+    return splitmix64(seed + (uint64_t)site * 0x9E3779B97F4A7C15ull + pair * 0xD1B54A32D192ED03ull);
+}
+
 // host side
 void t2v_set_error(const char* msg);
 const void* t2v_zero_page();  // >= 256 B of device zeros (lazily allocated per process)

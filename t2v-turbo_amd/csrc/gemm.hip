@@ -154,6 +154,19 @@ struct Epi {
                 v[4 * q + 3] *= fast_gelu(gate[4 * q + 3] * al + b.w);
             }
         }
+        if constexpr (!FAST) {  // dropout(alpha * acc + bias) / (1 - p): only the generic kernels carry it (the host keeps launches
+                                // with a dropout threshold off the FAST ones, whose epilogue is sized for the inference step)
+            if (dd.drop_thr) {
+                const uint64_t seed = *(const uint64_t*)dd.drop_seed;
+                const uint64_t pair0 = ((uint64_t)gm * (uint64_t)dd.drop_ncols + (uint64_t)(dd.drop_col0 + ch_out)) >> 1;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint64_t b = dropout_bits(seed, dd.drop_site, pair0 + k);
+                    v[2 * k] = ((uint32_t)b >= dd.drop_thr) ? v[2 * k] * dd.drop_inv_keep : 0.f;
+                    v[2 * k + 1] = ((uint32_t)(b >> 32) >= dd.drop_thr) ? v[2 * k + 1] * dd.drop_inv_keep : 0.f;
+                }
+            }
+        }
         const bool folded_rr = FOLD && !gate;  // rowvec / residual already inside the accumulators
         if (dd.rowvec && !folded_rr) {
             const float* rv = dd.rowvec + (long long)(gm / dd.rowvec_div) * dd.ld_rowvec + ch_out;
@@ -825,7 +838,7 @@ template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM
 int launch(GemmParams& p, hipStream_t s) {
     const int n_out = p.d.act == T2V_ACT_GEGLU ? p.d.N / 2 : p.d.N;
     static const bool no_fast = getenv("T2V_GEMM_NOFAST") != nullptr;  // diagnostics: force the generic epilogue
-    const bool fast = !no_fast && p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1 && p.d.alpha == 1.0f &&
+    const bool fast = !no_fast && !p.d.drop_thr && p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1 && p.d.alpha == 1.0f &&
                       !p.d.out_f32 && (!p.d.rowvec || ((uintptr_t)p.d.rowvec % 16 == 0 && p.d.ld_rowvec % 4 == 0));
     // 128x128 wave tiles keep their 256 accumulator registers in AGPRs and have no room for the generic epilogue's
     // partial-run paths (it spills 2 KiB per lane): shapes that need it run the 8-wave sibling of the same workgroup tile
@@ -997,6 +1010,10 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     T2V_REQUIRE(d.a_stride0 % 8 == 0 && d.a_stride1 % 8 == 0 && d.w_stride0 % 8 == 0 && d.w_stride1 % 8 == 0, T2V_ESHAPE,
                 "t2v_gemm: batch strides must be multiples of 8");
     T2V_REQUIRE(d.batch <= 65535, T2V_ESHAPE, "t2v_gemm: batch too large");
+    if (d.drop_thr)
+        T2V_REQUIRE(d.drop_seed && d.act == T2V_ACT_NONE && d.drop_ncols > 0 && d.drop_ncols % 2 == 0 && d.drop_col0 % 2 == 0 &&
+                        d.drop_col0 >= 0 && d.drop_col0 + d.N <= d.drop_ncols && d.batch == 1,
+                    T2V_EINVAL, "t2v_gemm: dropout epilogue (seed pointer, even column geometry, no activation, no batch)");
     p.nsrc = d.a1 ? 2 : 1;
     p.gh = d.h_in; p.gw = d.w_in;
     p.kh = 3; p.kw = 3; p.stride = 1; p.pad_y = 1; p.pad_x = 1; p.ups = 0;

@@ -686,10 +686,31 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
         return T2V_OK;
     }
 #endif
-    rc = gn_launch_partial(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups, ws, s);
-    if (rc) return rc;
     const int C = c0 + c1, nslab = gn_nslab(C, rows_per_unit, groups), slab_rows = gn_slab_rows(C, rows_per_unit, groups);
     const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / groups));
+    // opt-in: measured neutral on MI355X (2.70 vs 2.67 ms of GroupNorm per UNet step in-graph, 23.69 vs 23.71 ms per step:
+    // the coarser statistics pass of the 40960-row tensors costs what the dropped gn_final launches saved)
+    static const int two_launch = getenv("T2V_GN_TWO_LAUNCH") ? atoi(getenv("T2V_GN_TWO_LAUNCH")) : 0;
+    if (two_launch && nslab > gn_fuse_slabs(groups)) {
+        // Many slabs (the 40960- and 10240-row tensors): the statistics pass walks COARSER slabs — at most gn_fuse_slabs of
+        // them per unit, so that every block of the (fine-grained) apply pass can finish the statistics itself — instead of
+        // paying a third, latency-bound launch (gn_final: 6.6 us + a kernel boundary, 77 times per UNet step).
+        const GnGeom gg = gn_geom(C);
+        const int cap = gn_fuse_slabs(groups);
+        int stat_rows = (rows_per_unit + cap - 1) / cap;
+        stat_rows = (stat_rows + gg.ty * GN_RPT - 1) / (gg.ty * GN_RPT) * (gg.ty * GN_RPT);
+        const int stat_nslab = (rows_per_unit + stat_rows - 1) / stat_rows;
+        hipLaunchKernelGGL(gn_partial_kernel, dim3(stat_nslab, n_units), dim3(256), (size_t)2 * gg.ty * C * sizeof(float), s,
+                           (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, rows_per_unit, groups, stat_rows, ws);
+        T2V_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
+                           ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, stat_nslab,
+                           inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo);
+        T2V_CHECK_LAUNCH();
+        return T2V_OK;
+    }
+    rc = gn_launch_partial(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups, ws, s);
+    if (rc) return rc;
     if (nslab <= gn_fuse_slabs(groups)) {
         hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
                            ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, nslab,

@@ -45,15 +45,7 @@ extern "C" int t2v_gather_f32(const float* src, const int* idx, float alpha, voi
 // and in TemporalConvBlock conv2..4, openaimodel3d.py:280-297).  One splitmix64 finaliser per PAIR of adjacent columns
 // (low / high 32 bits).  out = keep ? x / (1 - p) : 0   (+ resid).  `seed` lives in device memory: a replayed launch list
 // sees the step's seed without being re-recorded.
-__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
-    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
-    z ^= z >> 27; z *= 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return z;
-}
-__device__ __forceinline__ uint64_t dropout_bits(uint64_t seed, uint32_t site, uint64_t pair) {
-    return splitmix64(seed + (uint64_t)site * 0x9E3779B97F4A7C15ull + pair * 0xD1B54A32D192ED03ull);
-}
+// (splitmix64 / dropout_bits: common.h)
 
 template <bool VEC8>
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ resid, int ldr,

@@ -56,6 +56,8 @@ class LoraTrainMixin:
     # the token-contracted weight gradients by t2v_wgrad_tn on the token-major operands (no transposed copies); T2V_TN_WGRAD=0
     # selects t2v_transpose_pad_bf16 + split-K t2v_gemm instead (both validated on MI355X; the step is 313 -> 290 ms with this one)
     tn_wgrad = os.environ.get("T2V_TN_WGRAD", "1") == "1"
+    # the LoRA branch's dropout as the epilogue of its up-projection GEMM (T2V_FUSE_DROPOUT=0: separate t2v_dropout_bf16 pass)
+    fuse_dropout = os.environ.get("T2V_FUSE_DROPOUT", "1") == "1"
 
     # ---- binding ------------------------------------------------------------------------------------------------------
     def bind_lora(self, params):
@@ -116,6 +118,7 @@ class LoraTrainMixin:
         self.src_flat = torch.empty(self.lora_numel + 1, dtype=torch.float32, device=dev)
         self.one_idx = self.lora_numel  # src_flat[-1] == 1: the constant entries of an operand (the selection packs) index it
         self._groups = {}
+        self._packs_key = None
         self._refresh_src()
 
     def _refresh_src(self):
@@ -139,7 +142,13 @@ class LoraTrainMixin:
             self.src_flat[-1] = 1.0
 
     def refresh_lora_packs(self):
-        """Per step: flat parameters -> every bf16 operand layout, one launch."""
+        """Per step: flat parameters -> every bf16 operand layout, one launch.  Skipped while no LoRA tensor has changed since
+        the last refresh (the target and the student forwards of one distillation step share the packs): every in-place update
+        moves a version counter (FlatAdamW.step touches one on purpose), and a re-homed parameter moves its data pointer."""
+        key = (sum(p._version for p in self.lora_params), self.lora_params[0].data_ptr(), self.lora_params[-1].data_ptr())
+        if key == getattr(self, "_packs_key", None):
+            return
+        self._packs_key = key
         self._refresh_src()
         if self.lp_used:
             self.ops.gather(self.src_flat, self.lp_idx[:self.lp_used], self.lp[:self.lp_used])
@@ -288,13 +297,18 @@ class LoraTrainMixin:
         zf = self.buf(m_out, _pad(grp.ntot, 8))
         z = zf[:, :grp.ntot]
         grp.drop = self.drop_site([mm.dropout for mm in grp.mods], kind or (self.row_kind if grp.mode == nt.GEMM_LINEAR else "conv"), kind_meta)
+        # train mode: dropout(up(down(x))) * scale (utils/lora.py:45-50), then the leaf's own residual.  The mask is the
+        # up-projection's own epilogue (t2v_gemm dropout fields) instead of a separate read-modify-write pass over z
+        # (442 launches and 23 GB per student forward); ``fuse_dropout = False`` keeps the two-kernel form (tests compare both).
+        fuse = bool(grp.drop) and self.fuse_dropout and grp.ntot % 2 == 0 and all(n % 2 == 0 for n in grp.N)
         c0 = 0
         for i in range(grp.n):
-            res = None if (residual is None or grp.drop) else residual[:, c0:c0 + grp.N[i]]
+            res = None if (residual is None or (grp.drop and not fuse)) else residual[:, c0:c0 + grp.N[i]]
+            drop = (grp.drop[0], self.seed_t, grp.drop[1], grp.ntot, c0) if fuse else None
             ops.gemm(t[:, i * grp.rp:(i + 1) * grp.rp], grp.Uf[i], z[:, c0:c0 + grp.N[i]], M=m_out, N=grp.N[i],
-                     alpha=grp.scale[i], residual=res)
+                     alpha=grp.scale[i], residual=res, dropout=drop)
             c0 += grp.N[i]
-        if grp.drop:  # train mode: dropout(up(down(x))) * scale (utils/lora.py:45-50), then the leaf's own residual
+        if grp.drop and not fuse:
             ops.dropout(z, None if residual is None else residual[:, :grp.ntot], z, grp.ntot, grp.drop[0], self.seed_t, grp.drop[1])
         self.hold(*x.parts)
         grp.saved = (x, t)

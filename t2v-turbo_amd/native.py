@@ -35,6 +35,8 @@ class GemmDesc(C.Structure):
         ("rowvec_div", C.c_int), ("ld_rowvec", C.c_int), ("residual", C.c_void_p), ("ldr", C.c_int),
         ("act", C.c_int), ("out", C.c_void_p), ("ldo", C.c_int), ("out_f32", C.c_int),
         ("tile_cfg", C.c_int), ("split_k", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_longlong),
+        ("drop_seed", C.c_void_p), ("drop_thr", C.c_uint), ("drop_site", C.c_uint), ("drop_inv_keep", C.c_float),
+        ("drop_ncols", C.c_int), ("drop_col0", C.c_int),
     ]
 
 
@@ -242,7 +244,10 @@ class HipOps:
     # -- ops ----------------------------------------------------------------------------------------
     def gemm(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
              rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
-             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0):
+             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None):
+        """``dropout``: (p, seed tensor [1] int64 on the device, site, ncols, col0) — the mask of ``dropout()`` over a
+        [M, ncols] matrix whose columns col0 .. col0 + N are this launch's output, applied to alpha*acc + bias before the
+        residual (include/t2v_hip.h)."""
         d = GemmDesc()
         d.a0, d.c0, d.lda0 = _p(a0), a0.shape[1], _row_stride(a0)
         if a1 is not None:
@@ -263,10 +268,19 @@ class HipOps:
         d.act = act
         d.out, d.ldo = _p(out), _row_stride(out)
         d.out_f32 = 1 if out.dtype == torch.float32 else 0
+        if dropout is not None and dropout[0] > 0:
+            p_drop, seed_t, site, ncols, col0 = dropout
+            t = float(p_drop) * 4294967296.0
+            d.drop_thr = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
+            d.drop_seed, d.drop_site, d.drop_inv_keep = _p(seed_t), int(site), 1.0 / (1.0 - float(p_drop))
+            d.drop_ncols, d.drop_col0 = int(ncols), int(col0)
+            split_k = 1
         taps = {GEMM_LINEAR: 1, GEMM_TCONV3: 3}.get(mode, 9)
         # a split_k argument without a tile id is a hint (the training engine's token-contracted weight gradients): a tuned entry wins
         tuned = self.tune.get((mode, M, N, taps * (d.c0 + d.c1), batch)) if tile_cfg == 0 else None
         d.tile_cfg, d.split_k = tuned if tuned else (tile_cfg, split_k)
+        if d.drop_thr:
+            d.split_k = 1
         ws = self.workspace(a0.device)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         self._call("t2v_gemm", C.byref(d))  # the byref object holds a reference to d: a recording keeps its descriptors alive

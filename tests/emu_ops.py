@@ -36,7 +36,7 @@ class EmuOps:
     # ------------------------------------------------------------------------------------ gemm
     def gemm(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
              rowvec=None, rowvec_div=0, residual=None, act=nt.ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
-             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0):
+             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None):
         self._log("gemm")
         # device-side argument rules (csrc/gemm.hip, t2v_gemm): operand row strides, batch strides and base addresses
         if self.strict:
@@ -89,6 +89,13 @@ class EmuOps:
             y = y * alpha
             if bias is not None:
                 y = y + bias.float()[None, :N]
+            if dropout is not None and dropout[0] > 0:  # the dropout epilogue of t2v_gemm: the mask of dropout() on its column block
+                p_drop, seed_t, site, ncols, col0 = dropout
+                assert act == nt.ACT_NONE and batch == 1 and ncols % 2 == 0 and col0 % 2 == 0 and col0 + N <= ncols
+                keep = self.dropout_keep(int(seed_t.reshape(-1)[0]), site, M, ncols, p_drop)
+                if getattr(self, "masks", None) is not None:
+                    self.masks[site] = keep
+                y = torch.where(keep[:, col0:col0 + N], y / (1.0 - p_drop), torch.zeros(()))
             if act == nt.ACT_GEGLU:
                 g = y.reshape(M, N // 64, 2, 32)
                 y = (g[:, :, 0] * F.gelu(g[:, :, 1])).reshape(M, N // 2)

@@ -35,7 +35,7 @@ def test_struct_layout_matches_header():
         stmt = stmt.split("{")[-1].strip()
         if not stmt:
             continue
-        names = re.sub(r"^(const\s+)?(void|float|int|long long)\s*\*?", "", stmt)
+        names = re.sub(r"^(const\s+)?(void|float|int|unsigned|long long)\s*\*?", "", stmt)
         fields += [n.strip().lstrip("*") for n in names.split(",")]
     assert fields == [f[0] for f in native.GemmDesc._fields_], fields
 

@@ -301,3 +301,35 @@ def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
     hip.wgrad_tn(_dev(a)[:, :R], _dev(b)[:, :C], o_h[:, :C], alpha=0.5, splits=splits)
     torch.cuda.synchronize()
     assert rel_l2(o_h[:, :C].cpu(), o_e) < 2e-4 and float(o_h[:, C:].min()) == 7.0
+
+
+@pytest.mark.parametrize("M,Ns,p", [(40960, (320,), 0.1), (2560, (1280,), 0.1), (770, (320, 320, 320), 0.1), (100, (4,), 0.5)])
+def test_gemm_dropout_epilogue_is_the_standalone_mask(ops, M, Ns, p):
+    """The LoRA up-projection with its dropout as the GEMM's epilogue (t2v_gemm drop_* fields) against the two-kernel form
+    (t2v_gemm, then t2v_dropout_bf16 with the residual) and the emulation: same mask bit for bit, same values within bf16."""
+    hip, emu = ops
+    K, ntot, site = 64, sum(Ns), 3
+    seed = torch.tensor([0x0BAD_5EED_1234], dtype=torch.int64)
+    a = _rt(M, K, seed=1)
+    ld = (ntot + 7) // 8 * 8
+    res = (_rt(M, ld, seed=9).abs() + 1.0).bfloat16().float()
+    z_f = torch.zeros(M, ld, dtype=torch.bfloat16, device="cuda")
+    z_2 = torch.zeros(M, ld, dtype=torch.bfloat16, device="cuda")
+    z_e = torch.zeros(M, ld)
+    a_d, res_d, seed_d = _dev(a), _dev(res), seed.cuda()
+    c0 = 0
+    for i, N in enumerate(Ns):
+        wt = _rt(max(N, 64), K, seed=2 + i, scale=K ** -0.5)[:N].contiguous()
+        w_d = _dev(wt)
+        drop = (p, seed_d, site, ntot, c0)
+        hip.gemm(a_d, w_d, z_f[:, c0:c0 + N], M=M, N=N, residual=res_d[:, c0:c0 + N], dropout=drop)
+        hip.gemm(a_d, w_d, z_2[:, c0:c0 + N], M=M, N=N)
+        emu.gemm(a, wt, z_e[:, c0:c0 + N], M=M, N=N, residual=res[:, c0:c0 + N], dropout=(p, seed, site, ntot, c0))
+        c0 += N
+    hip.dropout(z_2, res_d[:, :ntot], z_2, ntot, p, seed_d, site)
+    torch.cuda.synchronize()
+    keep = emu.dropout_keep(int(seed[0]), site, M, ntot, p)
+    got, two = z_f.float().cpu()[:, :ntot], z_2.float().cpu()[:, :ntot]
+    assert rel_l2(got, z_e[:, :ntot]) < TOL
+    assert rel_l2(got, two) < TOL                                   # (the fused form skips one bf16 rounding of z)
+    assert torch.equal(got[~keep], res[:, :ntot][~keep]) and torch.equal(two[~keep], res[:, :ntot][~keep])

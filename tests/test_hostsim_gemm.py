@@ -201,3 +201,29 @@ def test_training_step_with_the_real_gemm_kernel_on_the_simulator():
           f"dx {rel_l2(dx, dx_ref):.2e}, LoRA gradients median {float(errs.median()):.2e} max {float(errs.max()):.2e}")
     assert rel_l2(y, y_ref) < 3e-2 and rel_l2(dx, dx_ref) < 6e-2
     assert torch.isfinite(errs).all() and float(errs.median()) < 8e-2 and float(errs.max()) < 0.25
+
+
+@pytest.mark.parametrize("cfg", [1, 4, 9, 18])
+def test_dropout_epilogue_matches_the_standalone_mask(sim, cfg):
+    """t2v_gemm's dropout fields (the LoRA up-projection's epilogue, utils/lora.py:45-50): the mask must be t2v_dropout_bf16's on
+    the launch's column block — zeros exactly where the emulated mask drops, kept values scaled by 1 / (1 - p), residual added
+    behind the mask; two leaves of one group write two column blocks of the same masked matrix."""
+    M, K, p, site = 200, 64, 0.25, 5
+    seed = torch.tensor([0x1234_5678_9ABC], dtype=torch.int64)
+    a = _rt(M, K, seed=1)
+    res = (_rt(M, 320 + 128, seed=9).abs() + 1.0).bfloat16().float()   # strictly positive: dropped positions show as res exactly
+    z_s = torch.zeros(M, 320 + 128, dtype=torch.bfloat16)
+    z_e = torch.zeros(M, 320 + 128)
+    c0 = 0
+    for N, sd in ((320, 2), (128, 3)):
+        wt = _rt(N, K, seed=sd, scale=K ** -0.5)
+        drop = (p, seed, site, 320 + 128, c0)
+        sim.gemm(a.bfloat16(), wt.bfloat16().contiguous(), z_s[:, c0:c0 + N], M=M, N=N, alpha=0.5, residual=res[:, c0:c0 + N].bfloat16(),
+                 tile_cfg=cfg, dropout=drop)
+        EMU.gemm(a, wt, z_e[:, c0:c0 + N], M=M, N=N, alpha=0.5, residual=res[:, c0:c0 + N], dropout=drop)
+        c0 += N
+    keep = EMU.dropout_keep(int(seed[0]), site, M, 320 + 128, p)
+    got = z_s.float()
+    assert rel_l2(got, z_e) < BF16_TOL
+    assert torch.equal(got[~keep], res[~keep])            # dropped: the residual alone, bit for bit
+    assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
