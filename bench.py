@@ -137,18 +137,20 @@ def kernel_breakdown(engine, plan, rec=None):
 
 
 def gemm_traffic():
-    """HBM-side bytes per t2v_gemm launch from the committed PMC passes (profiles/r01_gemm_traffic.json: rocprofv3
+    """HBM-side bytes per t2v_gemm launch from the committed PMC passes (profiles/r0N_gemm_traffic.json: rocprofv3
     --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this same step, gfx950 FETCH_SIZE x2 correction;
     tools/pmc_traffic.py).  Counters cannot be read from inside the timed process, so this is the profile's number,
     labelled as such; null when the profile is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
-    try:
-        with open(path) as f:
-            g = json.load(f)["gemm"]
-        return {"traffic": round(g["hbm_bytes_per_launch"]), "traffic_unit": "bytes per launch (L2-miss side, incl. Infinity-Cache hits)",
-                "traffic_source": "profiles/r01_gemm_traffic.json"}
-    except Exception:
-        return {"traffic": None}
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name in ("r02_gemm_traffic.json", "r01_gemm_traffic.json"):  # the newest committed PMC passes
+        try:
+            with open(os.path.join(here, "profiles", name)) as f:
+                g = json.load(f)["gemm"]
+            return {"traffic": round(g["hbm_bytes_per_launch"]), "traffic_unit": "bytes per launch (L2-miss side, incl. Infinity-Cache hits)",
+                    "traffic_source": "profiles/" + name}
+        except Exception:  # noqa: BLE001
+            continue
+    return {"traffic": None}
 
 
 def log(msg):

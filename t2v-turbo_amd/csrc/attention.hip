@@ -38,7 +38,10 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base)
 // XOR-swizzled by (row>>1)&7, are filled by LDS-DMA (global_load_lds_dwordx4: no staging registers, no
 // ds_write): 16 wave-instructions per tile pair, 4 per wave.  Keys past seq_kv: K rows come from a zero
 // page; the V^T buffer's padding columns must be finite (the engine zero-fills them) since their P is 0.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void attn_spatial_kernel(const bf16_t* __restrict__ q, int ldq,
+#ifndef T2V_ATTN_WPE
+#define T2V_ATTN_WPE 3  // waves per SIMD the register budget is sized for (tools: -DT2V_ATTN_WPE=2 / 4 variants for A/B runs)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WPE, T2V_ATTN_WPE))) void attn_spatial_kernel(const bf16_t* __restrict__ q, int ldq,
                                                            const bf16_t* __restrict__ k, int ldk,
                                                            const bf16_t* __restrict__ vt, int ld_vt, long long vt_img_stride,
                                                            bf16_t* __restrict__ out, int ldo, int seq_q, int seq_kv,

@@ -62,7 +62,15 @@ class FlatGradSync:
 
     def clip_grad_norm_(self, max_norm):
         """Global L2 clip on the (already averaged) flat buffer (accelerator.clip_grad_norm_)."""
-        norm = self.flat.norm(2)
+        if self.flat.is_cuda and self.flat.dtype == torch.float32:  # deterministic two-pass sum of squares (t2v_sumsq), no ATen reduction
+            from .optim import _shared_ops
+            if getattr(self, "_norm_ws", None) is None:
+                self._norm_ws = torch.empty(1025, dtype=torch.float32, device=self.flat.device)
+            with torch.cuda.device(self.flat.device):
+                _shared_ops().sumsq(self.flat, self._norm_ws[:1024], self._norm_ws[1024:])
+            norm = self._norm_ws[1024].sqrt()
+        else:
+            norm = self.flat.norm(2)
         scale = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
         self.flat.mul_(scale)
         return norm

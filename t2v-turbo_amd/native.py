@@ -186,7 +186,7 @@ def on_tensor_device(fn):
 def load_tune_table(path=None):
     """(mode, M, N, K, batch) -> (tile_cfg, split_k), produced on an MI355X by tools/tune_gemm.py."""
     import json
-    path = path or os.path.join(_PKG, "gemm_tune.json")
+    path = path or os.environ.get("T2V_GEMM_TUNE_FILE") or os.path.join(_PKG, "gemm_tune.json")
     if os.environ.get("T2V_GEMM_TUNE", "1") == "0" or not os.path.exists(path):
         return {}
     with open(path) as f:
