@@ -389,7 +389,8 @@ def main():
                     "gbyte_per_step": round(gm["operand_gbyte"], 2), "ms": round(gm["operand_ms"], 3),
                     "tb_per_s": round(gm["operand_gbyte"] / gm["operand_ms"], 2),
                     "what": "tile panels streamed L2 -> LDS: sum over launches of tiles x (BM + BN) x K x 2 bytes / their time; "
-                            "256 CUs x 16 B/clk x 2.4 GHz (one LDS-DMA lane per clock per CU) = 9.8 TB/s"}
+                            "the fill path itself delivers 13.9-17 TB/s by LDS-DMA and 18-29 TB/s register-staged on an L2-resident "
+                            "window (profiles/r02_fill_rate.txt): not the bound"}
             result["kernel_ms"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflop": round(v["tflop"], 3),
                                        **({"gbyte": round(v["gbyte"], 3), "gb_per_s": round(v["gbyte"] / (v["ms"] / 1e3), 1)}
                                           if v.get("gbyte") else {})}
