@@ -92,3 +92,23 @@ def test_motion_rank_loss_and_score():
     context = {"context": ctx, "fps": 16, "timestep_cond": torch.randn(1, 256, generator=torch.Generator().manual_seed(1))}
     score, out = motion_prior.get_motion_prior_score(unet, x.clone(), ts, x * 0.9, context, context, 10.0)
     assert score.shape == x.shape and out.shape == x.shape and float(score.abs().sum()) > 0
+
+
+def test_dataset_reads_the_boolean_spellings_pandas_writes_and_fails_loudly_on_bad_ones(tmp_path):
+    """``use_motion_guide`` as pd.read_csv accepts it (data/mp4_dataset.py:87-154 reads the CSV with pandas): True / False / 1.0 /
+    0 / empty; a value that is no boolean is a schema error and must propagate instead of being resampled away forever."""
+    os.makedirs(tmp_path / "lat")
+    with open(tmp_path / "lat" / "a.pkl", "wb") as f:
+        f.write(latent_io.pack_latent_record(**_record(), text="a cat"))
+    rows = [("True", True), ("False", False), ("1.0", True), ("0", False), ("", True), ("true", True)]
+    with open(tmp_path / "meta.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["relpath", "text", "use_motion_guide", "short_text"])
+        for v, _ in rows:
+            w.writerow(["a.pkl", "a cat", v, "cat"])
+        w.writerow(["a.pkl", "a cat", "maybe", "cat"])
+    ds = latent_io.LatentRecordDataset(str(tmp_path / "meta.csv"), latent_root="lat", root_dir=str(tmp_path))
+    for i, (_, want) in enumerate(rows):
+        assert ds[i]["use_motion_guide"] is want
+    with pytest.raises(ValueError):
+        ds[len(rows)]

@@ -73,3 +73,37 @@ def test_bad_args_raise():
     g = load("unet_tiny_mg_b2")
     with pytest.raises(AssertionError):  # motion_cond without timestep_cond (openaimodel3d.py:691)
         m(g["x"], g["ts"], context=g["ctx"], motion_cond=g["mc"])
+
+
+def test_auto_route_decisions():
+    """``UNetModel._auto_route`` (what a CUDA call lands on under ``native_mode = "auto"``): inference engine for no-grad eval
+    calls, gradient engine for a LoRA student (grad or not, train or eval), torch composite — named reason — for the rest."""
+    import warnings
+    from t2v_turbo_amd import lora, unet3d
+    from tests.util import tiny_unet_params
+    m = unet3d.UNetModel(**tiny_unet_params()).eval()
+    x, ctx, tc = torch.zeros(1, 4, 4, 8, 8), torch.zeros(1, 7, 128), torch.zeros(1, 256)
+    with torch.no_grad():
+        assert m._auto_route(x, ctx, tc, None) == ("infer", None)
+    assert m._auto_route(x, ctx, tc, None)[0] == "composite"          # every parameter trainable: full fine-tuning
+    m.requires_grad_(False)
+    assert m._auto_route(x, ctx, tc, None) == ("infer", None)          # nothing wants a gradient
+    assert m._auto_route(x.clone().requires_grad_(True), ctx, tc, None)[0] == "composite"   # input gradient without LoRA
+    m.train()
+    with torch.no_grad():
+        assert m._auto_route(x, ctx, tc, None)[0] == "composite"      # train-mode dropout (temporal convs), no LoRA: e.g. the v1 teacher
+    m.eval()
+    lora.inject_trainable_lora_extended(m, r=4)
+    m.train()
+    assert m._auto_route(x, ctx, tc, None) == ("train", None)          # the student forward
+    with torch.no_grad():
+        assert m._auto_route(x, ctx, tc, None) == ("train", None)      # the target forward (train mode, no grad)
+    assert m._auto_route(x, ctx.clone().requires_grad_(True), tc, None)[0] == "composite"
+    next(p for n, p in m.named_parameters() if "lora" not in n).requires_grad_(True)
+    assert m._auto_route(x, ctx, tc, None)[0] == "composite"          # a base weight trainable besides the LoRA tensors
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        unet3d._WARNED_ATEN.discard("test reason")
+        unet3d._warn_aten_route("test reason")
+        unet3d._warn_aten_route("test reason")
+    assert len([x for x in w if "ATen" in str(x.message)]) == 1        # once per reason
