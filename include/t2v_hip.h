@@ -229,7 +229,7 @@ int t2v_sumpool2x2(const void* in, int n_img, int h, int w, int C, void* out, vo
  * temporal attention probabilities: motion_prior_sample.py:59-84 (autograd.grad(loss, latents)) and the data half of the
  * student's backward (train_t2v_turbo_v1_lora.py:1190).  Convolution / linear / spatial-attention gradients are t2v_gemm
  * launches; these are the rest.  STATUS: written after the round's GPU budget was spent - the engine's dataflow is verified on
- * CPU against autograd with an emulation of exactly these semantics, the kernels themselves have not run on hardware yet.
+ * CPU against autograd with an emulation of exactly these semantics, and on MI355X against the emulation and autograd (tests/test_gpu_unet_grad.py).
  * t2v_gn_bwd2: t2v_gn_bwd over a virtual channel concat [x0 | x1] (the skip connections), up to 4096 channels.
  * t2v_layernorm_bwd: dx = d/dx LayerNorm(x) . dy (+ resid); statistics recomputed per row (attention.py:279-281).
  * t2v_geglu_fwd / _bwd: h = packed pre-activation [M][2*inner] in 64-column groups [32 value | 32 gate] (the layout

@@ -10,7 +10,7 @@
 //                 dS = P (dP - D_i), dK^T += Q^T dS.
 //
 // Operands the caller provides next to the token-major rows: K^T, Q^T and dO^T per image ([heads*64][padded sequence], the
-// layout of the forward's V^T buffer; t2v_transpose_pad_bf16 makes them).  NOT yet run on hardware: verified on the host SIMT
+// layout of the forward's V^T buffer; t2v_transpose_pad_bf16 makes them).  Validated on MI355X (tests/test_gpu_unet_grad.py); also runs on the host SIMT
 // simulator (tests/test_hostsim_attention_bwd.py) against the emulated backend; single-buffered LDS tiles (correctness first).
 #include "common.h"
 

@@ -1,5 +1,5 @@
 // Backward (dX) kernels of the UNet data-gradient path (engine_unet_bwd.py; include/t2v_hip.h "backward (dX) pieces of the UNet").
-// NOT yet run on hardware: written after the round's GPU budget was spent.  Executed thread by thread on the host SIMT simulator
+// Written in round 1 after its GPU budget was spent, validated on MI355X in round 2 (tests/test_gpu_unet_grad.py).  Also executed thread by thread on the host SIMT simulator
 // (tests/hostsim, tests/test_hostsim_kernels.py) against the emulated backend's definitions (tests/emu_ops.py).  Kept in a translation unit of their own so that the validated kernels of backward.hip
 // compile to exactly the code that ran (adding kernels to that file changed the code generated for gn_bwd_apply_kernel).
 #include "common.h"
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void gn_bwd2_apply_kernel(const bf16_t* x, int
     }
 }
 
-// ---- UNet data-gradient pieces (engine_unet_bwd.py).  NOT yet run on hardware (see the file header); run on the host SIMT
+// ---- UNet data-gradient pieces (engine_unet_bwd.py).  validated on MI355X (see the file header); also run on the host SIMT
 // simulator against the emulated backend's definitions (tests/emu_ops.py). -------------------------------------------------
 
 // dx = d/dx LayerNorm(x) . dy (+ resid): one wave per row, the row in registers (NJ 16-byte chunks per lane)

@@ -943,7 +943,7 @@ const TileCfg kCfg[] = {{0, 0, 0},      {128, 128, 64}, {128, 64, 32},  {256, 64
                         // activation panel read once instead of once per N tile (wtn = 32 here just keeps GEGLU off it)
                         {160, 320, 32, 64}, {160, 320, 32, 32},
                         // 256x256 on FOUR waves, wave tile 128x128 (accumulators in AGPRs): half the LDS fragment bytes per
-                        // MFMA of the 8-wave 256x256 tiles.  Compiles with a spill-free main loop; NOT yet run on hardware
+                        // MFMA of the 8-wave 256x256 tiles.  Compiles with a spill-free main loop; correct on MI355X and slower than the 8-wave tiles on every UNet shape (round 2)
                         // (added after the round's GPU budget was spent) - the tuned table never selects it.
                         {256, 256, 128, 32},
                         // register-staged twins (global -> VGPR -> ds_write_b128, two-slot ring) of 6, 1, 20, 23 and 17: the

@@ -23,7 +23,8 @@ engine hands back d(loss)/d(emb_all), column sums of the ResBlock gradients take
 row.  A train-mode student's dropouts (LoRA branch, temporal conv blocks) are counter-based masks (``t2v_dropout_bf16``):
 a function of (step seed, site, element), applied in the forward and regenerated in the backward — not torch's random stream.
 
-Status: dataflow verified on CPU against torch autograd (tests/test_unet_lora_grad_cpu.py); not yet run on hardware."""
+Status: dataflow verified on CPU against torch autograd (tests/test_unet_lora_grad_cpu.py) and on MI355X against autograd and the
+reference's own LoRA gradients (tests/test_gpu_unet_grad.py)."""
 import os
 
 import torch

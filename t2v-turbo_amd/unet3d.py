@@ -366,6 +366,23 @@ def _warn_aten_route(why):
                       'set native_mode = "off" to silence, see INTEGRATION.md', RuntimeWarning, stacklevel=3)
 
 
+def _flat_grad_buffer(eng, leaves):
+    """The flat fp32 gradient buffer the LoRA tensors' ``.grad`` slots are views of (``dist.FlatGradSync`` built from
+    ``lora.lora_parameters``: same order and offsets as ``bind_lora``), or None if the gradients do not live that way."""
+    first = eng.lora_params[0].grad
+    if first is None or first.dtype != torch.float32 or not first.is_contiguous():
+        return None
+    base = first.data_ptr() - 4 * eng.lora_off[id(eng.lora_params[0])]
+    for p in eng.lora_params:
+        g = p.grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() != base + 4 * eng.lora_off[id(p)]:
+            return None
+    off0 = first.storage_offset() - eng.lora_off[id(eng.lora_params[0])]
+    if off0 < 0 or first.untyped_storage().nbytes() < 4 * (off0 + eng.lora_numel):
+        return None
+    return torch.as_strided(first, (eng.lora_numel,), (1,), off0)
+
+
 class _NativeStudent(torch.autograd.Function):
     """UNet forward whose backward — d/d(latents), d/d(emb_all) and every token-row LoRA weight gradient — runs on the native
     gradient engine.  Inputs: latents, the conditioning branch's output (torch keeps differentiating behind it), and the
@@ -388,6 +405,12 @@ class _NativeStudent(torch.autograd.Function):
             raise RuntimeError("native student: another grad-mode forward of the same shape ran before this backward "
                                "(the engine keeps one outstanding tape per input shape)")
         eng._last = ctx.plan
+        flat = _flat_grad_buffer(eng, ctx.leaves)
+        if flat is not None:
+            # every LoRA tensor's .grad is already its slot of ONE flat fp32 buffer in bind_lora order (dist.FlatGradSync): the engine
+            # adds its weight gradients there in one launch — what 1096 AccumulateGrad nodes would do with 1096 small kernels
+            dx = eng.backward(dout, flat_grad=flat, accumulate=True)
+            return (dx.to(ctx.x_dtype), eng.d_emb_all.to(ctx.e_dtype).clone(), None, None, *([None] * len(ctx.leaves)))
         flat = torch.empty(eng.lora_numel, dtype=torch.float32, device=dout.device)  # fresh: .grad may keep views of it
         dx = eng.backward(dout, flat_grad=flat, accumulate=False)
         grads = []

@@ -1,4 +1,4 @@
-"""Flash-style spatial-attention backward (csrc/attention_bwd.hip, not yet run on hardware) on the host SIMT simulator against the
+"""Flash-style spatial-attention backward (csrc/attention_bwd.hip; hardware-validated since round 2) on the host SIMT simulator against the
 emulated definition: tile tails in both sequences, several heads / images, V from the token-major buffer and from the per-head
 [keys][64] layout."""
 import os
