@@ -103,6 +103,15 @@ typedef struct t2v_gemm_desc {
     unsigned drop_thr, drop_site;
     float drop_inv_keep;
     int drop_ncols, drop_col0;
+    /* LayerNorm second output (NULL = off): ln_out[m][n] = (out[m][n] - mean_m) * rstd_m * ln_gamma[n] + ln_beta[n] over the N
+     * columns of the row (fp32 statistics on the fp32 epilogue values, two-pass), bf16 [M][ld_ln_out].  The pre-LN residual
+     * stream and its LayerNorm (BasicTransformerBlock._forward, attention.py:300-311) from one launch.  N == 320 only (the
+     * 160x320 workgroup tile holds whole rows); no batch, no activation, bf16 out, alpha == 1. */
+    const float* ln_gamma;
+    const float* ln_beta;
+    float ln_eps;
+    void* ln_out;
+    int ld_ln_out;
 } t2v_gemm_desc;
 
 int t2v_gemm(const t2v_gemm_desc* d, void* stream);

@@ -274,7 +274,10 @@ constexpr int gemm_smem_bytes() {  // (the same for the DMA-staged and the regis
 // sized for (2 x 4-wave workgroups or one 8-wave workgroup per CU at WPE = 2)
 // RS ("register-staged", experimental): operands travel global -> VGPR -> ds_write_b128 -> LDS instead of by LDS-DMA.  One
 // register set per wave holds the NEXT K step while the current one is computed; the LDS ring has exactly two slots.
-template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4, bool FAST = false, bool RS = false>
+// LNOUT (FAST kernels whose workgroup tile spans the whole row, i.e. the 160x320 tiles at N = 320): the epilogue also writes
+// LayerNorm(out) * gamma + beta to a second tensor — the transformer blocks' LayerNorms (attention.py:300-311) as a by-product
+// of the GEMM that produces their input, instead of 60 read-modify-write launches per UNet step.
+template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4, bool FAST = false, bool RS = false, bool LNOUT = false>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void gemm_kernel(const GemmParams p) {
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -726,6 +729,66 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
             return;
         }
         epi.n_out = d.N;
+        if constexpr (LNOUT) {
+            static_assert(FAST && TM == 1 && WN == 2, "LNOUT: one 32-row MFMA tile row per wave, two waves per output row");
+            // (host-checked: one N tile, i.e. BN == N, no batch, no activation)
+            const int gm = m0 + wave_m * WTM + frow;
+            float vals[TN][16];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) vals[j][e] = acc[0][j][e];
+                if (gm < d.M) epi.template compute<true>(vals[j], nullptr, gm, ch_lane + j * 32, ch_lane + j * 32);
+                *(uint4*)(st_w + j * 64) = pack8(vals[j]);
+                *(uint4*)(st_w + j * 64 + 16) = pack8(vals[j] + 8);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            flush_slab<P, TN * 4>(st, lane, obase, d.ldo, m0 + wave_m * WTM, d.M, n0 + wave_n * WTN, d.N);
+            // row statistics over the BN columns: this lane's TN*16 values, its partner lane (other 16-channel half of every
+            // 32-column tile: lane ^ 32) and the partner wave (the other WTN columns: wave ^ 1); two-pass (mean, then centred)
+            float* xch = (float*)(smem + NW * 32 * P);  // [2][NW][32] floats behind the slabs
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) sum += vals[j][e];
+            sum += __shfl_xor(sum, 32, 64);
+            if (hi == 0) xch[wave * 32 + frow] = sum;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const float mean = (sum + xch[(wave ^ 1) * 32 + frow]) * (1.0f / (float)BN);
+            float sq = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const float dl = vals[j][e] - mean; sq += dl * dl; }
+            sq += __shfl_xor(sq, 32, 64);
+            if (hi == 0) xch[NW * 32 + wave * 32 + frow] = sq;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const float rstd = rsqrtf((sq + xch[NW * 32 + (wave ^ 1) * 32 + frow]) * (1.0f / (float)BN) + d.ln_eps);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ch = ch_lane + j * 32;
+                float o[16];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 g4 = *(const float4*)(d.ln_gamma + ch + 4 * q4), b4 = *(const float4*)(d.ln_beta + ch + 4 * q4);
+                    o[4 * q4] = (vals[j][4 * q4] - mean) * rstd * g4.x + b4.x;
+                    o[4 * q4 + 1] = (vals[j][4 * q4 + 1] - mean) * rstd * g4.y + b4.y;
+                    o[4 * q4 + 2] = (vals[j][4 * q4 + 2] - mean) * rstd * g4.z + b4.z;
+                    o[4 * q4 + 3] = (vals[j][4 * q4 + 3] - mean) * rstd * g4.w + b4.w;
+                }
+                *(uint4*)(st_w + j * 64) = pack8(o);
+                *(uint4*)(st_w + j * 64 + 16) = pack8(o + 8);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            flush_slab<P, TN * 4>(st, lane, (bf16_t*)d.ln_out, d.ld_ln_out, m0 + wave_m * WTM, d.M, n0 + wave_n * WTN, d.N);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int gm = m0 + wave_m * WTM + i * 32 + frow;
@@ -831,7 +894,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     epi.run(v, nullptr, gm, ch, ch);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST, bool RS = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST, bool RS = false, bool LNOUT = false>
 int launch_impl(GemmParams& p, hipStream_t s);
 
 template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4, bool RS = false>
@@ -849,7 +912,7 @@ int launch(GemmParams& p, hipStream_t s) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST, bool RS>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST, bool RS, bool LNOUT>
 int launch_impl(GemmParams& p, hipStream_t s) {
     p.tiles_m = (p.d.M + BM - 1) / BM;
     p.tiles_n = (p.d.N + BN - 1) / BN;
@@ -880,13 +943,16 @@ int launch_impl(GemmParams& p, hipStream_t s) {
         for (int i = p.nblk; i < 8; ++i) { p.blk_start[i] = 1 << 30; p.blk_r0[i] = 0; p.blk_c0[i] = 0; p.blk_w[i] = 1; }
     }
     dim3 grid(p.tiles_m * p.tiles_n, p.d.batch, p.splits);
-    constexpr int smem = gemm_smem_bytes<BM, BN, WM, WN, STAGES, BK, FAST>();
+    // LNOUT: the row-statistics exchange area ([2][waves][32] floats) sits behind the epilogue slabs
+    constexpr int slab_end = WM * WN * 32 * ((BN / WN) * 2 + 16);
+    constexpr int base_smem = gemm_smem_bytes<BM, BN, WM, WN, STAGES, BK, FAST>();
+    constexpr int smem = LNOUT ? (base_smem > slab_end + 2 * WM * WN * 32 * 4 ? base_smem : slab_end + 2 * WM * WN * 32 * 4) : base_smem;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST, RS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST, RS, LNOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST, RS>), grid, dim3(WM * WN * 64), smem, s, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST, RS, LNOUT>), grid, dim3(WM * WN * 64), smem, s, p);
     T2V_CHECK_LAUNCH();
     if (p.splits > 1) {
         const long long work = (long long)p.d.M * ((p.d.N + 15) / 16);
@@ -903,7 +969,12 @@ int launch_impl(GemmParams& p, hipStream_t s) {
 // unit the 256x128 / 4-waves-per-SIMD kernel picked up a scratch reload inside its K loop), and the validated ids' code
 // should be exactly what ran on hardware.
 int t2v_gemm_launch_experimental(int cfg, GemmParams& p, hipStream_t s);
+int t2v_gemm_launch_ln(int cfg, GemmParams& p, hipStream_t s);  // the 160x320 tile (id 23) with the LayerNorm second output
 #ifdef T2V_GEMM_EXP_ONLY
+int t2v_gemm_launch_ln(int cfg, GemmParams& p, hipStream_t s) {  // tile id 23 only (its 64-deep twin, id 22, spills 22 registers with the extra epilogue)
+    (void)cfg;
+    return launch_impl<160, 320, 5, 2, 3, 32, 3, true, false, true>(p, s);
+}
 int t2v_gemm_launch_experimental(int cfg, GemmParams& p, hipStream_t s) {
     switch (cfg) {
         case 24: return launch<256, 256, 2, 2, 3, 32, 1>(p, s);
@@ -1085,6 +1156,17 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     p.splits = splits;
     p.ws = (float*)d.ws;
     p.debug = g_debug;
+    if (d.ln_out) {  // LayerNorm second output: only the full-row 160x320 FAST kernels carry it
+        cfg = 23;
+        p.nk = p.K / kCfg[cfg].bk;
+        p.splits = 1; p.nk_per_split = p.nk;
+        const bool fast = p.vec4 && d.N % 16 == 0 && d.alpha == 1.0f && !d.out_f32 && !d.drop_thr &&
+                          (!d.rowvec || ((uintptr_t)d.rowvec % 16 == 0 && d.ld_rowvec % 4 == 0));
+        T2V_REQUIRE(d.N == 320 && d.batch == 1 && d.act == T2V_ACT_NONE && fast && d.ln_gamma && d.ln_beta && d.ld_ln_out % 8 == 0 &&
+                        (uintptr_t)d.ln_out % 16 == 0 && (uintptr_t)d.ln_gamma % 16 == 0 && (uintptr_t)d.ln_beta % 16 == 0,
+                    T2V_ESHAPE, "t2v_gemm: the LayerNorm output needs N == 320, bf16 out, alpha 1, aligned operands, no batch / activation");
+        return t2v_gemm_launch_ln(cfg, p, s);
+    }
     return dispatch(cfg, p, s);
 }
 #endif  // T2V_GEMM_EXP_ONLY

@@ -257,13 +257,27 @@ class _Engine:
         self.pool.put(ws)
         return out
 
-    def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None):
+    def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None, ln=None):
+        """``ln``: (LayerNorm module, destination buffer) — LayerNorm(out) as a second output of the same launch (t2v_gemm ln_*
+        fields; N == 320 only, see ``ln_fusable``)."""
         w = self.pk.mat(mod) if w is None else w
         bias = self.pk.bias(mod) if isinstance(bias, str) else bias
         N = w.shape[0] if N is None else N
         out = self.buf(a.shape[0], N // 2 if act == nt.ACT_GEGLU else N, out_dtype)
-        self.ops.gemm(a, w, out, M=a.shape[0], N=N, bias=bias, residual=residual, act=act)
+        if ln is not None:
+            norm, dst = ln
+            ln = (self.pk.f32(norm.weight), self.pk.f32(norm.bias), norm.eps, dst)
+        self.ops.gemm(a, w, out, M=a.shape[0], N=N, bias=bias, residual=residual, act=act, **({"ln": ln} if ln is not None else {}))
         return out
+
+    # LayerNorm as a by-product of the GEMM that produces its input (T2V_FUSE_LN=0: separate t2v_layernorm launches)
+    fuse_ln = os.environ.get("T2V_FUSE_LN", "1") == "1"
+
+    def ln_fusable(self, C, norm):
+        """The 160x320 workgroup tile holds whole rows only at N = 320 (the full-resolution level: 60 of the 99 LayerNorms).  A
+        non-native (emulated) backend takes the fused form at every width, so that the CPU suite covers the dataflow."""
+        wide_ok = C == 320 or not getattr(self.ops, "is_native", False)
+        return self.fuse_ln and wide_ok and tuple(norm.normalized_shape) == (C,) and norm.elementwise_affine
 
     def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto"):
         """3x3 / strided / upsampled / temporal conv of an Act (virtual concat allowed); ``w`` / ``bias`` override the
@@ -566,8 +580,9 @@ class UNetEngine(_Engine):
         if attn.dim_head != 64:
             raise nt.NativeError(f"native attention kernels need dim_head == 64 (got {attn.dim_head})")
 
-    def transformer_block(self, blk, y, x_geom, temporal):
-        """BasicTransformerBlock on token rows y [M, C] (attention.py:300-311)."""
+    def transformer_block(self, blk, y, x_geom, temporal, ln1=None):
+        """BasicTransformerBlock on token rows y [M, C] (attention.py:300-311).  ``ln1``: norm1(y) if the GEMM that produced y
+        already wrote it (the buffer then serves the block's other two LayerNorms as well)."""
         ops, pk = self.ops, self.pk
         B, F = self.B, self.F
         M, C = y.shape
@@ -575,7 +590,8 @@ class UNetEngine(_Engine):
         a1, a2 = blk.attn1, blk.attn2
         self._check_heads(a1)
         inner = a1.heads * a1.dim_head
-        ln = self.buf(M, C)
+        ln = self.buf(M, C) if ln1 is None else ln1
+        fuse2, fuse3 = self.ln_fusable(C, blk.norm2), self.ln_fusable(C, blk.norm3)
 
         def lnorm(norm, src):
             ops.layernorm(src, pk.f32(norm.weight), pk.f32(norm.bias), norm.eps, ln)
@@ -615,18 +631,19 @@ class UNetEngine(_Engine):
             self.pool.put(q)
             return o
 
-        # attn1: self attention (spatial or temporal)
-        src = lnorm(blk.norm1, y)
+        # attn1: self attention (spatial or temporal).  Every consumer of a LayerNorm output has been launched before the next
+        # producer overwrites the shared buffer (stream order), fused or not.
+        src = ln if ln1 is not None else lnorm(blk.norm1, y)
         o = temporal_attn(a1, src) if temporal else spatial_self_attn(a1, src)
-        y1 = self.linear(o, a1.to_out[0], residual=y)
+        y1 = self.linear(o, a1.to_out[0], residual=y, ln=(blk.norm2, ln) if fuse2 else None)
         self.pool.put(o)
         # attn2: temporal self attention again, or text cross attention
-        src = lnorm(blk.norm2, y1)
+        src = ln if fuse2 else lnorm(blk.norm2, y1)
         o = temporal_attn(a2, src) if temporal else cross_attn(a2, src)
-        y2 = self.linear(o, a2.to_out[0], residual=y1)
+        y2 = self.linear(o, a2.to_out[0], residual=y1, ln=(blk.norm3, ln) if fuse3 else None)
         self.pool.put(o, y1)
         # GEGLU feed-forward
-        src = lnorm(blk.norm3, y2)
+        src = ln if fuse3 else lnorm(blk.norm3, y2)
         proj = blk.ff.net[0]
         assert hasattr(proj, "proj"), "non-gated FeedForward is not built by the VideoCrafter2 config"
         wg, bg = pk.geglu(proj.proj)
@@ -635,14 +652,25 @@ class UNetEngine(_Engine):
         self.pool.put(g, y2, ln)
         return y3
 
+    def _proj_in_with_ln(self, t, proj_in, blocks):
+        """proj_in (a Linear: use_linear=True) and, where the tile holds whole rows, norm1 of the first block from the same launch."""
+        blk0 = blocks[0] if len(blocks) else None
+        C = leaf_out_channels(proj_in)
+        is_linear = isinstance(proj_in, nn.Linear) or isinstance(getattr(proj_in, "linear", None), nn.Linear)  # (or LoRA-injected)
+        if blk0 is not None and is_linear and self.ln_fusable(C, blk0.norm1):
+            ln1 = self.buf(t.shape[0], C)
+            return self.linear(t, proj_in, ln=(blk0.norm1, ln1)), ln1
+        return self.linear(t, proj_in), None
+
     def spatial_transformer(self, st, x):
         B, F = self.B, self.F
         hw = x.h * x.w
         t = self.gn(x, st.norm, B * F, hw, False)
-        y = self.linear(t, st.proj_in)
+        y, ln1 = self._proj_in_with_ln(t, st.proj_in, st.transformer_blocks)
         self.pool.put(t)
         for blk in st.transformer_blocks:
-            ny = self.transformer_block(blk, y, (x.n_img, hw), temporal=False)
+            ny = self.transformer_block(blk, y, (x.n_img, hw), temporal=False, ln1=ln1)
+            ln1 = None
             self.pool.put(y)
             y = ny
         out = self.linear(y, st.proj_out, residual=x.t)
@@ -653,10 +681,11 @@ class UNetEngine(_Engine):
         B, F = self.B, self.F
         hw = x.h * x.w
         t = self.gn(x, tt.norm, B, F * hw, False)
-        y = self.linear(t, tt.proj_in)
+        y, ln1 = self._proj_in_with_ln(t, tt.proj_in, tt.transformer_blocks)
         self.pool.put(t)
         for blk in tt.transformer_blocks:
-            ny = self.transformer_block(blk, y, (x.n_img, hw), temporal=True)
+            ny = self.transformer_block(blk, y, (x.n_img, hw), temporal=True, ln1=ln1)
+            ln1 = None
             self.pool.put(y)
             y = ny
         out = self.linear(y, tt.proj_out, residual=x.t)

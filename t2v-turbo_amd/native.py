@@ -37,6 +37,7 @@ class GemmDesc(C.Structure):
         ("tile_cfg", C.c_int), ("split_k", C.c_int), ("ws", C.c_void_p), ("ws_bytes", C.c_longlong),
         ("drop_seed", C.c_void_p), ("drop_thr", C.c_uint), ("drop_site", C.c_uint), ("drop_inv_keep", C.c_float),
         ("drop_ncols", C.c_int), ("drop_col0", C.c_int),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p), ("ld_ln_out", C.c_int),
     ]
 
 
@@ -244,7 +245,7 @@ class HipOps:
     # -- ops ----------------------------------------------------------------------------------------
     def gemm(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
              rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
-             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None):
+             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None, ln=None):
         """``dropout``: (p, seed tensor [1] int64 on the device, site, ncols, col0) — the mask of ``dropout()`` over a
         [M, ncols] matrix whose columns col0 .. col0 + N are this launch's output, applied to alpha*acc + bias before the
         residual (include/t2v_hip.h)."""
@@ -281,6 +282,9 @@ class HipOps:
         d.tile_cfg, d.split_k = tuned if tuned else (tile_cfg, split_k)
         if d.drop_thr:
             d.split_k = 1
+        if ln is not None:  # (gamma fp32 [N], beta fp32 [N], eps, out2 bf16 [M, N]): LayerNorm(out) as a second output (N == 320)
+            gamma, beta, eps, out2 = ln
+            d.ln_gamma, d.ln_beta, d.ln_eps, d.ln_out, d.ld_ln_out = _p(gamma), _p(beta), float(eps), _p(out2), _row_stride(out2)
         ws = self.workspace(a0.device)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         self._call("t2v_gemm", C.byref(d))  # the byref object holds a reference to d: a recording keeps its descriptors alive

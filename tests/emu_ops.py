@@ -36,8 +36,10 @@ class EmuOps:
     # ------------------------------------------------------------------------------------ gemm
     def gemm(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
              rowvec=None, rowvec_div=0, residual=None, act=nt.ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
-             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None):
+             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None, ln=None):
         self._log("gemm")
+        if ln is not None:
+            assert batch == 1 and act == nt.ACT_NONE and alpha == 1.0, "LN output: no batch / activation / alpha (the device kernel: N == 320)"
         # device-side argument rules (csrc/gemm.hip, t2v_gemm): operand row strides, batch strides and base addresses
         if self.strict:
             assert a0.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and (a1 is None or a1.stride(0) % 8 == 0), "lda/ldw % 8"
@@ -107,6 +109,9 @@ class EmuOps:
             if act == nt.ACT_SILU:
                 y = F.silu(y)
             _strided(out, M, n_out, out.stride(0), o_off).copy_(y.to(out.dtype))
+            if ln is not None:  # LayerNorm of the fp32 epilogue values (before they are rounded to the output dtype), second output
+                gamma, beta, eps, out2 = ln
+                out2[:, :N] = F.layer_norm(y, (N,), gamma.float(), beta.float(), eps).to(out2.dtype)
 
     def conv_small(self, x, n_img, h, w, wgt, bias, out):
         self._log("conv_small")

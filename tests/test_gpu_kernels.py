@@ -483,3 +483,30 @@ def test_group_norm_one_launch_form_at_unet_sizes(pair, C, c1, units, rows):
         assert rel_l2(outs[(1, k)].float().cpu(), ref) < BF16_TOL
         assert rel_l2(outs[(0, k)].float().cpu(), ref) < BF16_TOL
         assert torch.equal(o2[k], outs[(1, k)])
+
+
+@pytest.mark.parametrize("M,K,res", [(40960, 320, True), (320, 320, False), (1000, 1280, True)])
+def test_gemm_layernorm_second_output(pair, M, K, res):
+    """t2v_gemm ln_* fields on the 160x320 tile: main output bit-identical to the plain launch of the same tile, LayerNorm output
+    against the emulation (LN of the fp32 epilogue values) and against t2v_layernorm of the bf16 main output; residual stream with
+    |mean| >> std; M not a multiple of the tile."""
+    N = 320
+    a = pair.act(_rt(M, K, seed=1))
+    wt = pair.act(_rt(N, K, seed=2, scale=K ** -0.5))
+    b = pair.f32(_rt(N, seed=3))
+    r = pair.act((_rt(M, N, seed=5) * 0.5 + 6.0).bfloat16().float()) if res else (None, None)
+    gamma, beta = pair.f32(_rt(N, seed=6) * 0.1 + 1.0), pair.f32(_rt(N, seed=7) * 0.1)
+    out_h = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ln_h = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    out_p = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    ln_p = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    out_e, ln_e = torch.zeros(M, N), torch.zeros(M, N)
+    pair.hip.gemm(a[0], wt[0], out_h, M=M, N=N, bias=b[0], residual=r[0], ln=(gamma[0], beta[0], 1e-5, ln_h))
+    pair.hip.gemm(a[0], wt[0], out_p, M=M, N=N, bias=b[0], residual=r[0], tile_cfg=23, split_k=1)
+    pair.hip.layernorm(out_p, gamma[0], beta[0], 1e-5, ln_p)
+    pair.emu.gemm(a[1], wt[1], out_e, M=M, N=N, bias=b[1], residual=r[1], ln=(gamma[1], beta[1], 1e-5, ln_e))
+    torch.cuda.synchronize()
+    assert torch.equal(out_h, out_p)
+    assert torch.isfinite(ln_h.float()).all()
+    assert rel_l2(ln_h.float().cpu(), ln_e) < BF16_TOL
+    assert rel_l2(ln_h.float().cpu(), ln_p.float().cpu()) < 2e-2   # LN of the bf16-rounded stream: the rounding of x shows when |mean| >> std

@@ -227,3 +227,28 @@ def test_dropout_epilogue_matches_the_standalone_mask(sim, cfg):
     assert rel_l2(got, z_e) < BF16_TOL
     assert torch.equal(got[~keep], res[~keep])            # dropped: the residual alone, bit for bit
     assert abs(float(keep.float().mean()) - (1 - p)) < 0.01
+
+
+@pytest.mark.parametrize("M,K,res,rowvec", [(320, 320, True, 0), (200, 64, False, 0), (480, 1280, True, 160)])
+def test_layernorm_second_output_of_the_160x320_tile(sim, M, K, res, rowvec):
+    """t2v_gemm's ln_* fields: LayerNorm(out) over the 320 columns as a second output of the full-row 160x320 kernel (two waves
+    per row exchange their row sums through LDS) — main output unchanged, LN output = F.layer_norm of the fp32 epilogue values;
+    rows beyond M masked; inputs with |mean| >> std (a residual stream is not zero-mean)."""
+    N = 320
+    a = _rt(M, K, seed=1)
+    wt = _rt(N, K, seed=2, scale=K ** -0.5)
+    b = _rt(N, seed=3)
+    r = (_rt(M, N, seed=5) * 0.5 + 6.0).bfloat16().float() if res else None
+    rv = _rt((M + rowvec - 1) // rowvec, N, seed=4) if rowvec else None
+    gamma, beta = _rt(N, seed=6) * 0.1 + 1.0, _rt(N, seed=7) * 0.1
+    bf = lambda t: None if t is None else t.bfloat16().contiguous()  # noqa: E731
+    out_s, ln_s = torch.full((M, N), float("nan"), dtype=torch.bfloat16), torch.full((M, N), float("nan"), dtype=torch.bfloat16)
+    out_p = torch.zeros(M, N, dtype=torch.bfloat16)
+    out_e, ln_e = torch.zeros(M, N), torch.zeros(M, N)
+    kw = dict(M=M, N=N, rowvec_div=rowvec)
+    sim.gemm(bf(a), bf(wt), out_s, bias=b, rowvec=rv, residual=bf(r), ln=(gamma, beta, 1e-5, ln_s), **kw)
+    sim.gemm(bf(a), bf(wt), out_p, bias=b, rowvec=rv, residual=bf(r), tile_cfg=23, split_k=1, **kw)
+    EMU.gemm(a, wt, out_e, bias=b, rowvec=rv, residual=r, ln=(gamma, beta, 1e-5, ln_e), **kw)
+    assert torch.equal(out_s, out_p)                      # the main output is the plain kernel's, bit for bit
+    assert torch.isfinite(ln_s.float()).all()
+    assert rel_l2(out_s.float(), out_e) < BF16_TOL and rel_l2(ln_s.float(), ln_e) < BF16_TOL
