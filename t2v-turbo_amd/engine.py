@@ -270,8 +270,10 @@ class _Engine:
         self.ops.gemm(a, w, out, M=a.shape[0], N=N, bias=bias, residual=residual, act=act, **({"ln": ln} if ln is not None else {}))
         return out
 
-    # LayerNorm as a by-product of the GEMM that produces its input (T2V_FUSE_LN=0: separate t2v_layernorm launches)
-    fuse_ln = os.environ.get("T2V_FUSE_LN", "1") == "1"
+    # LayerNorm as a by-product of the GEMM that produces its input.  Opt-in (T2V_FUSE_LN=1): measured on MI355X it removes 30
+    # launches and 0.7 ms of t2v_layernorm per UNet step but adds 0.36 ms to the producing GEMMs (a second 26 MB write in their
+    # epilogue) — 23.95 vs 24.06 ms per step in a same-box A/B, i.e. the kernel time is a wash and only the boundaries are saved.
+    fuse_ln = os.environ.get("T2V_FUSE_LN", "0") == "1"
 
     def ln_fusable(self, C, norm):
         """The 160x320 workgroup tile holds whole rows only at N = 320 (the full-resolution level: 60 of the 99 LayerNorms).  A

@@ -139,3 +139,26 @@ def test_vae_decode_backward_dataflow_matches_oracle_autograd():
         (ref2 * dout2).sum().backward()
     assert rel_l2(out2, ref2.detach()) < 2e-5 and rel_l2(dz2, zz2.grad) < 1e-4
     assert "gn_bwd" in eng.ops.calls and "softmax_bwd_rows" in eng.ops.calls and "sumpool2x2" in eng.ops.calls
+
+
+def test_unet_engine_with_layernorm_fused_into_the_producing_gemm():
+    """``fuse_ln`` (opt-in on the device, engine.py): the transformer blocks' LayerNorms as second outputs of proj_in and of the
+    attention out-projections — the emulated backend takes the fused form at every width, so the dataflow (shared LN buffer,
+    stream-order reuse, first block fed by proj_in) is pinned against the reference golden; fewer launches, same numbers."""
+    g = load("unet_tiny")
+    cfg = tiny_unet_params()
+    m = UNetModel(**cfg).eval()
+    m.load_state_dict(synth_state_dict(manifest("unet_tiny")), strict=True)
+    counts = {}
+    for fuse in (False, True):
+        ops = EmuOps()
+        eng = UNetEngine(m, ops)
+        eng.fuse_ln = fuse
+        with torch.no_grad():
+            y = eng(g["x"], g["ts"], g["ctx"], 16, g["tc"], None)
+        assert rel_l2(y, g["y"]) < 2e-5, fuse
+        counts[fuse] = {name: ops.calls.count(name) for name in ("layernorm", "gemm")}
+    n_ln = sum(1 for mod in m.modules() if isinstance(mod, torch.nn.LayerNorm))
+    assert counts[False]["layernorm"] == n_ln and counts[True]["gemm"] == counts[False]["gemm"]
+    # init_attn's proj_in is a Conv1d (openaimodel3d.py:439-453): its first LayerNorm stays a launch of its own
+    assert 0 < counts[True]["layernorm"] <= 2

@@ -249,6 +249,19 @@ def test_unet_full_width_c2_config_vs_oracle():
     err = rel_l2(ys[0], ref)
     print(f"full-width C2 parity: rel-L2 {err:.3e}")
     assert err < E2E_TOL, err
+    # the opt-in LayerNorm-in-the-GEMM-epilogue form (engine.fuse_ln, 30 launches fewer at these widths): same network
+    n_plain = len(next(iter(eng.plans.values()))["rec"])
+    eng.fuse_ln = True
+    eng.plans.clear()
+    try:
+        with torch.no_grad():
+            y_f = model(x, ts, context=ctx, fps=16, timestep_cond=tc).float().cpu()
+        n_fused = len(next(iter(eng.plans.values()))["rec"])
+    finally:
+        eng.fuse_ln = False
+        eng.plans.clear()
+    assert n_fused == n_plain - 30
+    assert rel_l2(y_f, ref) < E2E_TOL and rel_l2(y_f, ys[0]) < 1e-2
 
 
 def test_rccl_world_size_1_flat_gradient_all_reduce():
