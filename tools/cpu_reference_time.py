@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--runs", type=int, default=3)
+    ap.add_argument("--decode-frames", type=int, default=0, help="also time the KL-VAE decode of this many 320x512 frames (reported per 16 frames)")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_cpu_reference_timing.json"))
     a = ap.parse_args()
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -83,6 +84,43 @@ def main():
     d = (res["oracle"] - res["reference"]).double().norm() / res["reference"].double().norm()
     out["oracle_vs_reference_rel_l2"] = float(d)
     out["oracle_over_reference_time"] = round(out["oracle"]["median_s"] / out["reference"]["median_s"], 3)
+    if a.decode_frames:
+        # the reference's KL-VAE decode (frame loop of LatentDiffusion.decode_first_stage_2DAE, ddpm3d.py:666-679)
+        # and the 4-step clip total = 4 UNet forwards + the 16-frame decode, reference vs oracle
+        import yaml
+        from lvdm.models.autoencoder import AutoencoderKL as RefAE
+        from oracle import vae_oracle as vo
+        cfgfull = yaml.safe_load(open(os.path.join(mg.REF, "configs/inference_t2v_512_v2.0.yaml")))
+        fs = cfgfull["model"]["params"]["first_stage_config"]["params"]
+        torch.manual_seed(4321)
+        ae = RefAE(**fs).eval()
+        ae_sd = {k: v.detach().float() for k, v in ae.state_dict().items()}
+        f = a.decode_frames
+        z = torch.randn(1, 4, f, 40, 64, generator=torch.Generator().manual_seed(3)) * 0.18215
+
+        def dec_ref():
+            with torch.no_grad():
+                zz = z / 0.18215
+                return torch.cat([ae.decode(zz[:, :, i]).unsqueeze(2) for i in range(f)], dim=2)
+
+        def dec_oracle():
+            return vo.decode_first_stage_2dae(ae_sd, fs["ddconfig"], z)
+
+        dres = {}
+        for name, fn in (("reference", dec_ref), ("oracle", dec_oracle)):
+            fn()
+            times = []
+            for _ in range(a.runs):
+                t0 = time.time()
+                dres[name] = fn()
+                times.append(time.time() - t0)
+            med = statistics.median(times)
+            out["decode_" + name] = {"frames": f, "runs_s": [round(t, 2) for t in times], "median_s_per_frame": round(med / f, 2),
+                                     "s_per_16_frames": round(med / f * 16, 1)}
+            print("decode", name, out["decode_" + name], flush=True)
+        out["decode_oracle_vs_reference_rel_l2"] = float((dres["oracle"] - dres["reference"]).double().norm() / dres["reference"].double().norm())
+        for name in ("reference", "oracle"):
+            out["clip_4step_s_" + name] = round(4 * out[name]["median_s"] * 16.0 / a.frames + out["decode_" + name]["s_per_16_frames"], 1)
     with open(a.out, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
