@@ -77,6 +77,37 @@ def main():
         ms_step = timed(lambda: ms_model(x, ts, ctx, timestep_cond=tc), iters=10, warm=3)
     out["modelscope_unet_step_16f_256x256"] = {"ms": round(ms_step, 2), "latent": [1, 4, 16, 32, 32], "hip_graph": True}
     del ms_model
+    # BASELINE config C4: T2V-Turbo-v2 sampling, 16 steps on the 200-step grid with the motion-guidance embedding (unet_mg:
+    # motion_cond_proj_dim = 256, switched off below the percentage threshold: pipeline/t2v_turbo_vc2_pipeline.py:190-204) +
+    # 16-frame decode; the motion-prior preprocessing that feeds it (DDIM inversion = 200 UNet forwards) is timed per forward
+    import bench
+    from t2v_turbo_amd.pipeline import T2VTurboVC2Pipeline, make_synthetic_t2v
+    from t2v_turbo_amd.unet3d import UNetModel
+    cfg = dict(bench.VC2_UNET, motion_cond_proj_dim=256)
+    torch.manual_seed(1234)
+    with torch.device(dev):
+        unet = UNetModel(**cfg)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    with torch.no_grad():
+        for p_ in unet.parameters():
+            if float(p_.abs().max()) == 0.0:
+                p_.normal_(0.0, 0.02, generator=g)
+    unet = unet.to(torch.bfloat16).eval()
+    unet.dtype = torch.bfloat16
+    pipe = T2VTurboVC2Pipeline(make_synthetic_t2v(unet, dev, torch.bfloat16), None, {"params": {"unet_config": {"params": cfg}}})
+    pe = torch.randn(1, 77, 1024, device=dev, dtype=torch.bfloat16)
+
+    def clip16():
+        gen = torch.Generator(device=dev).manual_seed(42)
+        return pipe(prompt=None, height=320, width=512, frames=16, fps=16, guidance_scale=7.5, motion_gs=0.1, use_motion_cond=True,
+                    percentage=0.3, num_inference_steps=16, lcm_origin_steps=200, prompt_embeds=pe, generator=gen, output_type="pt")
+
+    with torch.no_grad():
+        ms_c4 = timed(clip16, iters=3, warm=2)
+        vid16 = clip16()
+    out["clip_16step_v2_motion_cond_16f_320x512"] = {"ms": round(ms_c4, 1), "finite": bool(torch.isfinite(vid16.float()).all()),
+                                                     "video_shape": list(vid16.shape), "hip_graph": True}
+    del pipe, unet
     n = 117_150_000  # LoRA parameter count of the v1 run (468.6 MB fp32)
     p = [torch.nn.Parameter(torch.randn(n, device=dev))]
     sync = FlatGradSync(p)
