@@ -56,6 +56,12 @@ def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_em
                  reward_scale=0.0, reward_frame_bsz=5, reward_train_bsz=1, vae_scale_factor=0.18215, student_engine=None,
                  batch_teacher=False):
     """Returns (loss, info).  ``rng`` may pin the random draws for tests: dict(index, noise, w)."""
+    import time as _time
+    _marks = [("start", _time.perf_counter())]
+
+    def _mark(name):  # host-side timestamps only (no synchronisation): where the launching thread spends its time
+        _marks.append((name, _time.perf_counter()))
+
     eng = student_engine
     if eng is not None:
         assert eng.model is unet and eng.training_lora, "student_engine must wrap this UNet with its LoRA tensors bound"
@@ -106,12 +112,15 @@ def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_em
             x_prev = _teacher_solver_step(teacher_unet, solver, noisy, start_timesteps, prompt_embeds, uncond_prompt_embeds, fps,
                                           w, index, alpha_schedule, sigma_schedule, batch_teacher)
             target_pred, _ = student_native(x_prev, timesteps, False)
+        _mark("teacher+target")
         noise_pred, emb_all = student_native(noisy, start_timesteps, True)
         noise_pred.requires_grad_(True)  # leaf: loss.backward() leaves d(loss)/d(noise_pred) on it for the engine
+        _mark("student_fwd")
     else:
         # 7. online (student) prediction, with grad
         with autocast():
             noise_pred = unet(noisy, start_timesteps, **context, timestep_cond=w_embedding)
+        _mark("student_fwd")
     pred_x_0 = cd_math.get_predicted_original_sample(noise_pred, start_timesteps, noisy, "epsilon", alpha_schedule, sigma_schedule)
     model_pred = c_skip_start * noisy + c_out_start * pred_x_0
 
@@ -140,6 +149,7 @@ def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_em
                 target_pred = unet(x_prev.float(), timesteps, **context, timestep_cond=w_embedding)
         target_x0 = cd_math.get_predicted_original_sample(target_pred, timesteps, x_prev, "epsilon", alpha_schedule, sigma_schedule)
         target = c_skip * x_prev + c_out * target_x0
+    _mark("teacher+target" if eng is None else "targets")
 
     # 10. loss, 11. backward + exchange + update
     if loss_type == "l2":
@@ -159,6 +169,7 @@ def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_em
             # conditioning branch put there), then the B-row conditioning branch through torch
             eng.backward(noise_pred.grad, flat_grad=grad_sync.flat, accumulate=True)
             emb_all.backward(eng.d_emb_all.to(emb_all.dtype))
+        _mark("backward")
         if grad_sync is not None:
             grad_sync.all_reduce_mean()
             info["grad_norm"] = grad_sync.clip_grad_norm_(max_grad_norm)
@@ -166,4 +177,6 @@ def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_em
             optimizer.step()
             if grad_sync is None:
                 optimizer.zero_grad(set_to_none=True)
+        _mark("sync+clip+step")
+    info["host_ms"] = {b[0]: round((b[1] - a[1]) * 1e3, 2) for a, b in zip(_marks, _marks[1:])}
     return loss, info

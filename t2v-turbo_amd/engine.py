@@ -84,8 +84,10 @@ class Act:
 
 # =================================================================================== weights
 def is_lora_leaf(mod):
-    base = getattr(mod, "linear", None) or getattr(mod, "conv", None)
-    return base is not None and hasattr(mod, "lora_up") and hasattr(mod, "lora_down")
+    """A LoraInjected{Linear,Conv2d,Conv3d} (utils/lora.py:19-230) by its children — dictionary lookups, not ``getattr``: a missing
+    attribute on an nn.Module costs an exception, and this runs over every module of the UNet on every training-path call."""
+    d = mod._modules
+    return "lora_up" in d and "lora_down" in d and (d.get("linear") is not None or d.get("conv") is not None)
 
 
 def effective_weight_bias(mod, merge=True):
@@ -208,8 +210,10 @@ class Packer:
 
 
 def params_fingerprint(module, skip=()):
+    """Changes when any parameter is updated in place (version counter), re-homed (data pointer), added or removed."""
+    from .nn_util import walk_parameters
     fp = 0
-    for p in module.parameters():
+    for p in walk_parameters(module):
         if id(p) in skip:
             continue
         fp = (fp * 1000003 + p._version + (p.data_ptr() & 0xFFFFFFF)) & 0xFFFFFFFFFFFF

@@ -72,13 +72,22 @@ class LoraTrainMixin:
         self.lora_ids = set(self.lora_off)
         self.plans.clear()
         self.fingerprint = None
+        self._engine_leaves = None
 
     @property
     def training_lora(self):
         return self.lora_params is not None
 
     def engine_leaves(self):
-        """Injected leaves whose gradients the engine computes (token-row leaves; the B-row conditioning branch is torch's)."""
+        """Injected leaves whose gradients the engine computes (token-row leaves; the B-row conditioning branch is torch's), in
+        registration order.  Cached per binding: the module route asks on every call, and a walk in ``modules()`` order costs ms."""
+        cached = getattr(self, "_engine_leaves", None)
+        if cached is not None and all(is_lora_leaf(mod) for mod in cached[:4]):
+            return cached
+        self._engine_leaves = self._find_engine_leaves()
+        return self._engine_leaves
+
+    def _find_engine_leaves(self):
         m = self.model
         cond = set()
         for name in ("time_embed", "fps_embedding", "time_cond_proj", "motion_cond_proj", "combine_proj"):

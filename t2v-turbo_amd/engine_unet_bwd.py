@@ -47,12 +47,13 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
     def _active_dropouts(self):
         """Number of active Dropout(p > 0) modules; in LoRA training they must all be ones the engine (or torch's conditioning
         branch) applies: the LoRA branches' and the temporal conv blocks' (train-mode student, train_t2v_turbo_v1_lora.py:641)."""
-        m = self.model
-        active = [mod for mod in m.modules() if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training]
+        from .nn_util import walk_modules
+        mods = walk_modules(self.model)  # (one cheap walk per call: order does not matter here)
+        active = [mod for mod in mods if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training]
         if active and self.training_lora:
             from .unet3d import TemporalConvBlock
-            known = {id(mod.dropout) for mod in m.modules() if is_lora_leaf(mod)}
-            for blk in m.modules():
+            known = {id(mod.dropout) for mod in mods if is_lora_leaf(mod)}
+            for blk in mods:
                 if isinstance(blk, TemporalConvBlock):
                     known.update(id(l) for st in (blk.conv1, blk.conv2, blk.conv3, blk.conv4) for l in st if isinstance(l, nn.Dropout))
             other = [mod for mod in active if id(mod) not in known]

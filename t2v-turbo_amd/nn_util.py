@@ -53,3 +53,28 @@ def guidance_embedding(w, embedding_dim=512, dtype=torch.float32):
         emb = torch.nn.functional.pad(emb, (0, 1))
     assert emb.shape == (w.shape[0], embedding_dim)
     return emb
+
+
+def walk_modules(root):
+    """Every module under ``root`` (itself included), depth first, straight off the ``_modules`` dicts: ``nn.Module.modules()``
+    builds a name for each of the ~3 000 modules of the UNet on the way (4 ms per walk; this is 1 ms), and the engines walk the
+    tree on every call."""
+    out, stack = [], [root]
+    while stack:
+        mod = stack.pop()
+        out.append(mod)
+        for child in mod._modules.values():
+            if child is not None:
+                stack.append(child)
+    return out
+
+
+def walk_parameters(root):
+    """Every distinct parameter under ``root`` in a fixed (not ``parameters()``'s) order, without building names."""
+    out, seen = [], set()
+    for mod in walk_modules(root):
+        for p in mod._parameters.values():
+            if p is not None and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+    return out

@@ -555,8 +555,10 @@ class UNetModel(nn.Module):
                                                              -> "train": gradient engine (un-merged LoRA branch, counter-based dropout);
           * anything else (full fine-tuning, a train-mode network without LoRA, gradients w.r.t. the context, adapters)
                                                              -> the torch composite path, with a one-time warning."""
+        from .nn_util import walk_modules, walk_parameters
         grad = torch.is_grad_enabled() and self._needs_grad(x, context, timestep_cond)
-        dropping = self.training and any(isinstance(mod, nn.Dropout) and mod.p > 0 for mod in self.modules())
+        mods = walk_modules(self) if (self.training or grad) else ()
+        dropping = self.training and any(isinstance(mod, nn.Dropout) and mod.p > 0 for mod in mods)
         if features_adapter is not None:
             if not grad and not dropping:
                 raise NotImplementedError("features_adapter is not used by t2v-turbo and not supported natively")
@@ -564,13 +566,13 @@ class UNetModel(nn.Module):
         if not grad and not dropping:
             return "infer", None
         from .engine import is_lora_leaf
-        lora_ids = {id(w) for mod in self.modules() if is_lora_leaf(mod) for w in (mod.lora_up.weight, mod.lora_down.weight)}
+        lora_ids = {id(w) for mod in mods if is_lora_leaf(mod) for w in (mod.lora_up.weight, mod.lora_down.weight)}
         if not lora_ids:
             return "composite", ("a train-mode network with active Dropout and no LoRA" if not grad else
                                  "gradients without LoRA injection (full fine-tuning / input gradients)")
         if context is None:
             return "composite", "no text context"
-        if any(p.requires_grad and id(p) not in lora_ids for p in self.parameters()):
+        if any(p.requires_grad and id(p) not in lora_ids for p in walk_parameters(self)):
             return "composite", "trainable parameters besides the LoRA tensors"
         if grad and (context.requires_grad or (timestep_cond is not None and timestep_cond.requires_grad)):
             return "composite", "gradients w.r.t. the context / guidance embedding"
@@ -612,7 +614,8 @@ class UNetModel(nn.Module):
             raise ValueError("native LoRA training needs the text context")
         grad = torch.is_grad_enabled()
         eng = self.native_train_engine(forward_only=not grad)
-        trainable = {id(p) for p in self.parameters() if p.requires_grad}
+        from .nn_util import walk_parameters
+        trainable = {id(p) for p in walk_parameters(self) if p.requires_grad}
         if trainable - eng.lora_ids:
             raise RuntimeError('native_mode = "train": only LoRA tensors may require grad (the base weights are frozen packs)')
         if context.requires_grad or (timestep_cond is not None and timestep_cond.requires_grad):
@@ -642,7 +645,11 @@ class UNetModel(nn.Module):
         conditioning input of the native training engine (engine_lora.py).  Differentiable: this M = B-row branch (27
         small leaves) stays with torch autograd, the engine returns d(loss)/d(this tensor)."""
         emb = self._embedding(timesteps, fps, timestep_cond, motion_cond)
-        return torch.cat([mod.emb_layers(emb) for mod in self.modules() if isinstance(mod, ResBlock)], dim=1).float()
+        blocks = self.__dict__.get("_resblocks")  # the ResBlock objects never change (LoRA injection swaps leaves inside them)
+        if blocks is None:
+            blocks = [mod for mod in self.modules() if isinstance(mod, ResBlock)]
+            self.__dict__["_resblocks"] = blocks
+        return torch.cat([mod.emb_layers(emb) for mod in blocks], dim=1).float()
 
     def _forward_composite(self, x, timesteps, context, features_adapter, fps, timestep_cond, motion_cond):
         """Reference-semantics torch path (openaimodel3d.py:672-740)."""

@@ -140,7 +140,7 @@ def main():
             print(json.dumps({"metric": "v1 distillation steps/sec (student " + ("native gradient engine" if eng is not None else "fwd+bwd torch path")
                               + ", teacher x2 native HIP)", "student_native": eng is not None or bool(a.module_route), "variant": variant or ("module-route" if a.module_route else None),
                               "value": round(world / dt, 4), "unit": "samples/s", "n_gpus": world, "ms_per_step": round(dt * 1e3, 1),
-                              "lora_grad_mb": round(sync.numel * 4 / 2 ** 20, 1), "loss": float(loss),
+                              "lora_grad_mb": round(sync.numel * 4 / 2 ** 20, 1), "loss": float(loss), "host_ms_last_step": info.get("host_ms"),
                               "teacher_native": teacher._engine_box.engine is not None, "peak_mem_gb":
                               round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}), flush=True)
     if world > 1:
