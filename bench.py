@@ -9,6 +9,12 @@ A "step" is one UNet forward of the t2v-turbo sampling loop (timesteps cycle thr
 LCM table [999,759,519,279]) on synthetic inputs already resident in HBM.  Multi-GPU = independent
 replicas (inference shards by clip, no collective): weak scaling, value = N*K / max-over-ranks time.
 Rank 0 prints ONE JSON line (see DESIGN.md §Measurement for the extra objects).
+
+`python bench.py --gpus N` without a torchrun environment re-executes itself under `torch.distributed.run`
+(one rank per GPU, rendezvous on 127.0.0.1).  At N > 1 the `distill_step` leg (BASELINE config C3) runs on
+every rank with the real flat-buffer gradient all-reduce (RCCL) and reports global samples/s.
+`--dry-run-cpu 1` runs the same control flow on CPU (tiny widths, gloo, the emulated op backend of the test
+suite): a plumbing check of the multi-rank path for boxes without GPUs, labelled as such, never a measurement.
 """
 import argparse
 import json
@@ -188,8 +194,7 @@ def cpu_baseline(model, x, ctx, tc, frames_req):
     the GPU box, and tools/cpu_reference_time.py shows the two run at the same speed where it does:
     profiles/r02_cpu_reference_timing.json) timed on this host's cores, BASELINE.md 3 style: 1 warm-up + 3 runs, median.
     The warm-up is ONE fp32 forward of the whole 16-frame clip, which is also the parity check of the GPU output at the
-    size the metric is quoted on; the three timed runs use the whole clip when that fits ~75 s of CPU time, else its first
-    4 frames (every per-frame operator of the UNet is linear in the frame count; reported as 16-frame-equivalent steps/s)."""
+    size the metric is quoted on; the timed runs are whole 16-frame forwards too."""
     import statistics
     from oracle import unet_oracle as uo
     cores = os.cpu_count() or 1
@@ -211,97 +216,232 @@ def cpu_baseline(model, x, ctx, tc, frames_req):
     with torch.no_grad():
         y_gpu = model(x[:, :, :full].contiguous(), ts.to(x.device), context=ctx, fps=16, timestep_cond=tc)
     parity = float((y_gpu.float().cpu() - y).double().norm() / y.double().norm())
-    frames = full if t_warm * 3 < 75 else min(4, full)
+    # time what is named: whole 16-frame forwards (3 of them when they fit ~100 s of CPU time, else one more besides the
+    # warm-up); the 4-frame slice of earlier rounds under-counted by 7 % and is gone
+    n_timed = 3 if t_warm * 3 < 100 else 1
     times = []
-    for _ in range(3):
-        dt, _y = run(frames)
+    for _ in range(n_timed):
+        dt, _y = run(full)
         times.append(dt)
     med = statistics.median(times)
-    log(f"cpu oracle timed runs ({frames} frames): {[round(t, 1) for t in times]} s")
-    return {"value": round((frames / 16.0) / med, 5), "unit": "UNet steps/s (16f-equivalent)", "cores": threads, "kind": "port",
+    log(f"cpu oracle timed runs ({full} frames): {[round(t, 1) for t in times]} s")
+    return {"value": round((full / 16.0) / med, 5), "unit": "UNet steps/s", "cores": threads, "kind": "port",
             "runs_s": [round(t, 2) for t in times], "warmup_s": round(t_warm, 2),
-            "sample": f"fp32 forward of oracle.unet_oracle (restated reference UNetModel.forward) on a (1,4,{frames},40,64) "
-                      f"latent: 1 warm-up ({full} frames, {t_warm:.1f} s) + 3 runs, median {med:.1f} s, torch CPU {threads} "
-                      f"threads of {cores} cores",
+            "sample": f"fp32 forward of oracle.unet_oracle (restated reference UNetModel.forward) on the whole (1,4,{full},40,64) "
+                      f"latent: 1 warm-up ({t_warm:.1f} s, also the parity run) + {n_timed} timed run(s), median {med:.1f} s, torch CPU "
+                      f"{threads} threads of {cores} cores",
             "parity_rel_l2_vs_gpu": parity, "parity_frames": full, "parity_tol": PARITY_TOL}
 
 
-def distill_step_leg(teacher, dev):
-    """BASELINE config C3 on one GPU: the v1 consistency-distillation step (train_t2v_turbo_v1_lora.py:978-1196) at full size,
-    B=1 — LoRA r=64 student (fp32 master weights, train mode, bf16 engine) forward + target forward + backward on the native
-    gradient engine, the two frozen-teacher forwards on the inference engine, flat-buffer clip + fused AdamW."""
-    from t2v_turbo_amd import cd_math, dist as tdist, lora
-    from t2v_turbo_amd.distill import distill_step
-    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
-    from t2v_turbo_amd.native import HipOps
-    from t2v_turbo_amd.optim import FlatAdamW
-    from t2v_turbo_amd.scheduler import T2VTurboScheduler
+DISTILL_PARITY = {"out": 3e-2, "dx": 6e-2, "cos_min": 0.98, "norm_ratio": 0.12}   # bf16 device engine vs fp32 CPU autograd
+
+
+def _new_student(cfg, dev, rank_r, seed=4321):
+    """LoRA-injected student (fp32 master weights; zero-init tensors and the zero lora_up factors re-drawn: same on every rank)."""
+    from t2v_turbo_amd import lora
     from t2v_turbo_amd.unet3d import UNetModel
     with torch.device(dev):
-        student = UNetModel(**VC2_UNET)
-    g = torch.Generator(device=dev).manual_seed(4321)
+        student = UNetModel(**cfg)
+    g = torch.Generator(device=dev).manual_seed(seed)
     with torch.no_grad():
         for p in student.parameters():
             if float(p.abs().max()) == 0.0:
                 p.normal_(0.0, 0.02, generator=g)
     student.requires_grad_(False)
-    lora.inject_trainable_lora_extended(student, r=64)
+    lora.inject_trainable_lora_extended(student, r=rank_r)
     params = lora.lora_parameters(student)
     with torch.no_grad():  # lora_up starts at zero: give the down-projection gradients something to do
         for p in params:
             if float(p.abs().max()) == 0.0:
                 p.normal_(0.0, 0.01, generator=g)
+    return student, params
+
+
+def distill_parity(student, params, sync, make_ops, cfg, dev, frames=4):
+    """Parity gate of the distillation leg (exit code 3 on failure, like the inference leg): the student's forward + backward on
+    the device gradient engine against fp32 CPU autograd (oracle/lora_grad_oracle.py) at the FULL widths on a bounded
+    ``frames``-frame latent (the 16-frame comparison is tests/test_gpu_train_parity.py: ~3 min of CPU), eval mode — the
+    train-mode masks are checked by the GPU suite.  Every LoRA tensor's gradient by cosine and norm ratio."""
+    import statistics
+    from oracle.lora_grad_oracle import per_tensor_agreement, student_reference
+    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+    t0 = time.time()
+    was_training = student.training
+    student.eval()
+    try:
+        gen = torch.Generator().manual_seed(11)
+        h, w = (40, 64) if cfg["model_channels"] >= 320 else (8, 8)
+        x = torch.randn(1, 4, frames, h, w, generator=gen)
+        ctx = torch.randn(1, 77, cfg["context_dim"], generator=gen)
+        tc = torch.randn(1, 256, generator=gen)
+        r_out = torch.randn(x.shape, generator=gen)
+        ts = torch.tensor([519])
+        eng = UNetGradEngine(student, make_ops())
+        eng.bind_lora(params)
+        emb_all = student.conditioning_emb_all(ts.to(dev), 16, tc.to(dev))
+        y = eng.forward_tape(x.to(dev), ts.to(dev), ctx.to(dev), 16, tc.to(dev), None, emb_all=emb_all)
+        flat = torch.zeros(eng.lora_numel, device=dev)
+        dx = eng.backward(r_out.to(dev), flat_grad=flat, accumulate=False)
+        sync.zero_()                              # the conditioning branch's 27 leaves stay with torch autograd:
+        emb_all.backward(eng.d_emb_all)           # their gradients land in the flat buffer's own slots
+        flat = (flat + sync.flat).cpu()
+        sync.zero_()
+        del eng
+        rank_r = max(p.shape[0] for p in params[1::2])
+        y_ref, dx_ref, g_ref = student_reference(student.state_dict(), cfg, rank_r, x, ts, ctx, 16, tc, r_out,
+                                                 threads=min(os.cpu_count() or 1, 64))
+        grads, off = [], 0
+        for p in params:
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        rows, zeros = per_tensor_agreement(grads, g_ref)
+
+        def rel(a, b):
+            return float((a.double().cpu() - b.double()).norm() / b.double().norm())
+
+        cs, qs = [r[1] for r in rows], [abs(r[2] - 1.0) for r in rows]
+        out = {"frames": frames, "out_rel_l2": rel(y, y_ref), "dx_rel_l2": rel(dx, dx_ref), "lora_tensors": len(rows),
+               "lora_grad_cos_min": min(cs), "lora_grad_cos_median": statistics.median(cs), "lora_grad_norm_ratio_max_dev": max(qs),
+               "zero_reference_gradients": len(zeros), "tol": DISTILL_PARITY, "seconds": round(time.time() - t0, 1),
+               "reference": "fp32 CPU autograd through the torch module (oracle/lora_grad_oracle.py, pinned to the reference's own "
+                            "LoRA gradients: tests/golden/unet_tiny_lora_grad.npz)"}
+        out["ok"] = bool(out["out_rel_l2"] <= DISTILL_PARITY["out"] and out["dx_rel_l2"] <= DISTILL_PARITY["dx"] and
+                         out["lora_grad_cos_min"] >= DISTILL_PARITY["cos_min"] and
+                         out["lora_grad_norm_ratio_max_dev"] <= DISTILL_PARITY["norm_ratio"] and
+                         all(float(grads[i].abs().max()) < 1e-6 for i in zeros))
+        return out
+    finally:
+        student.train(was_training)
+
+
+def distill_step_leg(teacher, dev, world=1, dry=False, parity=True):
+    """BASELINE config C3: the v1 consistency-distillation step (train_t2v_turbo_v1_lora.py:978-1196) at full size, per-rank
+    B=1 — LoRA r=64 student (fp32 master weights, train mode, bf16 engine) forward + target forward + backward on the native
+    gradient engine, the two frozen-teacher forwards on the inference engine, ONE flat-buffer gradient all-reduce (RCCL at
+    world > 1: train_t2v_turbo_v1_lora.py:1190 through accelerate/DDP in the reference), flat-buffer clip + fused AdamW.
+    Runs on every rank; the timed region is bracketed by barrier + synchronize and the max over ranks is reported."""
+    import torch.distributed as dist
+    from t2v_turbo_amd import cd_math, dist as tdist
+    from t2v_turbo_amd.distill import distill_step
+    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+    from t2v_turbo_amd.optim import FlatAdamW
+    from t2v_turbo_amd.scheduler import T2VTurboScheduler
+    cfg = dict(VC2_UNET, model_channels=64, context_dim=128) if dry else VC2_UNET
+    if dry:
+        from tests.emu_ops import EmuOps   # CPU plumbing check only (--dry-run-cpu): the emulated op backend of the test suite
+
+        def make_ops():
+            return EmuOps(strict=True)
+    else:
+        from t2v_turbo_amd.native import HipOps as make_ops
+    rank = int(os.environ.get("RANK", "0"))
+    cuda = dev.type == "cuda"
+    student, params = _new_student(cfg, dev, 16 if dry else 64)
     student.train()
     sync = tdist.FlatGradSync(params)
     opt = FlatAdamW(params, sync, lr=1e-5)
-    eng = UNetGradEngine(student, HipOps())
+    eng = UNetGradEngine(student, make_ops())
     eng.flash_attn_bwd = eng.tn_wgrad = True
     eng.bind_lora(params)
     sched = T2VTurboScheduler()
     solver = cd_math.DDIMSolver(sched.alphas_cumprod.numpy(), ddim_timesteps=50).to(dev)
-    gen = torch.Generator().manual_seed(0)
-    lat = torch.randn((1, 4, 16, 40, 64), generator=gen).to(dev) * 0.18215
-    pe, ue = torch.randn(1, 77, 1024, generator=gen).to(dev), torch.randn(1, 77, 1024, generator=gen).to(dev)
+    gen = torch.Generator().manual_seed(rank)       # every rank its own clip: data parallel, per-rank batch 1
+    shape = (1, 4, 2, 8, 8) if dry else (1, 4, 16, 40, 64)
+    lat = torch.randn(shape, generator=gen).to(dev) * 0.18215
+    pe = torch.randn(1, 77, cfg["context_dim"], generator=gen).to(dev)
+    ue = torch.randn(1, 77, cfg["context_dim"], generator=gen).to(dev)
 
     def step():
         return distill_step(student, teacher, solver, sched, lat, pe, ue, optimizer=opt, grad_sync=sync,
-                            autocast_dtype=torch.bfloat16, student_engine=eng)
+                            autocast_dtype=torch.bfloat16 if cuda else None, student_engine=eng)
 
-    t_eng = teacher.native_engine()
-    t_graph, t_eng.use_graph = t_eng.use_graph, False   # the step is GPU-bound: plain replay of the teacher's list measured 3 % faster
+    def fence():
+        if world > 1:
+            dist.barrier()
+        if cuda:
+            torch.cuda.synchronize()
+
+    t_eng = None if dry else teacher.native_engine()
+    if t_eng is not None:
+        t_graph, t_eng.use_graph = t_eng.use_graph, False   # the step is GPU-bound: plain replay of the teacher's list measured 3 % faster
     try:
-        for _ in range(2):
+        for _ in range(1 if dry else 2):
             loss, info = step()
-        torch.cuda.synchronize()
+        fence()
         t0 = time.perf_counter()
-        n = 5
+        n = 2 if dry else 5
         for _ in range(n):
             loss, info = step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / n * 1e3
+        fence()
+        dt = time.perf_counter() - t0
     finally:
-        t_eng.use_graph = t_graph
+        if t_eng is not None:
+            t_eng.use_graph = t_graph
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms = dt / n * 1e3
+    # the exchange by itself: the same all-reduce of the flat gradient buffer, timed in isolation (it is inside ms_per_step too)
+    ar_ms = None
+    if world > 1:
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sync.all_reduce_mean()
+        fence()
+        ar_ms = (time.perf_counter() - t0) / 3 * 1e3
+        sync.zero_()
     plan = eng._last
-    out = {"ms_per_step": round(ms, 1), "samples_per_s": round(1e3 / ms, 3), "loss": float(loss.detach()),
+    out = {"ms_per_step": round(ms, 1), "samples_per_s": round(world * 1e3 / ms, 3), "n_gpus": world, "per_rank_batch": 1,
+           "loss": float(loss.detach()),
            "finite": bool(torch.isfinite(sync.flat).all() and torch.isfinite(opt.flat_param).all()),
            "lora_params_m": round(sync.numel / 1e6, 1), "student": "native gradient engine (flash attention backward, token-contracted "
            "weight gradients), train mode", "teacher": "2 forwards on the inference engine",
-           "launches": {"student_forward": len(plan["rec"]), "student_backward": len(plan["rec_bwd"])},
+           "grad_exchange": ("one all-reduce(mean) of the flat fp32 LoRA gradient buffer, %.1f MB, backend %s"
+                             % (sync.numel * 4 / 2 ** 20, dist.get_backend())) if world > 1 else "none (1 rank)",
+           "allreduce_ms": None if ar_ms is None else round(ar_ms, 3),
+           "launches": {"student_forward": len(plan["rec"]), "student_backward": len(plan["rec_bwd"])} if "rec" in plan else None,
            "host_ms_last_step": info.get("host_ms"),
-           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
-    try:
-        with torch.no_grad():
-            fwd = kernel_breakdown(eng, plan, plan["rec"])
-            plan["static"]["dout"].normal_()
-            bwd = kernel_breakdown(eng, plan, plan["rec_bwd"])
-        for tag, agg in (("forward", fwd), ("backward", bwd)):
-            out[tag + "_ms"] = round(sum(v["ms"] for v in agg.values()), 2)
-            out[tag + "_gemm_tflop"] = round(agg.get("t2v_gemm", {}).get("tflop", 0.0), 2)
-            out[tag + "_kernel_ms"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 2)}
-                                       for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]}
-    except Exception as e:  # noqa: BLE001 - a derived table must not cost the measured number
-        out["breakdown_error"] = repr(e)
+           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1) if cuda else None}
+    if rank != 0:
+        return out
+    if cuda:
+        try:
+            with torch.no_grad():
+                fwd = kernel_breakdown(eng, plan, plan["rec"])
+                plan["static"]["dout"].normal_()
+                bwd = kernel_breakdown(eng, plan, plan["rec_bwd"])
+            for tag, agg in (("forward", fwd), ("backward", bwd)):
+                out[tag + "_ms"] = round(sum(v["ms"] for v in agg.values()), 2)
+                out[tag + "_gemm_tflop"] = round(agg.get("t2v_gemm", {}).get("tflop", 0.0), 2)
+                out[tag + "_kernel_ms"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 2)}
+                                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]}
+        except Exception as e:  # noqa: BLE001 - a derived table must not cost the measured number
+            out["breakdown_error"] = repr(e)
+    if parity and world == 1:
+        del eng, plan
+        try:
+            out["parity"] = distill_parity(student, params, sync, make_ops, cfg, dev)
+        except Exception as e:  # noqa: BLE001 - an unverifiable step is reported as a parity failure, not as a number
+            out["parity"] = {"ok": False, "error": repr(e)}
     return out
+
+
+def self_spawn(n):
+    """`python bench.py --gpus N` from a plain shell: re-execute under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-spawn: " + " ".join(cmd))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -311,46 +451,70 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graph", type=int, default=1, help="replay the recorded forward as one hipGraph")
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU sample (0 = auto by core count)")
-    ap.add_argument("--clip", type=int, default=1, help="also time the 4-step clip incl. VAE decode")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU sample (0 = the whole 16-frame clip)")
+    ap.add_argument("--clip", type=int, default=1, help="also time the 4-step clip and the 16-step v2 clip incl. VAE decode")
     ap.add_argument("--breakdown", type=int, default=1)
-    ap.add_argument("--distill", type=int, default=1, help="also time the v1 distillation step (config C3, one GPU)")
+    ap.add_argument("--distill", type=int, default=1, help="also time the v1 distillation step (config C3; on every rank at N > 1)")
+    ap.add_argument("--distill-parity", type=int, default=1, help="gate the distillation leg on its gradient parity check (N = 1)")
+    ap.add_argument("--dry-run-cpu", type=int, default=0, help="plumbing check on CPU: tiny widths, gloo, emulated kernels (not a measurement)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:   # plain `python bench.py --gpus N`: become N ranks
+        sys.exit(self_spawn(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (MI355X)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dtype = torch.bfloat16
+    dry = bool(args.dry_run_cpu)
+    import torch.distributed as dist
+    if dry:
+        torch.set_num_threads(max(1, (os.cpu_count() or 2) // max(world, 1) // 2))
+        if world > 1:
+            dist.init_process_group("gloo")
+        dev, dtype = torch.device("cpu"), torch.float32
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (MI355X); --dry-run-cpu 1 only checks the plumbing"
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        torch.cuda.set_device(local)
+        dev, dtype = torch.device("cuda", local), torch.bfloat16
 
     log("building model")
-    model = build_model(dev, dtype)
-    x, ctx, tc = synth_inputs(dev, dtype)
+    if dry:
+        from t2v_turbo_amd.unet3d import UNetModel
+        torch.manual_seed(1234)
+        model = UNetModel(**dict(VC2_UNET, model_channels=64, context_dim=128)).eval()
+        with torch.no_grad():
+            for p in model.parameters():
+                if float(p.abs().max()) == 0.0:
+                    p.normal_(0.0, 0.02)
+        g0 = torch.Generator().manual_seed(0)
+        x, ctx = torch.randn(1, 4, 2, 8, 8, generator=g0), torch.randn(1, 77, 128, generator=g0)
+        from t2v_turbo_amd.nn_util import guidance_embedding
+        tc = guidance_embedding(torch.tensor([7.5]), 256)
+    else:
+        model = build_model(dev, dtype)
+        x, ctx, tc = synth_inputs(dev, dtype)
     log("model built")
-    eng = model.native_engine()
-    eng.use_graph = bool(args.graph)
+    eng = None if dry else model.native_engine()
+    if eng is not None:
+        eng.use_graph = bool(args.graph)
     table = [999, 759, 519, 279]
     ts = [torch.tensor([t], device=dev, dtype=torch.long) for t in table]
 
     def step(i):
         return model(x, ts[i % 4], context=ctx, fps=16, timestep_cond=tc)
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        if not dry:
+            torch.cuda.synchronize()
+
     with torch.no_grad():
-        y0 = step(0)  # recording pass (also packs weights)
+        step(0)  # recording pass (also packs weights)
         log("plan recorded")
         for i in range(max(args.warmup, 2)):  # >= 2: the second call captures the graph
             step(i)
-
-        def barrier():
-            if world > 1:
-                dist.barrier()
-            torch.cuda.synchronize()
-
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
@@ -373,7 +537,11 @@ def main():
                    "parallelism": f"replicas x{world}", "hip_graph": bool(args.graph)},
         "tflops_per_gpu": round(UNET_TFLOP_PER_STEP / (ms_per_step / 1e3), 2),
     }
-    if rank == 0:
+    if dry:
+        result.update(dtype="f32", data="CPU DRY RUN of the launch path (tiny widths, latent (1,4,2,8,8), gloo, emulated kernels): "
+                                        "plumbing only, NOT a measurement", tflops_per_gpu=None)
+        result["config"]["workload"] = "dry run: tiny UNet forward on CPU"
+    if rank == 0 and not dry:
         plan = next(iter(eng.plans.values()))
         result["config"]["graph_captured"] = plan.get("graph") is not None
         result["config"]["launches_per_step"] = len(plan["rec"])
@@ -409,28 +577,80 @@ def main():
             except Exception as e:  # noqa: BLE001 - optional leg, reported not fatal
                 result["clip_4step"] = {"error": repr(e)}
             log(f"clip leg: {result['clip_4step']}")
+            try:
+                with Watchdog(150, "16-step v2 clip leg"):
+                    result["clip_16step_v2"] = clip_v2_wallclock(dev, dtype)
+            except Exception as e:  # noqa: BLE001
+                result["clip_16step_v2"] = {"error": repr(e)}
+            log(f"v2 clip leg: {result['clip_16step_v2']}")
         if args.cpu_baseline and world == 1:
             try:
-                with Watchdog(240, "cpu baseline leg"):
+                with Watchdog(300, "cpu baseline leg"):
                     result["cpu_baseline"] = cpu_baseline(model, x, ctx, tc, args.cpu_frames)
             except Exception as e:  # noqa: BLE001
                 result["cpu_baseline"] = {"error": repr(e)}
             log(f"cpu baseline leg: {result['cpu_baseline']}")
-        if args.distill and world == 1:
-            try:
-                with Watchdog(300, "distillation step leg"):
-                    result["distill_step"] = distill_step_leg(model, dev)
-            except Exception as e:  # noqa: BLE001
-                result["distill_step"] = {"error": repr(e)}
-            log(f"distill leg: {result['distill_step']}")
+    # the distillation step (config C3) runs on EVERY rank: at N > 1 it carries the real gradient all-reduce
+    if args.distill:
+        try:
+            with Watchdog(420, "distillation step leg"):
+                d = distill_step_leg(model, dev, world=world, dry=dry, parity=bool(args.distill_parity))
+        except Exception as e:  # noqa: BLE001
+            if world > 1:
+                raise   # a rank that drops out of a collective leg must not leave the others waiting silently
+            d = {"error": repr(e)}
+        if rank == 0:
+            result["distill_step"] = d
+            log(f"distill leg: {d}")
+    rc = 0
+    if rank == 0:
         print(json.dumps(result), flush=True)
         par = result.get("cpu_baseline", {}).get("parity_rel_l2_vs_gpu")
         if par is not None and not par <= PARITY_TOL:  # a fast wrong answer is not a result
             log(f"PARITY FAILURE: rel-L2 {par:.3e} vs the oracle exceeds {PARITY_TOL}")
-            sys.exit(3)
+            rc = 3
+        dpar = result.get("distill_step", {}).get("parity")
+        if dpar is not None and not dpar.get("ok", False):
+            log(f"PARITY FAILURE (distillation leg: student forward / backward vs fp32 CPU autograd): {dpar}")
+            rc = 3
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
+
+
+def clip_v2_wallclock(dev, dtype):
+    """BASELINE config C4: T2V-Turbo-v2 sampling — 16 steps on the 200-step grid with the motion-guidance embedding (`unet_mg`:
+    motion_cond_proj_dim = 256, switched off below the percentage threshold: pipeline/t2v_turbo_vc2_pipeline.py:190-204) +
+    16-frame VAE decode -> (1,3,16,320,512).  Full-width parity of the motion-conditioned forward: tests/test_gpu_engine.py."""
+    from t2v_turbo_amd.pipeline import T2VTurboVC2Pipeline, make_synthetic_t2v
+    from t2v_turbo_amd.unet3d import UNetModel
+    cfg = dict(VC2_UNET, motion_cond_proj_dim=256)
+    torch.manual_seed(1234)
+    with torch.device(dev):
+        unet = UNetModel(**cfg)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    with torch.no_grad():
+        for p_ in unet.parameters():
+            if float(p_.abs().max()) == 0.0:
+                p_.normal_(0.0, 0.02, generator=g)
+    unet = unet.to(dtype).eval()
+    unet.dtype = dtype
+    unet.native_engine().use_graph = True
+    pipe = T2VTurboVC2Pipeline(make_synthetic_t2v(unet, dev, dtype), None, {"params": {"unet_config": {"params": cfg}}})
+    pe = torch.randn(1, 77, 1024, generator=torch.Generator().manual_seed(0)).to(dev, dtype)
+    times = []
+    for it in range(4):
+        gen = torch.Generator(device=dev).manual_seed(42)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        vid = pipe(prompt=None, height=320, width=512, frames=16, fps=16, guidance_scale=7.5, motion_gs=0.1, use_motion_cond=True,
+                   percentage=0.3, num_inference_steps=16, lcm_origin_steps=200, prompt_embeds=pe, generator=gen, output_type="pt")
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+    return {"ms": round(min(times[1:]), 2), "ms_all": [round(t, 2) for t in times], "unet_steps": 16, "video_shape": list(vid.shape),
+            "finite": bool(torch.isfinite(vid.float()).all()),
+            "workload": "16 UNet steps (motion_cond on for t >= 700) + fused scheduler steps + 16-frame VAE decode"}
 
 
 def clip_wallclock(model, dev, dtype):

@@ -17,7 +17,9 @@ def init_distributed(backend=None, single_process_group=False):
     ``single_process_group``: create the group even at world size 1 (a one-rank RCCL communicator: smoke tests)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if torch.cuda.is_available() and local < torch.cuda.device_count():
+    # the rank's GPU becomes the current device only when a launcher said which one it is (or there are several ranks): a
+    # single process that chose its own device earlier (torch.cuda.set_device(1)) keeps it
+    if torch.cuda.is_available() and local < torch.cuda.device_count() and ("LOCAL_RANK" in os.environ or world > 1):
         torch.cuda.set_device(local)
     if dist.is_initialized() or (world == 1 and not single_process_group):
         return
@@ -47,6 +49,7 @@ class FlatGradSync:
         off = 0
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            p._t2v_flat_sync = self   # the native student writes its weight gradients straight into this buffer (unet3d._flat_grad_buffer)
             off += p.numel()
         self.numel = n
 
@@ -66,9 +69,14 @@ class FlatGradSync:
             from .optim import _shared_ops
             if getattr(self, "_norm_ws", None) is None:
                 self._norm_ws = torch.empty(1025, dtype=torch.float32, device=self.flat.device)
-            with torch.cuda.device(self.flat.device):
-                _shared_ops().sumsq(self.flat, self._norm_ws[:1024], self._norm_ws[1024:])
-            norm = self._norm_ws[1024].sqrt()
+            try:
+                with torch.cuda.device(self.flat.device):
+                    _shared_ops().sumsq(self.flat, self._norm_ws[:1024], self._norm_ws[1024:])
+                norm = self._norm_ws[1024].sqrt()
+            except Exception as e:  # noqa: BLE001 - the clip is exchange plumbing, not the hot path: say so and use torch's norm
+                import warnings
+                warnings.warn(f"FlatGradSync.clip_grad_norm_: native t2v_sumsq unavailable ({e}); using torch.norm", RuntimeWarning)
+                norm = self.flat.norm(2)
         else:
             norm = self.flat.norm(2)
         scale = torch.clamp(max_norm / (norm + 1e-6), max=1.0)

@@ -4,17 +4,18 @@ passes): student forward with grad, teacher cond + uncond forwards, CFG estimate
 solver step, target forward with the student's own weights, pseudo-Huber / L2 loss, backward, flat
 gradient all-reduce, clip, optimizer step.
 
-Execution split on MI355X: the two frozen-teacher forwards run on the native HIP engine (eval, no grad).  The
-student has two paths:
+Execution split on MI355X: the two frozen-teacher forwards run on the native inference engine (eval, no grad).  The student
+(forward with grad, no-grad target forward, backward) runs on the native GRADIENT engine in both ways of calling this:
 
-* default — the modules' torch path (autograd over ATen kernels) for the student forward/backward and the no-grad
-  target forward: the reference keeps the student in train mode (LoRA / temporal-conv dropout), which the native
-  engines refuse;
-* ``student_engine=`` a ``UNetGradEngine`` with the LoRA tensors bound (``bind_lora``) — student forward, target forward
-  and the whole backward (data gradient + all token-row LoRA weight gradients) on the native engine, un-merged LoRA
-  branch, operand packs refreshed from the flat parameters once per step; only the M = B-row conditioning branch
-  (time / fps / guidance MLPs + ``emb_layers``) stays in torch autograd.  A train-mode student keeps its dropouts
-  (counter-based masks, not torch's random stream).  Needs a ``grad_sync`` flat buffer for the gradients to land in.
+* default (``student_engine=None``) — the student is called as a module, ``unet(noisy, t, **context)`` and
+  ``loss.backward()``, exactly as the reference trainer does; ``UNetModel.forward`` routes a LoRA-injected student whose only
+  trainable tensors are the LoRA ones to the gradient engine by itself (``unet3d._auto_route`` -> ``_NativeStudent``), in train
+  mode (the reference's: LoRA / temporal-conv dropouts as counter-based masks) or eval mode.  Anything the engine cannot
+  run (full fine-tuning, gradients w.r.t. the context) falls to the torch composite path with a one-time ``RuntimeWarning``;
+* ``student_engine=`` a ``UNetGradEngine`` with the LoRA tensors bound (``bind_lora``) — the same engine driven explicitly
+  (what ``bench.py`` times): un-merged LoRA branch, operand packs refreshed from the flat parameters once per step, the weight
+  gradients written straight into the ``grad_sync`` flat buffer; only the M = B-row conditioning branch (time / fps / guidance
+  MLPs + ``emb_layers``) stays in torch autograd.
 
 The gradient exchange is the single flat all-reduce of ``dist.FlatGradSync``."""
 import torch

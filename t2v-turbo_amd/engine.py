@@ -246,6 +246,18 @@ class _Engine:
         plan["owned"] = (self.pool, self.pk, self.keep)
         return plan
 
+    # A plan pins its activation pool (GBs at 16x40x64) and its hipGraph: a service that sees many batch sizes / resolutions
+    # would grow without bound.  Least-recently-used plans beyond this many are dropped (their pool and graph go with them).
+    max_plans = int(os.environ.get("T2V_MAX_PLANS", "4"))
+
+    def _keep_plan(self, key, plan):
+        """Register / refresh ``plan`` as the most recently used one and evict beyond ``max_plans``."""
+        self.plans.pop(key, None)
+        self.plans[key] = plan          # dicts keep insertion order: the first key is the least recently used
+        while len(self.plans) > max(1, self.max_plans):
+            old = next(iter(self.plans))
+            self.plans.pop(old)
+
     def buf(self, rows, cols, dtype=None, zero=False):
         return self.pool.get(rows, cols, dtype or self.adt, zero)
 
@@ -358,8 +370,9 @@ class UNetEngine(_Engine):
                                        "call .eval() on the model (after any LoRA injection) first")
             plan = self._own(self._record(x, timesteps, context, fps, timestep_cond, motion_cond))
             plan["training"] = m.training
-            self.plans[key] = plan
+            self._keep_plan(key, plan)
         else:
+            self._keep_plan(key, plan)
             st = plan["static"]
             st["x"].copy_(x)
             st["ts"].copy_(timesteps)

@@ -154,14 +154,24 @@ class LoraTrainMixin:
     def refresh_lora_packs(self):
         """Per step: flat parameters -> every bf16 operand layout, one launch.  Skipped while no LoRA tensor has changed since
         the last refresh (the target and the student forwards of one distillation step share the packs): every in-place update
-        moves a version counter (FlatAdamW.step touches one on purpose), and a re-homed parameter moves its data pointer."""
-        key = (sum(p._version for p in self.lora_params), self.lora_params[0].data_ptr(), self.lora_params[-1].data_ptr())
+        moves a version counter (FlatAdamW.step touches one on purpose), and a re-homed parameter moves its data pointer.
+        Contract: a write that moves no version counter (through ``p.data``, or through a flat buffer the tensors are ``.data``
+        views of — a restored ``flat_param``, an EMA or a custom optimizer on the flat buffer) must call
+        ``invalidate_lora_packs()``; ``FlatAdamW.step`` and ``update_ema_flat`` do (they also touch one version counter)."""
+        fp = 0
+        for p in self.lora_params:   # every version counter and every data pointer (re-homing of ANY tensor is seen)
+            fp = (fp * 1000003 + p._version * 31 + (p.data_ptr() & 0xFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFF
+        key = (fp, getattr(self, "_packs_epoch", 0))
         if key == getattr(self, "_packs_key", None):
             return
         self._packs_key = key
         self._refresh_src()
         if self.lp_used:
             self.ops.gather(self.src_flat, self.lp_idx[:self.lp_used], self.lp[:self.lp_used])
+
+    def invalidate_lora_packs(self):
+        """Force the next forward to re-gather the bf16 operand packs from the LoRA tensors (see ``refresh_lora_packs``)."""
+        self._packs_epoch = getattr(self, "_packs_epoch", 0) + 1
 
     def _lp_alloc(self, idx2d):
         """Operand pack in the arena: records its gather indices and fills it (record time only: torch indexing)."""

@@ -84,7 +84,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 # replaces the recorded plan instead of leaving one behind whose launches point into freed arenas
                 self.plans.clear()
             plan = self._own(self._record_grad(x, timesteps, context, fps, timestep_cond, motion_cond, emb_all))
-            self.plans[key] = plan
+            self._keep_plan(key, plan)
             if getattr(self.ops, "is_native", False):
                 self._replay(plan, "rec")  # recording ran the backward once and recycled the saved buffers
         else:

@@ -26,7 +26,7 @@ class VAEDecodeEngine(_Engine):
         plan = self.plans.get(key)
         if plan is None:
             plan = self._own(self._record(z, scale))
-            self.plans[key] = plan
+            self._keep_plan(key, plan)
         else:
             plan["static"]["z"].copy_(z)
             self._run(plan)
@@ -170,7 +170,7 @@ class VAEEncodeEngine(VAEDecodeEngine):
         plan = self.plans.get(key)
         if plan is None:
             plan = self._own(self._record_enc(x))
-            self.plans[key] = plan
+            self._keep_plan(key, plan)
         else:
             plan["static"]["x"].copy_(x)
             self._run(plan)

@@ -31,7 +31,7 @@ class VAEDecodeGradEngine(VAEDecodeEngine):
         plan = self.plans.get(key)
         if plan is None:
             plan = self._own(self._record_grad(z, scale))
-            self.plans[key] = plan
+            self._keep_plan(key, plan)
             if getattr(self.ops, "is_native", False):
                 # recording executed the backward list once (on a zero gradient) and that recycled the saved forward
                 # buffers: run the forward list again so the tape holds this call's activations

@@ -57,6 +57,14 @@ class LatentRecordDataset(Dataset):
         with open(path_to_csv, newline="") as f:
             self.rows = list(csv.DictReader(f))
         self.length = len(self.rows)
+        # CSV schema / parse errors are the annotation file's, not a record's: found here, once, for every row — resampling
+        # on them would spin forever.  Everything raised later, while a record file is read or checked, is a per-record fault.
+        for i, row in enumerate(self.rows):
+            for col in ("relpath", "text"):
+                if row.get(col) is None:
+                    raise KeyError(f"{path_to_csv}: row {i} lacks the column {col!r}")
+            if row.get("use_motion_guide") not in (None, ""):
+                row["use_motion_guide"] = _parse_bool(row["use_motion_guide"])
 
     def __len__(self):
         return self.length
@@ -66,7 +74,7 @@ class LatentRecordDataset(Dataset):
         relpath, text = row["relpath"], row["text"]
         root = row.get("latent_root") or self.latent_root
         latent_dir = f"{root}/{relpath}"
-        use_motion_guide = _parse_bool(row["use_motion_guide"]) if row.get("use_motion_guide") not in (None, "") else True
+        use_motion_guide = row["use_motion_guide"] if row.get("use_motion_guide") not in (None, "") else True   # parsed in __init__
         short_text = row.get("short_text") or ""
         if str(short_text) == "nan":
             short_text = ""
@@ -81,7 +89,8 @@ class LatentRecordDataset(Dataset):
 
     def __getitem__(self, idx):
         tries = 0
-        while True:  # a broken record is replaced by a random other one, as the reference does (bounded here)
+        while True:  # ANY fault of a record (missing file, damaged pickle, a webvid record without text, a text mismatch) is
+            # answered by a random other record, as the reference does (data/mp4_dataset.py:139-154); bounded here
             try:
                 latent_dict, text, short_text, use_motion_guide = self.get_latent_text_pair(idx)
                 for k in latent_dict:
@@ -90,8 +99,6 @@ class LatentRecordDataset(Dataset):
                 sample = dict(txt=text, short_txt=short_text, use_motion_guide=use_motion_guide)
                 sample.update(latent_dict)
                 return sample
-            except (KeyError, AssertionError, ValueError):
-                raise  # schema / parse errors are the CSV's, not a broken record: resampling would spin forever
             except Exception:
                 tries += 1
                 if self.length <= 1 or tries >= self.MAX_RETRIES:

@@ -27,6 +27,7 @@ class FlatAdamW:
         self.step_count = 0
         self._ops = None
         self._ws = None
+        self.after_step_hooks = []   # callables run after every step (engines that cache operand packs of the parameters)
 
     def _hip(self):
         if self._ops is None:
@@ -68,6 +69,8 @@ class FlatAdamW:
         # (engine.params_fingerprint).  Touch one parameter so that a later inference call re-packs instead of sampling with
         # the weights of the previous step.
         self.params[0].add_(0.0)
+        for hook in self.after_step_hooks:   # e.g. UNetGradEngine.invalidate_lora_packs (engine_lora.py)
+            hook()
         return norm
 
     def zero_grad(self):

@@ -367,20 +367,23 @@ def _warn_aten_route(why):
 
 
 def _flat_grad_buffer(eng, leaves):
-    """The flat fp32 gradient buffer the LoRA tensors' ``.grad`` slots are views of (``dist.FlatGradSync`` built from
-    ``lora.lora_parameters``: same order and offsets as ``bind_lora``), or None if the gradients do not live that way."""
-    first = eng.lora_params[0].grad
-    if first is None or first.dtype != torch.float32 or not first.is_contiguous():
+    """The flat fp32 gradient buffer of a ``dist.FlatGradSync`` whose slots ARE the LoRA tensors' ``.grad`` (same order and
+    offsets as ``bind_lora``), or None.  Only a buffer that announced itself (``FlatGradSync`` tags its parameters) is taken:
+    writing into ``.grad`` bypasses AccumulateGrad, so a look-alike layout owned by somebody else — DDP's
+    ``gradient_as_bucket_view`` bucket, accelerate's reducer — or any parameter with gradient hooks gets its gradients
+    through autograd instead (the hooks then fire as usual)."""
+    sync = getattr(eng.lora_params[0], "_t2v_flat_sync", None)
+    if sync is None or sync.flat.dtype != torch.float32 or sync.numel != eng.lora_numel:
         return None
-    base = first.data_ptr() - 4 * eng.lora_off[id(eng.lora_params[0])]
+    base = sync.flat.data_ptr()
     for p in eng.lora_params:
         g = p.grad
-        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.data_ptr() != base + 4 * eng.lora_off[id(p)]:
+        if getattr(p, "_t2v_flat_sync", None) is not sync or g is None or g.dtype != torch.float32 or not g.is_contiguous() \
+                or g.data_ptr() != base + 4 * eng.lora_off[id(p)]:
             return None
-    off0 = first.storage_offset() - eng.lora_off[id(eng.lora_params[0])]
-    if off0 < 0 or first.untyped_storage().nbytes() < 4 * (off0 + eng.lora_numel):
-        return None
-    return torch.as_strided(first, (eng.lora_numel,), (1,), off0)
+        if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+            return None
+    return sync.flat
 
 
 class _NativeStudent(torch.autograd.Function):

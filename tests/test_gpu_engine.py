@@ -264,6 +264,43 @@ def test_unet_full_width_c2_config_vs_oracle():
     assert rel_l2(y_f, ref) < E2E_TOL and rel_l2(y_f, ys[0]) < E2E_TOL   # two bf16 roundings of one network: each ~1.7e-2 from fp32
 
 
+def test_unet_full_width_motion_cond_config_c4_vs_oracle():
+    """BASELINE configs[3] (T2V-Turbo-v2 sampling): the motion-conditioned UNet (`unet_mg`: motion_cond_proj_dim = 256,
+    pipeline/t2v_turbo_vc2_pipeline.py:190-204) at the VC2 widths on latent (1,4,16,40,64), bf16 device path vs the fp32 CPU
+    oracle, at a timestep of the 16-step grid above the motion threshold (t >= 700): the forward bench.py's clip_16step_v2 runs."""
+    import bench
+    from t2v_turbo_amd.nn_util import guidance_embedding
+    from t2v_turbo_amd.unet3d import UNetModel
+    dev = torch.device("cuda", 0)
+    cfg = dict(bench.VC2_UNET, motion_cond_proj_dim=256)
+    torch.manual_seed(1234)
+    with torch.device(dev):
+        model = UNetModel(**cfg)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    with torch.no_grad():
+        for p in model.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0.0, 0.02, generator=g)
+    model = model.to(torch.bfloat16).eval()
+    model.dtype = torch.bfloat16
+    x, ctx, tc = bench.synth_inputs(dev, torch.bfloat16)
+    mc = guidance_embedding(torch.tensor([0.1]), 256).to(dev, torch.bfloat16)
+    ts = torch.tensor([939], device=dev)
+    with torch.no_grad():
+        ys = [model(x, ts, context=ctx, fps=16, timestep_cond=tc, motion_cond=mc).float().cpu() for _ in range(2)]
+        y_off = model(x, ts, context=ctx, fps=16, timestep_cond=tc,
+                      motion_cond=guidance_embedding(torch.tensor([0.0]), 256).to(dev, torch.bfloat16)).float().cpu()
+    assert model._engine_box.engine is not None and torch.isfinite(ys[0]).all() and torch.equal(ys[0], ys[1])
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    ref = uo.unet_forward(sd, cfg, x.float().cpu(), ts.cpu(), ctx.float().cpu(), fps=16, timestep_cond=tc.float().cpu(),
+                          motion_cond=mc.float().cpu())
+    err = rel_l2(ys[0], ref)
+    print(f"full-width C4 (motion cond) parity: rel-L2 {err:.3e}; motion embedding on vs off: {rel_l2(y_off, ys[0]):.3e}")
+    assert err < E2E_TOL, err
+    assert rel_l2(y_off, ys[0]) > 1e-3, "the motion-guidance embedding must reach the output"
+
+
 def test_rccl_world_size_1_flat_gradient_all_reduce():
     """The RCCL path of dist.py (backend "nccl" = RCCL on ROCm) on the one GPU there is: a one-rank communicator, one
     all-reduce of the v1 LoRA gradient buffer (117.1 M fp32 = 468.6 MB, train_t2v_turbo_v1_lora.py:1190), mean semantics."""

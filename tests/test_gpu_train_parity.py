@@ -1,0 +1,345 @@
+"""-m gpu: hardware parity of the LoRA TRAINING path at the size it is timed on, and of the route the trainer takes.
+
+The distillation step `bench.py` times (`distill_step` leg: VideoCrafter2 widths, latent (1,4,16,40,64), LoRA r = 64) runs the
+student on the native gradient engine.  These tests gate that path on MI355X the way `test_gpu_engine.py` gates inference:
+
+  (i)   full-width student forward + backward on the device vs fp32 CPU autograd through the torch module
+        (utils/lora.py:45-50,124-129,204-209 forward; train_t2v_turbo_v1_lora.py:1022-1028,1190 backward): output, d/d(latents)
+        and EVERY LoRA tensor's gradient by cosine and norm ratio (a scale slip on one leaf fails);
+  (ii)  tiny width DIRECTLY against tests/golden/unet_tiny_lora_grad.npz — gradients the reference itself computed;
+  (iii) the trainer's route: `unet(...)` -> `_NativeStudent` -> `loss.backward()` inside `distill.distill_step`, two steps with a
+        `FlatAdamW` update between them; the second step must have seen the update (operand packs refreshed);
+  (iv)  train mode: the engine's counter-based dropout masks replayed inside the torch module (tests/mask_replay.py).
+
+Tolerances (bf16 device path vs fp32 reference): output <= 3e-2 rel-L2, d/d(latents) <= 6e-2, LoRA gradients per tensor
+cosine >= 0.99 and norm within 10 % (tiny width: >= 0.985 — 64-channel GroupNorm groups of 2 channels are noisier)."""
+import os
+import time
+
+import pytest
+import torch
+
+from tests.util import load, manifest, rel_l2, tiny_unet_params
+
+pytestmark = pytest.mark.gpu
+
+OUT_TOL, DX_TOL = 3e-2, 6e-2
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
+
+
+def _per_tensor(params, flat, cond_grads, refs, names):
+    """[(name, cosine, norm ratio, ref norm)] per LoRA tensor: engine leaves from the flat buffer, conditioning leaves from torch."""
+    rows, off = [], 0
+    for p, r in zip(params, refs):
+        g = flat[off:off + p.numel()].view_as(p).float().cpu()
+        off += p.numel()
+        cg = cond_grads.get(id(p))
+        if cg is not None:
+            g = g + cg.float().cpu()
+        rn = float(r.double().norm())
+        if rn == 0.0:
+            assert float(g.abs().max()) < 1e-6, names[id(p)]
+            continue
+        rows.append((names[id(p)], _cos(g, r), float(g.double().norm()) / rn, rn))
+    return rows
+
+
+def _report(tag, rows, cos_min, ratio_tol):
+    import statistics
+    cs = [r[1] for r in rows]
+    rt = [abs(r[2] - 1.0) for r in rows]
+    worst = sorted(rows, key=lambda r: r[1])[:5]
+    print(f"[{tag}] {len(rows)} LoRA tensors: cosine min {min(cs):.4f} median {statistics.median(cs):.5f}; "
+          f"|norm ratio - 1| max {max(rt):.3f} median {statistics.median(rt):.4f}; worst: "
+          + ", ".join(f"{n} cos {c:.4f} ratio {q:.3f}" for n, c, q, _ in worst), flush=True)
+    bad = [r for r in rows if r[1] < cos_min or abs(r[2] - 1.0) > ratio_tol]
+    assert not bad, bad[:8]
+
+
+# ------------------------------------------------------------------------------------------------------------- (i)
+def test_student_full_width_forward_backward_vs_cpu_autograd():
+    """VC2 widths, latent (1,4,16,40,64), r = 64, eval mode: the configuration of bench.py's distill_step leg."""
+    import bench
+    from t2v_turbo_amd import lora
+    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+    from t2v_turbo_amd.native import HipOps
+    from t2v_turbo_amd.unet3d import UNetModel
+    t0 = time.time()
+    dev = torch.device("cuda", 0)
+    with torch.device(dev):
+        student = UNetModel(**bench.VC2_UNET)
+    g = torch.Generator(device=dev).manual_seed(4321)
+    with torch.no_grad():
+        for p in student.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0.0, 0.02, generator=g)
+    student.requires_grad_(False)
+    lora.inject_trainable_lora_extended(student, r=64)
+    params = lora.lora_parameters(student)
+    with torch.no_grad():
+        for p in params:   # lora_up starts at zero: every lora_down gradient would be zero
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0.0, 0.02, generator=g)
+    student.eval()
+    assert len(params) == 1150 and sum(p.numel() for p in params) == 117_142_176  # the v1 all-reduce payload
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, 16, 40, 64, generator=gen)
+    ctx = torch.randn(1, 77, 1024, generator=gen)
+    tc = torch.randn(1, 256, generator=gen)
+    r_out = torch.randn(x.shape, generator=gen)
+    ts = torch.tensor([519])
+    # ---- device: forward + backward on the gradient engine ------------------------------------------------------------
+    eng = UNetGradEngine(student, HipOps())
+    eng.bind_lora(params)
+    ys, dxs, flats = [], [], []
+    for rep in range(2):   # recording pass, then the replayed launch lists
+        emb_all = student.conditioning_emb_all(ts.to(dev), 16, tc.to(dev))
+        y = eng.forward_tape(x.to(dev), ts.to(dev), ctx.to(dev), 16, tc.to(dev), None, emb_all=emb_all)
+        flat = torch.zeros(eng.lora_numel, device=dev)
+        dx = eng.backward(r_out.to(dev), flat_grad=flat, accumulate=False)
+        for p in params:
+            p.grad = None
+        emb_all.backward(eng.d_emb_all)
+        ys.append(y.float().cpu()); dxs.append(dx.float().cpu()); flats.append(flat.cpu())
+    cond = {id(p): p.grad.detach().clone() for p in params if p.grad is not None}
+    assert torch.isfinite(ys[0]).all() and torch.isfinite(dxs[0]).all() and torch.isfinite(flats[0]).all()
+    assert rel_l2(ys[1], ys[0]) < 1e-6 and rel_l2(dxs[1], dxs[0]) < 1e-6 and rel_l2(flats[1], flats[0]) < 1e-5
+    print(f"device side done (+{time.time() - t0:.0f}s): {len(eng._last['rec'])} forward / {len(eng._last['rec_bwd'])} backward launches",
+          flush=True)
+    # ---- host: fp32 autograd through the torch module (oracle/lora_grad_oracle.py; checkpointing bounds the host memory) ----
+    from oracle.lora_grad_oracle import student_reference
+    y_ref, dx_ref, g_ref = student_reference(student.state_dict(), bench.VC2_UNET, 64, x, ts, ctx, 16, tc, r_out,
+                                             threads=min(os.cpu_count() or 1, 64))
+    print(f"host reference done (+{time.time() - t0:.0f}s)", flush=True)
+    e_out, e_dx = rel_l2(ys[0], y_ref), rel_l2(dxs[0], dx_ref)
+    print(f"[full width] out rel-L2 {e_out:.3e}  d/d(latents) rel-L2 {e_dx:.3e}", flush=True)
+    names = {id(p): n for n, p in student.named_parameters()}
+    rows = _per_tensor(params, flats[0], cond, g_ref, names)
+    _report("full width", rows, 0.99, 0.10)
+    assert e_out < OUT_TOL and e_dx < DX_TOL, (e_out, e_dx)
+
+
+# ------------------------------------------------------------------------------------------------------------- (ii)
+def _tiny_student(rank, draw, **cfg):
+    from oracle.synth import synth_state_dict
+    from t2v_turbo_amd import lora
+    from t2v_turbo_amd.unet3d import UNetModel
+    m = UNetModel(**tiny_unet_params(**cfg)).eval()
+    m.load_state_dict(synth_state_dict(manifest("unet_tiny")), strict=True)
+    m.requires_grad_(False)
+    lora.inject_trainable_lora_extended(m, r=rank)
+    params = lora.lora_parameters(m)
+    draw(params)
+    m.eval()
+    return m, params
+
+
+def _engine_step_gpu(eng, m, params, x, ts, ctx, tc, r_out, seed=None, dev="cuda"):
+    emb_all = m.conditioning_emb_all(ts.to(dev), 16, tc.to(dev))
+    y = eng.forward_tape(x.to(dev), ts.to(dev), ctx.to(dev), 16, tc.to(dev), None, emb_all=emb_all, seed=seed)
+    flat = torch.zeros(eng.lora_numel, device=dev)
+    dx = eng.backward(r_out.to(dev), flat_grad=flat, accumulate=False)
+    for p in params:
+        p.grad = None
+    emb_all.backward(eng.d_emb_all)
+    grads, off = [], 0
+    for p in params:
+        gr = flat[off:off + p.numel()].view_as(p)
+        grads.append((gr if p.grad is None else gr + p.grad).float().cpu())
+        off += p.numel()
+    return y.float().cpu(), dx.float().cpu(), grads
+
+
+def test_tiny_student_on_device_vs_the_reference_lora_gradient_fixture():
+    """unet_tiny_lora_grad.npz was computed by the REFERENCE (its UNetModel, its inject_trainable_lora_extended, autograd):
+    the device engine is compared with it directly — output, d/d(latents), per-tensor norm and two random projections of all
+    1150 gradients, the four rank-4 leaves in full."""
+    from t2v_turbo_amd import lora
+    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+    from t2v_turbo_amd.native import HipOps
+    from tests.golden.make_golden_lora_grad import SEED_R, digests, draw_lora
+    g, gg = load("unet_tiny"), load("unet_tiny_lora_grad")
+    m, params = _tiny_student(64, draw_lora)
+    m = m.cuda()
+    params = lora.lora_parameters(m)
+    assert len(params) == 2 * int(gg["n_leaves"]) == 1150
+    eng = UNetGradEngine(m, HipOps())
+    eng.bind_lora(params)
+    x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(SEED_R))
+    for rep in range(2):
+        y, dx, grads = _engine_step_gpu(eng, m, params, x, ts, ctx, tc, r_out)
+        e_out, e_dx = rel_l2(y, gg["out"]), rel_l2(dx, gg["dx"])
+        d, ref = torch.from_numpy(digests(grads)), gg["digests"]
+        norm_err = ((d[:, 0] - ref[:, 0]).abs() / ref[:, 0])
+        proj_err = ((d[:, 1:] - ref[:, 1:]).abs() / ref[:, :1])
+        print(f"[fixture, pass {rep}] out {e_out:.3e} dx {e_dx:.3e}; norm err max {float(norm_err.max()):.3f} median "
+              f"{float(norm_err.median()):.4f}; projection err / norm max {float(proj_err.max()):.3f} median "
+              f"{float(proj_err.median()):.4f}", flush=True)
+        assert e_out < OUT_TOL and e_dx < DX_TOL
+        assert float(norm_err.max()) < 0.10, int(norm_err.argmax())
+        assert float(proj_err.max()) < 0.30 and float(proj_err.median()) < 0.06, int(proj_err.max(dim=1).values.argmax())
+        for k in ("g10", "g11", "g1148", "g1149"):
+            assert rel_l2(grads[int(k[1:])], gg[k]) < 0.12, k
+
+
+# ------------------------------------------------------------------------------------------------------------- (iv)
+def test_train_mode_student_on_device_with_replayed_masks():
+    """Train mode is what the step is timed in.  The device draws counter-based masks; the same masks (regenerated on the host
+    from the recorded site geometry, bit-identical by tests/test_gpu_unet_grad.py::test_dropout_mask_is_the_emulated_one) are
+    patched into the fp32 torch module on the CPU: output, d/d(latents) and every LoRA gradient must agree."""
+    from t2v_turbo_amd.native import HipOps
+    run_train_mode_with_replayed_masks("cuda", HipOps(), OUT_TOL, DX_TOL, 0.985, 0.12)
+
+
+def run_train_mode_with_replayed_masks(dev, ops, out_tol, dx_tol, cos_min, ratio_tol):
+    import copy
+    from t2v_turbo_amd import lora
+    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+    from tests.mask_replay import SiteGeometrySpy, patch_engine_masks
+    from tests.test_unet_lora_grad_cpu import _autograd
+
+    def draw(params):
+        gen = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for p in params:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.05)
+
+    g = load("unet_tiny")
+    ref, rparams = _tiny_student(64, draw)
+    m = copy.deepcopy(ref).to(dev)
+    params = lora.lora_parameters(m)
+    m.train(); ref.train()
+    spy = SiteGeometrySpy(ops)
+    eng = UNetGradEngine(m, ops)
+    eng.bind_lora(params)
+    mine = set(map(id, eng.engine_leaves()))
+    for mod_d, mod_h in zip(m.modules(), ref.modules()):   # the conditioning branch is torch's in both runs: no random masks there
+        if hasattr(mod_d, "lora_up") and id(mod_d) not in mine:
+            mod_d.dropout.eval(); mod_h.dropout.eval()
+    x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
+    seed = 0x5EED_1234_ABCD
+    y, dx, grads = _engine_step_gpu(eng, m, params, x, ts, ctx, tc, r_out, seed=seed, dev=dev)       # recording pass
+    y2, dx2, grads2 = _engine_step_gpu(eng, m, params, x, ts, ctx, tc, r_out, seed=seed, dev=dev)    # replayed lists, same seed
+    assert torch.equal(y, y2) and rel_l2(dx2, dx) < 1e-6
+    y3, _, _ = _engine_step_gpu(eng, m, params, x, ts, ctx, tc, r_out, seed=seed + 1, dev=dev)
+    assert rel_l2(y3, y) > 1e-3, "a new seed must draw new masks"
+    sites = eng.drop_sites
+    assert len(sites) > 100 and set(spy.sites) == set(range(len(sites)))
+    masks = spy.masks(seed)
+    keep = torch.cat([masks[i].reshape(-1).float() for i in range(len(sites))]).mean()
+    assert abs(float(keep) - 0.9) < 2e-3
+    patch_engine_masks(ref, eng, masks)
+    y_ref, dx_ref, g_ref = _autograd(ref, rparams, x, ts, ctx, 16, tc, None, r_out)
+    e_out, e_dx = rel_l2(y, y_ref), rel_l2(dx, dx_ref)
+    print(f"[train mode] out {e_out:.3e} dx {e_dx:.3e}", flush=True)
+    names = {id(p): n for n, p in m.named_parameters()}
+    rows = []
+    for p, gq, r in zip(params, grads, g_ref):
+        rn = float(r.double().norm())
+        if rn == 0.0:
+            assert float(gq.abs().max()) < 1e-6
+            continue
+        rows.append((names[id(p)], _cos(gq, r), float(gq.double().norm()) / rn, rn))
+    _report("train mode, tiny", rows, cos_min, ratio_tol)
+    assert e_out < out_tol and e_dx < dx_tol
+
+
+# ------------------------------------------------------------------------------------------------------------- (iii)
+def test_trainer_route_two_distill_steps_with_an_optimizer_update_between():
+    """What train_t2v_turbo_v1_lora.py does with the drop-in classes: `unet(noisy, t, **context)` under autocast ->
+    `loss.backward()` -> clip -> optimizer step, twice.  The module routes itself to the gradient engine (`_auto_route` ->
+    `_NativeStudent`); the frozen teacher to the inference engine.  Reference: the same two steps through the torch composite
+    path in fp32 (ATen, same GPU), its parameters set to the device run's parameters before each step, so that step 2 checks
+    that the engine's operand packs followed the FlatAdamW update (control: the reference with the OLD parameters is worse)."""
+    run_trainer_route(torch.device("cuda", 0), None, 0.08, 0.97)
+
+
+def run_trainer_route(dev, emu_factory, loss_tol, cos_min):
+    """``emu_factory``: CPU dry run of the same body on the emulated op backend (tests/test_train_parity_cpu.py)."""
+    import copy
+    import warnings
+    from t2v_turbo_amd import cd_math, lora
+    from t2v_turbo_amd.dist import FlatGradSync
+    from t2v_turbo_amd.distill import distill_step
+    from t2v_turbo_amd.optim import FlatAdamW
+    from t2v_turbo_amd.scheduler import T2VTurboScheduler
+    from t2v_turbo_amd.unet3d import UNetModel
+    from oracle.synth import synth_state_dict
+
+    def draw(params):
+        gen = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for p in params:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.05)
+
+    on_gpu = emu_factory is None
+    sd = synth_state_dict(manifest("unet_tiny"))
+    teacher32 = UNetModel(**tiny_unet_params(time_cond_proj_dim=None)).eval()
+    teacher32.load_state_dict({k: v for k, v in sd.items() if not k.startswith("time_cond_proj")}, strict=True)
+    teacher32.requires_grad_(False)
+    if on_gpu:
+        teacher = copy.deepcopy(teacher32).to(dev, torch.bfloat16)
+        teacher.dtype = torch.bfloat16
+    else:
+        teacher = copy.deepcopy(teacher32)
+    teacher32 = teacher32.to(dev)
+    teacher32.native_mode = "off"
+    base, _ = _tiny_student(16, draw)
+    student = copy.deepcopy(base).to(dev)           # device run: native_mode "auto"
+    if not on_gpu:
+        student._native_ops_factory = emu_factory
+        student.native_mode = "train"
+    ref = copy.deepcopy(base).to(dev)               # reference: torch composite, fp32
+    ref.native_mode = "off"
+    sched = T2VTurboScheduler()
+    solver = cd_math.DDIMSolver(sched.alphas_cumprod.numpy(), ddim_timesteps=50).to(dev)
+    gen = torch.Generator().manual_seed(0)
+    lat = torch.randn(2, 4, 2, 8, 8, generator=gen).to(dev)
+    pe, ue = torch.randn(2, 77, 128, generator=gen).to(dev), torch.randn(2, 77, 128, generator=gen).to(dev)
+    rngs = [dict(index=torch.tensor([3, 40], device=dev), noise=torch.randn(lat.shape, generator=gen).to(dev), w=torch.tensor([6.0, 11.5])),
+            dict(index=torch.tensor([25, 9], device=dev), noise=torch.randn(lat.shape, generator=gen).to(dev), w=torch.tensor([14.0, 5.5]))]
+    params = lora.lora_parameters(student)
+    sync = FlatGradSync(params)
+    opt = FlatAdamW(params, sync, lr=2e-2, weight_decay=0.0)
+    rparams = lora.lora_parameters(ref)
+    rsync = FlatGradSync(rparams)
+    kw = dict(loss_type="l2", max_grad_norm=1e9)
+
+    def ref_step(rng, flat_param):
+        with torch.no_grad():
+            off = 0
+            for p in rparams:
+                p.copy_(flat_param[off:off + p.numel()].view_as(p)); off += p.numel()
+        loss, _ = distill_step(ref, teacher32, solver, sched, lat, pe, ue, grad_sync=rsync, rng=rng, **kw)
+        return float(loss.detach()), rsync.flat.clone()
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)   # the ATen fallback announces itself with a RuntimeWarning: not here
+        p0 = opt.flat_param.clone()
+        loss1, _ = distill_step(student, teacher, solver, sched, lat, pe, ue, optimizer=opt, grad_sync=sync, rng=rngs[0],
+                                autocast_dtype=torch.bfloat16 if on_gpu else None, **kw)
+        g1 = sync.flat.clone()
+        p1 = opt.flat_param.clone()
+        loss2, _ = distill_step(student, teacher, solver, sched, lat, pe, ue, optimizer=opt, grad_sync=sync, rng=rngs[1],
+                                autocast_dtype=torch.bfloat16 if on_gpu else None, **kw)
+        g2 = sync.flat.clone()
+    box = student._engine_box
+    assert box.grad is not None and box.enc is not None, "student forward / target forward did not run on the gradient engine"
+    assert not on_gpu or teacher._engine_box.engine is not None, "the teacher did not run on the inference engine"
+    assert len(box.grad.plans) == 1 and box.grad._last["fwd_id"] >= 2, "step 2 must replay step 1's recorded plan"
+    assert float((p1 - p0).abs().mean()) > 1e-2, "the optimizer did not move the parameters"
+    r_loss1, r_g1 = ref_step(rngs[0], p0)
+    r_loss2, r_g2 = ref_step(rngs[1], p1)
+    _, r_g2_old = ref_step(rngs[1], p0)
+    c1, c2, c2_old = _cos(g1, r_g1), _cos(g2, r_g2), _cos(g2, r_g2_old)
+    print(f"[trainer route] loss {float(loss1):.5f} / {float(loss2):.5f} vs fp32 {r_loss1:.5f} / {r_loss2:.5f}; flat-gradient cosine "
+          f"step 1 {c1:.4f}, step 2 {c2:.4f} (against the pre-update parameters: {c2_old:.4f})", flush=True)
+    assert abs(float(loss1) - r_loss1) < loss_tol * abs(r_loss1) and abs(float(loss2) - r_loss2) < loss_tol * abs(r_loss2)
+    assert c1 > cos_min and c2 > cos_min
+    assert c2 - c2_old > 0.03, "step 2 looks like it ran on the parameters of step 1: operand packs not refreshed"

@@ -101,14 +101,45 @@ def test_dataset_reads_the_boolean_spellings_pandas_writes_and_fails_loudly_on_b
     with open(tmp_path / "lat" / "a.pkl", "wb") as f:
         f.write(latent_io.pack_latent_record(**_record(), text="a cat"))
     rows = [("True", True), ("False", False), ("1.0", True), ("0", False), ("", True), ("true", True)]
-    with open(tmp_path / "meta.csv", "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["relpath", "text", "use_motion_guide", "short_text"])
-        for v, _ in rows:
-            w.writerow(["a.pkl", "a cat", v, "cat"])
-        w.writerow(["a.pkl", "a cat", "maybe", "cat"])
+
+    def write(extra):
+        with open(tmp_path / "meta.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["relpath", "text", "use_motion_guide", "short_text"])
+            for v, _ in rows:
+                w.writerow(["a.pkl", "a cat", v, "cat"])
+            for r in extra:
+                w.writerow(r)
+
+    write([])
     ds = latent_io.LatentRecordDataset(str(tmp_path / "meta.csv"), latent_root="lat", root_dir=str(tmp_path))
     for i, (_, want) in enumerate(rows):
         assert ds[i]["use_motion_guide"] is want
+    # schema / parse errors belong to the annotation file: raised when it is opened, for any row, never resampled away
+    write([["a.pkl", "a cat", "maybe", "cat"]])
     with pytest.raises(ValueError):
-        ds[len(rows)]
+        latent_io.LatentRecordDataset(str(tmp_path / "meta.csv"), latent_root="lat", root_dir=str(tmp_path))
+
+
+def test_dataset_resamples_on_any_per_record_fault(tmp_path):
+    """data/mp4_dataset.py:139-154 answers ANY exception of a record with a random other record: a missing file, a damaged
+    pickle, a text that does not match the CSV, a webvid record without text must not abort a long training run."""
+    import random
+    os.makedirs(tmp_path / "lat" / "webvid")
+    with open(tmp_path / "lat" / "good.pkl", "wb") as f:
+        f.write(latent_io.pack_latent_record(**_record(), text="a cat"))
+    with open(tmp_path / "lat" / "mismatch.pkl", "wb") as f:
+        f.write(latent_io.pack_latent_record(**_record(), text="a dog"))
+    with open(tmp_path / "lat" / "damaged.pkl", "wb") as f:
+        f.write(b"\x80\x04not a pickle")
+    with open(tmp_path / "lat" / "webvid" / "notext.pkl", "wb") as f:
+        f.write(latent_io.pack_latent_record(**_record()))
+    with open(tmp_path / "meta.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["relpath", "text"])
+        for rel in ("good.pkl", "mismatch.pkl", "damaged.pkl", "webvid/notext.pkl", "missing.pkl"):
+            w.writerow([rel, "a cat"])
+    ds = latent_io.LatentRecordDataset(str(tmp_path / "meta.csv"), latent_root="lat", root_dir=str(tmp_path))
+    random.seed(0)
+    for i in range(5):
+        assert ds[i]["txt"] == "a cat"      # every faulty row ends up on the one good record

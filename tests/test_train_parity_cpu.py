@@ -1,0 +1,39 @@
+"""CPU dry runs (emulated op backend, fp32) of the bodies of tests/test_gpu_train_parity.py: the trainer's route through
+``unet(...)`` -> ``_NativeStudent`` -> ``loss.backward()`` with a FlatAdamW update between two steps, and the train-mode mask
+replay with the masks REGENERATED from the recorded site geometry (what the GPU test has to do: the device keeps no masks)."""
+import torch
+
+from tests.emu_ops import EmuOps
+from tests.test_gpu_train_parity import run_train_mode_with_replayed_masks, run_trainer_route
+
+
+def test_trainer_route_two_steps_cpu():
+    run_trainer_route(torch.device("cpu"), lambda: EmuOps(strict=True), 1e-4, 0.9999)
+
+
+def test_train_mode_regenerated_masks_cpu():
+    run_train_mode_with_replayed_masks("cpu", EmuOps(strict=True), 2e-5, 1e-4, 0.99999, 1e-3)
+
+
+def test_lora_grad_oracle_reproduces_the_reference_fixture():
+    """oracle/lora_grad_oracle.student_reference (the checker of the GPU training-parity tests and of bench.py's distillation
+    parity gate) against gradients the reference itself computed: tests/golden/unet_tiny_lora_grad.npz."""
+    from oracle.lora_grad_oracle import per_tensor_agreement, student_reference
+    from oracle.synth import synth_state_dict
+    from t2v_turbo_amd import lora
+    from t2v_turbo_amd.unet3d import UNetModel
+    from tests.golden.make_golden_lora_grad import SEED_R, digests, draw_lora
+    from tests.util import load, manifest, rel_l2, tiny_unet_params
+    g, gg = load("unet_tiny"), load("unet_tiny_lora_grad")
+    m = UNetModel(**tiny_unet_params()).eval()
+    m.load_state_dict(synth_state_dict(manifest("unet_tiny")), strict=True)
+    m.requires_grad_(False)
+    lora.inject_trainable_lora_extended(m, r=64)
+    draw_lora(lora.lora_parameters(m))
+    r_out = torch.randn(g["x"].shape, generator=torch.Generator().manual_seed(SEED_R))
+    y, dx, grads = student_reference(m.state_dict(), tiny_unet_params(), 64, g["x"], g["ts"], g["ctx"], 16, g["tc"], r_out)
+    assert rel_l2(y, gg["out"]) < 2e-5 and rel_l2(dx, gg["dx"]) < 1e-4
+    d, ref = torch.from_numpy(digests(grads)), gg["digests"]
+    assert float(((d[:, 0] - ref[:, 0]).abs() / ref[:, 0]).max()) < 1e-4
+    rows, zeros = per_tensor_agreement(grads, grads)
+    assert not zeros and all(abs(c - 1) < 1e-12 and abs(q - 1) < 1e-12 for _, c, q in rows)

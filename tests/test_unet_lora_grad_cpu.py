@@ -193,7 +193,6 @@ def test_train_mode_dropout_masks_and_gradients():
     The engine draws counter-based masks (t2v_dropout_bf16) and regenerates them in the backward; torch's own random stream
     cannot be matched, so the masks the engine used are replayed inside the torch module (re-laid into torch's row orders)
     and everything — output, d/d(latents), all LoRA gradients — must agree with autograd."""
-    from t2v_turbo_amd.unet3d import GEGLU
     g = load("unet_tiny")
     m, params = _student("unet_tiny", 64)
     m.train()
@@ -222,49 +221,9 @@ def test_train_mode_dropout_masks_and_gradients():
     assert n_lora > 100 and len(sites) - n_lora > 20
     keep_frac = torch.cat([eng.ops.masks[i].reshape(-1).float() for i in range(len(sites))]).mean()
     assert abs(float(keep_frac) - 0.9) < 2e-3
-    # ---- replay the masks in the torch module ------------------------------------------------------------------------
-    leaf_of = {id(mod.dropout): mod for mod in m.modules() if hasattr(mod, "lora_up")}
-    geglu = {id(mod.proj) for mod in m.modules() if isinstance(mod, GEGLU)}
-
-    def patch(drop, keep, kind, meta, p):
-        def fwd(t):
-            if kind == "rows":
-                k = keep.reshape(t.shape)
-            elif kind == "temporal":
-                B, F, hw = meta
-                k = keep.view(B, F, hw, -1).permute(0, 2, 1, 3).reshape(t.shape)
-            elif kind == "ctx":
-                B, F, L = meta
-                k = keep.view(B, 1, L, -1).expand(B, F, L, keep.shape[1]).reshape(t.shape)
-            elif kind == "conv":
-                n, ho, wo = meta
-                k = keep.view(n, ho, wo, -1).permute(0, 3, 1, 2)
-            else:
-                B, F, h, w = meta
-                k = keep.view(B, F, h, w, -1).permute(0, 4, 1, 2, 3)
-            assert k.shape == t.shape, (kind, k.shape, t.shape)
-            return t * k / (1.0 - p)
-        drop.forward = fwd
-
-    for sid, (drops, kind, meta) in enumerate(sites):
-        keep = eng.ops.masks[sid]
-        c0 = 0
-        for d in drops:
-            if kind == "tconv":
-                patch(d, keep, kind, meta, d.p)
-                continue
-            leaf = leaf_of[id(d)]
-            n_out = leaf.lora_up.weight.shape[0]
-            k = keep[:, c0:c0 + n_out]
-            if id(leaf) in geglu:  # the engine's columns are the packed GEGLU rows
-                j = torch.arange(n_out)
-                perm = (j // 64) * 32 + (j % 32) + (j % 64 >= 32) * (n_out // 2)
-                full = torch.empty_like(k)
-                full[:, perm] = k
-                k = full
-            patch(d, k.contiguous(), kind, meta, d.p)
-            c0 += n_out
-        assert kind == "tconv" or c0 == keep.shape[1]
+    # ---- replay the masks in the torch module (tests/mask_replay.py, shared with the GPU suite) --------------------------
+    from tests.mask_replay import patch_engine_masks
+    patch_engine_masks(m, eng, eng.ops.masks)
     y_ref, dx_ref, g_ref = _autograd(m, params, x, ts, ctx, 16, tc, None, r_out)
     assert rel_l2(y, y_ref) < 2e-5
     assert rel_l2(dx, dx_ref) < 1e-4

@@ -11,7 +11,7 @@ Writes t2v-turbo_amd/gemm_tune.json, which native.HipOps loads at start-up.
 Two passes per shape keep a sweep affordable: every candidate is screened with a handful of eager back-to-back
 launches (the queue stays full, so the event pair around them is device time), and only those within 15 % of the best
 are re-timed inside a hipGraph.  After a full sweep the candidates within 25 % of each shape's best are written to
-t2v-turbo_amd/gemm_tune_candidates.json; later runs (after a kernel change) re-time only those unless --full 1.
+tools/gemm_tune_candidates.json; later runs (after a kernel change) re-time only those unless --full 1.
 """
 import argparse
 import ctypes as C
@@ -104,7 +104,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--vae", type=int, default=1)
     ap.add_argument("--full", type=int, default=0, help="sweep every (tile, split) even where a candidate list exists")
-    ap.add_argument("--candidates", default=os.path.join(ROOT, "t2v-turbo_amd", "gemm_tune_candidates.json"))
+    ap.add_argument("--candidates", default=os.path.join(ROOT, "tools", "gemm_tune_candidates.json"))
     ap.add_argument("--out", default=os.path.join(ROOT, "t2v-turbo_amd", "gemm_tune.json"))
     ap.add_argument("--widen", type=int, default=1, help="also tune the VAE encode / decode-gradient / ModelScope shapes")
     ap.add_argument("--cold", type=int, default=0, help="evict caches before every timed launch (what the UNet step sees)")
