@@ -112,9 +112,36 @@ typedef struct t2v_gemm_desc {
     float ln_eps;
     void* ln_out;
     int ld_ln_out;
+    /* ---- normalisation statistics as by-products of the producing GEMM, LayerNorm folded into the consuming one ----------
+     * (all NULL = off; honoured by the fast kernels only: ask t2v_gemm_fuse_supported first, t2v_gemm refuses otherwise)
+     *
+     * rowstat_out [M][ld_rowstat] fp32: for every output row and every 32-column block b the pair (sum, sum of squares) of the
+     * fp32 epilogue values at floats [2b, 2b+1] — the row statistics the NEXT LayerNorm needs (attention.py:300-311), written
+     * by the GEMM that produces its input instead of a pass over the tensor.  N % 32 == 0, ld_rowstat >= N/16, % 4 == 0.
+     *
+     * colstat_out [M/32][N][2] fp32: for every 32-row slab and every column (sum, sum of squares) of the bf16-ROUNDED outputs —
+     * what GroupNorm (openaimodel3d.py:223-254, lvdm/basics.py:78-89) reduces per (unit, group); t2v_group_norm_cs finishes
+     * them for any unit whose row count is a multiple of 32.  M % 32 == 0.
+     *
+     * lnf_stats: this launch CONSUMES LayerNorm(x) without x ever being normalised in memory: A holds the raw rows x [M][C],
+     * W holds W diag(gamma) (bf16), lnf_s[n] = sum_c W'[n][c] (fp32, of the bf16-rounded W'), bias[n] = b[n] + sum_c W[n][c]
+     * beta[c]; with (mean_m, rstd_m) from the producer's rowstat (lnf_nblk blocks of 32 columns, C = 32 lnf_nblk):
+     *     out[m][n] = rstd_m * (acc[m][n] - mean_m * lnf_s[n]) + bias[n]      (then GEGLU / activation as usual)
+     * LINEAR mode, no batch, no residual / rowvec / dropout, alpha == 1. */
+    float* rowstat_out;
+    int ld_rowstat;
+    float* colstat_out;
+    const float* lnf_stats;
+    int lnf_ld, lnf_nblk;
+    float lnf_eps;
+    const float* lnf_s;
 } t2v_gemm_desc;
 
 int t2v_gemm(const t2v_gemm_desc* d, void* stream);
+/* 1 if t2v_gemm would honour the descriptor's rowstat_out / colstat_out / lnf_stats fields (it resolves the tile and the
+ * split-K factor exactly as the launch does: fast kernel, one K split, a tile that carries the fused epilogue), 0 if the
+ * caller has to use the standalone normalisation kernels, negative on an invalid descriptor.  Launches nothing. */
+int t2v_gemm_fuse_supported(const t2v_gemm_desc* d);
 /* tuning/test hooks: override tile id / split-K factor for every following call (0 = off) */
 int t2v_gemm_force_config(int cfg);
 int t2v_gemm_force_split(int splits);
@@ -146,6 +173,15 @@ long long t2v_group_norm_ws_floats(int n_units, int rows_per_unit, int groups, i
 int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units, int rows_per_unit,
                    int groups, float eps, const float* gamma, const float* beta, int silu, float* ws, void* out, int ldo,
                    void* stream);
+
+/* GroupNorm(+SiLU) whose statistics pass reads the column statistics the producing t2v_gemm launches wrote
+ * (t2v_gemm_desc::colstat_out) instead of the tensor: cs0 [rows/32][c0][2] for x0, cs1 [rows/32][c1][2] for the second part of
+ * a virtual concat (NULL without one); rows_per_unit % 32 == 0.  Two launches; ws: t2v_group_norm_cs_ws_floats(...) floats.
+ * Same result as t2v_group_norm up to the summation order of the statistics (fixed: deterministic). */
+long long t2v_group_norm_cs_ws_floats(int n_units, int rows_per_unit, int groups);
+int t2v_group_norm_cs(const float* cs0, const float* cs1, const void* x0, int c0, int ld0, const void* x1, int c1, int ld1,
+                      int n_units, int rows_per_unit, int groups, float eps, const float* gamma, const float* beta, int silu,
+                      float* ws, void* out, int ldo, void* stream);
 
 /* LayerNorm over the channel dim, eps, affine; bf16 in/out (attention.py:279-281). */
 int t2v_layernorm(const void* x, int ldx, int M, int C, const float* gamma, const float* beta,

@@ -104,24 +104,48 @@ struct Epi {
     const t2v_gemm_desc* d;
     long long o_off;
     int n_out, vec;
+    float ln_r = 1.f, ln_rmu = 0.f;  // LayerNorm folded into this GEMM (FUSE bit 4): rstd and rstd * mean of the row being finished
     // pre_res: the run's 16 residual values already in registers (issued for the whole wave tile before the first
     // store, so their latency is paid once instead of once per run behind the previous run's stores)
     // FAST: every run is a full, 16-byte aligned run (host-checked: vector-aligned operands, n_out % 16 == 0): the
     // per-element partial paths compile away.  The epilogue is unrolled over the wave tile, so this is most of the kernel's
     // code size, and these kernels pay for instruction fetch (a ~10 % longer epilogue measured 6 % slower end to end).
     template <bool FAST = false>
-    __device__ __forceinline__ void run(float* v, const float* gate, int gm, int ch_in, int ch_out, bool has_pre = false,
+    __device__ __forceinline__ void run(float* v, float* gate, int gm, int ch_in, int ch_out, bool has_pre = false,
                                         uint4 pre0 = uint4{0, 0, 0, 0}, uint4 pre1 = uint4{0, 0, 0, 0}) const {
         if (ch_out >= n_out) return;
         compute<FAST>(v, gate, gm, ch_in, ch_out, has_pre, pre0, pre1);
         store<FAST>(v, gm, ch_out);
     }
     // everything up to the final values of the run (v is updated in place)
-    template <bool FAST = false>
-    __device__ __forceinline__ void compute(float* v, const float* gate, int gm, int ch_in, int ch_out, bool has_pre = false,
+    template <bool FAST = false, bool LNF = false>
+    __device__ __forceinline__ void compute(float* v, float* gate, int gm, int ch_in, int ch_out, bool has_pre = false,
                                             uint4 pre0 = uint4{0, 0, 0, 0}, uint4 pre1 = uint4{0, 0, 0, 0}) const {
         const t2v_gemm_desc& dd = *d;
         const bool full = FAST || (vec && ch_out + 16 <= n_out);
+        if constexpr (LNF) {
+            // out = rstd * (acc - mean * s[n]) + t[n]: the consumer of a LayerNorm computed on the raw rows (W holds W diag(gamma),
+            // s its row sums, bias = t = b + W beta); value and gate columns of a GEGLU projection alike
+            static_assert(FAST, "the LayerNorm fold lives in the fast kernels (accumulators start at zero there)");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 s4 = *(const float4*)(dd.lnf_s + ch_in + 4 * q), t4 = *(const float4*)(dd.bias + ch_in + 4 * q);
+                v[4 * q] = fmaf(ln_r, v[4 * q], fmaf(-ln_rmu, s4.x, t4.x));
+                v[4 * q + 1] = fmaf(ln_r, v[4 * q + 1], fmaf(-ln_rmu, s4.y, t4.y));
+                v[4 * q + 2] = fmaf(ln_r, v[4 * q + 2], fmaf(-ln_rmu, s4.z, t4.z));
+                v[4 * q + 3] = fmaf(ln_r, v[4 * q + 3], fmaf(-ln_rmu, s4.w, t4.w));
+            }
+            if (gate) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 s4 = *(const float4*)(dd.lnf_s + ch_in + 32 + 4 * q), t4 = *(const float4*)(dd.bias + ch_in + 32 + 4 * q);
+                    gate[4 * q] = fmaf(ln_r, gate[4 * q], fmaf(-ln_rmu, s4.x, t4.x));
+                    gate[4 * q + 1] = fmaf(ln_r, gate[4 * q + 1], fmaf(-ln_rmu, s4.y, t4.y));
+                    gate[4 * q + 2] = fmaf(ln_r, gate[4 * q + 2], fmaf(-ln_rmu, s4.z, t4.z));
+                    gate[4 * q + 3] = fmaf(ln_r, gate[4 * q + 3], fmaf(-ln_rmu, s4.w, t4.w));
+                }
+            }
+        }
         // FAST kernels (alpha == 1, host-checked) start their accumulators at bias (+ rowvec + residual when there is no
         // gate), so those terms cost nothing here and the residual's latency hides under the main loop
         constexpr bool FOLD = FAST;
@@ -277,8 +301,13 @@ constexpr int gemm_smem_bytes() {  // (the same for the DMA-staged and the regis
 // LNOUT (FAST kernels whose workgroup tile spans the whole row, i.e. the 160x320 tiles at N = 320): the epilogue also writes
 // LayerNorm(out) * gamma + beta to a second tensor — the transformer blocks' LayerNorms (attention.py:300-311) as a by-product
 // of the GEMM that produces their input, instead of 60 read-modify-write launches per UNet step.
-template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4, bool FAST = false, bool RS = false, bool LNOUT = false>
+// FUSE (fast kernels only; instantiated in gemm_fuse.hip): 1 = row statistics of the output (t2v_gemm_desc::rowstat_out), 2 = column
+// statistics per 32-row slab (colstat_out), 4 = this GEMM consumes a LayerNorm folded into its weights (lnf_*).
+template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4, bool FAST = false, bool RS = false, bool LNOUT = false,
+          int FUSE = 0>
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void gemm_kernel(const GemmParams p) {
+    static_assert(FUSE == 0 || (FAST && !RS && !LNOUT), "fused statistics: fast DMA-staged kernels only");
+    constexpr bool F_ROW = (FUSE & 1) != 0, F_COL = (FUSE & 2) != 0, F_LNF = (FUSE & 4) != 0;
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -593,7 +622,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
             const int ch = ch_lane + j * 32;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                binit[j][q] = (d.bias && ch < d.N && !ABL(64)) ? *(const float4*)(d.bias + ch + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                binit[j][q] = (!F_LNF && d.bias && ch < d.N && !ABL(64)) ? *(const float4*)(d.bias + ch + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -608,6 +637,34 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
                     rinit[i][j][1] = *(const uint4*)(rp + 8);
                 }
             }
+        }
+    }
+    // LayerNorm fold: (rstd, rstd * mean) of this lane's TM rows from the producer's per-32-column (sum, sum of squares) pairs,
+    // added in block order (deterministic); loaded here, with the other initial register loads, so that the main loop hides them
+    float lnr[F_LNF ? TM : 1], lnrm[F_LNF ? TM : 1];
+    if constexpr (F_LNF) {
+        // a row's partials are lnf_nblk (sum, sumsq) pairs = nq float4; the two lanes that own a row (hi = 0 / 1) take one half
+        // each — at most LNQ 16-byte loads, all issued before the first add — and exchange their sums (lane ^ 32)
+        constexpr int LNQ = 10;  // C <= 1280
+        const float inv_c = 1.0f / (float)(d.lnf_nblk * 32);
+        const int nq = d.lnf_nblk >> 1, halfq = (nq + 1) >> 1;
+        const int q0 = hi * halfq, q1 = min(nq, q0 + halfq);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int gm = m0 + wave_m * WTM + i * 32 + frow;
+            const float4* sp = (const float4*)(d.lnf_stats + (long long)min(gm, d.M - 1) * d.lnf_ld);
+            float4 t[LNQ];
+#pragma unroll
+            for (int k = 0; k < LNQ; ++k) t[k] = (q0 + k < q1) ? sp[q0 + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < LNQ; ++k) { s1 += t[k].x; s2 += t[k].y; s1 += t[k].z; s2 += t[k].w; }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const float mean = s1 * inv_c;
+            const float var = fmaxf(s2 * inv_c - mean * mean, 0.f);
+            lnr[i] = rsqrtf(var + d.lnf_eps);
+            lnrm[i] = lnr[i] * mean;
         }
     }
     // accumulators start at bias (+ row vector + residual) in FAST kernels, at zero otherwise
@@ -710,6 +767,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int gm = m0 + wave_m * WTM + i * 32 + frow;
+                    if constexpr (F_LNF) { epi.ln_r = lnr[i]; epi.ln_rmu = lnrm[i]; }
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int u = 0; u < TN / 2; ++u) {
@@ -717,7 +775,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 #pragma unroll
                         for (int e = 0; e < 16; ++e) { v[e] = acc[i][2 * u][e]; gt[e] = acc[i][2 * u + 1][e]; }
                         const int ch_out = (n0 + wave_n * WTN) / 2 + u * 32 + 16 * hi;
-                        if (gm < d.M && ch_out < epi.n_out) epi.template compute<true>(v, gt, gm, ch_lane + u * 64, ch_out);
+                        if (gm < d.M && ch_out < epi.n_out) epi.template compute<true, F_LNF>(v, gt, gm, ch_lane + u * 64, ch_out);
                         *(uint4*)(st_w + u * 64) = pack8(v);
                         *(uint4*)(st_w + u * 64 + 16) = pack8(v + 8);
                     }
@@ -792,17 +850,53 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int gm = m0 + wave_m * WTM + i * 32 + frow;
+            if constexpr (F_LNF) { epi.ln_r = lnr[i]; epi.ln_rmu = lnrm[i]; }
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float v[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
-                if (gm < d.M && ch_lane + j * 32 < d.N) epi.template compute<true>(v, nullptr, gm, ch_lane + j * 32, ch_lane + j * 32);
+                if (gm < d.M && ch_lane + j * 32 < d.N) epi.template compute<true, F_LNF>(v, nullptr, gm, ch_lane + j * 32, ch_lane + j * 32);
+                if constexpr (F_ROW) {
+                    // (sum, sum of squares) of this row over the 32-column block j of the wave tile: the lane's 16 fp32 epilogue
+                    // values plus its partner's (lane ^ 32 holds the block's other 16 channels), in a fixed order
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    if (hi == 0 && gm < d.M && ch_lane + j * 32 < d.N)
+                        *(float2*)(d.rowstat_out + (long long)gm * d.ld_rowstat + 2 * (((n0 + wave_n * WTN) >> 5) + j)) = make_float2(s1, s2);
+                }
                 *(uint4*)(st_w + j * 64) = pack8(v);
                 *(uint4*)(st_w + j * 64 + 16) = pack8(v + 8);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr (F_COL) {
+                // (sum, sum of squares) per column over the slab's 32 rows, from the bf16 values parked in LDS (what the consumer
+                // will read): lane = (column pair, row half); the two halves meet through lane ^ 32.  host-checked: M % 32 == 0
+                const int gm0 = m0 + wave_m * WTM + i * 32, col0 = n0 + wave_n * WTN;
+                const int rh = hi * 16;
+#pragma unroll
+                for (int c2 = 0; c2 < (WTN / 2 + 31) / 32; ++c2) {
+                    const int cpair = c2 * 32 + frow;
+                    float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
+                    if (cpair < WTN / 2) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const uint32_t w2 = *(const uint32_t*)(st + (rh + r) * P + cpair * 4);
+                            const float x0 = __uint_as_float(w2 << 16), x1 = __uint_as_float(w2 & 0xffff0000u);
+                            a0 += x0; q0 = fmaf(x0, x0, q0);
+                            a1 += x1; q1 = fmaf(x1, x1, q1);
+                        }
+                    }
+                    a0 += __shfl_xor(a0, 32, 64); q0 += __shfl_xor(q0, 32, 64);
+                    a1 += __shfl_xor(a1, 32, 64); q1 += __shfl_xor(q1, 32, 64);
+                    if (hi == 0 && cpair < WTN / 2 && gm0 < d.M && col0 + 2 * cpair < d.N)
+                        *(float4*)(d.colstat_out + ((long long)(gm0 >> 5) * d.N + col0 + 2 * cpair) * 2) = make_float4(a0, q0, a1, q1);
+                }
+            }
             if (ABL(32)) flush_slab_nostore<P, TN * 4>(st, lane, obase, d.ldo, m0 + wave_m * WTM + i * 32, d.M, n0 + wave_n * WTN, d.N);
             else flush_slab<P, TN * 4>(st, lane, obase, d.ldo, m0 + wave_m * WTM + i * 32, d.M, n0 + wave_n * WTN, d.N);
         }
@@ -894,15 +988,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
     epi.run(v, nullptr, gm, ch, ch);
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST, bool RS = false, bool LNOUT = false>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST, bool RS = false, bool LNOUT = false, int FUSE = 0>
 int launch_impl(GemmParams& p, hipStream_t s);
+
+// does this launch qualify for the fast kernels (accumulators start at bias + row vector + residual, bf16 slab epilogue)?
+inline bool gemm_is_fast(const GemmParams& p) {
+    const int n_out = p.d.act == T2V_ACT_GEGLU ? p.d.N / 2 : p.d.N;
+    static const bool no_fast = getenv("T2V_GEMM_NOFAST") != nullptr;  // diagnostics: force the generic epilogue
+    return !no_fast && !p.d.drop_thr && p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1 && p.d.alpha == 1.0f &&
+           !p.d.out_f32 && (!p.d.rowvec || ((uintptr_t)p.d.rowvec % 16 == 0 && p.d.ld_rowvec % 4 == 0));
+}
 
 template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM * WN) / 4, bool RS = false>
 int launch(GemmParams& p, hipStream_t s) {
-    const int n_out = p.d.act == T2V_ACT_GEGLU ? p.d.N / 2 : p.d.N;
-    static const bool no_fast = getenv("T2V_GEMM_NOFAST") != nullptr;  // diagnostics: force the generic epilogue
-    const bool fast = !no_fast && !p.d.drop_thr && p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1 && p.d.alpha == 1.0f &&
-                      !p.d.out_f32 && (!p.d.rowvec || ((uintptr_t)p.d.rowvec % 16 == 0 && p.d.ld_rowvec % 4 == 0));
+    const bool fast = gemm_is_fast(p);
     // 128x128 wave tiles keep their 256 accumulator registers in AGPRs and have no room for the generic epilogue's
     // partial-run paths (it spills 2 KiB per lane): shapes that need it run the 8-wave sibling of the same workgroup tile
     if constexpr (BM / WM >= 128 && BN / WN >= 128) {
@@ -912,7 +1011,7 @@ int launch(GemmParams& p, hipStream_t s) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST, bool RS, bool LNOUT>
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST, bool RS, bool LNOUT, int FUSE>
 int launch_impl(GemmParams& p, hipStream_t s) {
     p.tiles_m = (p.d.M + BM - 1) / BM;
     p.tiles_n = (p.d.N + BN - 1) / BN;
@@ -949,10 +1048,10 @@ int launch_impl(GemmParams& p, hipStream_t s) {
     constexpr int smem = LNOUT ? (base_smem > slab_end + 2 * WM * WN * 32 * 4 ? base_smem : slab_end + 2 * WM * WN * 32 * 4) : base_smem;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST, RS, LNOUT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST, RS, LNOUT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST, RS, LNOUT>), grid, dim3(WM * WN * 64), smem, s, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST, RS, LNOUT, FUSE>), grid, dim3(WM * WN * 64), smem, s, p);
     T2V_CHECK_LAUNCH();
     if (p.splits > 1) {
         const long long work = (long long)p.d.M * ((p.d.N + 15) / 16);
@@ -970,7 +1069,56 @@ int launch_impl(GemmParams& p, hipStream_t s) {
 // should be exactly what ran on hardware.
 int t2v_gemm_launch_experimental(int cfg, GemmParams& p, hipStream_t s);
 int t2v_gemm_launch_ln(int cfg, GemmParams& p, hipStream_t s);  // the 160x320 tile (id 23) with the LayerNorm second output
-#ifdef T2V_GEMM_EXP_ONLY
+// The fast kernels with fused normalisation statistics (FUSE = 1 row statistics out, 2 column statistics out, 4 LayerNorm folded
+// in) live in gemm_fuse.hip (= this file with T2V_GEMM_FUSE_ONLY) for the same reason as the experimental ids: the validated
+// kernels' code must not depend on them.  t2v_gemm_fuse_tile maps a tile id to the id whose fused variants exist (same workgroup
+// tile where possible), 0 if none.
+int t2v_gemm_launch_fused(int cfg, int fuse, GemmParams& p, hipStream_t s);
+int t2v_gemm_fuse_tile(int cfg, int act);
+#ifdef T2V_GEMM_FUSE_ONLY
+namespace {
+template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE>
+int launch_fused(int fuse, GemmParams& p, hipStream_t s) {
+    switch (fuse) {
+        case 1: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 1>(p, s);
+        case 2: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 2>(p, s);
+        case 4: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 4>(p, s);
+        default: return T2V_EINVAL;
+    }
+}
+}  // namespace
+// tiles with fused variants: one per workgroup-tile shape the tuned table uses for the UNet's norm producers / consumers
+int t2v_gemm_fuse_tile(int cfg, int act) {
+    switch (cfg) {
+        case 1: case 4: case 10: case 18: case 26: case 30: case 33: return 4;     // 128x128
+        case 31: case 32: return act == T2V_ACT_GEGLU ? 4 : 31;                   // 128x128, eight waves (32-wide wave tiles: no GEGLU)
+        case 6: case 7: case 13: case 16: case 19: case 25: return cfg == 19 ? 19 : (cfg == 16 ? 16 : 7);   // 256x128
+        case 11: case 14: case 17: case 29: return cfg == 17 ? 17 : 11;           // 128x256
+        case 12: case 15: case 20: case 21: case 24: case 27: return cfg == 20 ? 20 : 12;   // 256x256
+        case 22: case 23: case 28: return act == T2V_ACT_GEGLU ? 17 : 23;         // 160x320 (no GEGLU on its 32-wide value / gate split)
+        case 3: case 9: return 9;                                                 // 256x64
+        case 2: case 5: return 5;                                                 // 128x64
+        default: return 0;
+    }
+}
+int t2v_gemm_launch_fused(int cfg, int fuse, GemmParams& p, hipStream_t s) {
+    switch (cfg) {
+        case 4: return launch_fused<128, 128, 2, 2, 3, 64, 1>(fuse, p, s);
+        case 5: return launch_fused<128, 64, 2, 2, 3, 64, 1>(fuse, p, s);
+        case 7: return launch_fused<256, 128, 4, 2, 3, 64, 2>(fuse, p, s);
+        case 9: return launch_fused<256, 64, 4, 2, 3, 64, 2>(fuse, p, s);
+        case 11: return launch_fused<128, 256, 2, 4, 3, 64, 2>(fuse, p, s);
+        case 12: return launch_fused<256, 256, 2, 4, 2, 64, 2>(fuse, p, s);
+        case 16: return launch_fused<256, 128, 2, 2, 3, 32, 2>(fuse, p, s);
+        case 17: return launch_fused<128, 256, 1, 4, 3, 32, 2>(fuse, p, s);
+        case 19: return launch_fused<256, 128, 4, 2, 3, 32, 4>(fuse, p, s);
+        case 20: return launch_fused<256, 256, 2, 4, 4, 32, 2>(fuse, p, s);
+        case 23: return launch_fused<160, 320, 5, 2, 3, 32, 3>(fuse, p, s);
+        case 31: return launch_fused<128, 128, 2, 4, 3, 64, 2>(fuse, p, s);
+        default: return T2V_EINVAL;
+    }
+}
+#elif defined(T2V_GEMM_EXP_ONLY)
 int t2v_gemm_launch_ln(int cfg, GemmParams& p, hipStream_t s) {  // tile id 23 only (its 64-deep twin, id 22, spills 22 registers with the extra epilogue)
     (void)cfg;
     return launch_impl<160, 320, 5, 2, 3, 32, 3, true, false, true>(p, s);
@@ -1065,9 +1213,11 @@ extern "C" int t2v_gemm_force_config(int cfg) { g_force_cfg = cfg; return T2V_OK
 extern "C" int t2v_gemm_force_split(int s) { g_force_split = s; return T2V_OK; }
 extern "C" int t2v_gemm_num_configs(void) { return kNumCfg; }
 
-extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
+// Everything t2v_gemm decides before it launches: argument checks, geometry, tile id, split-K factor and — when the descriptor
+// asks for fused normalisation statistics — whether the launch can carry them (fuse = FUSE bits, fuse_cfg = the tile that does;
+// fuse_ok = false: the caller has to use the standalone kernels).  Shared by t2v_gemm and t2v_gemm_fuse_supported.
+static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, int& fuse, int& fuse_cfg, bool& fuse_ok) {
     T2V_REQUIRE(dd && dd->a0 && dd->w && dd->out, T2V_EINVAL, "t2v_gemm: null pointer");
-    GemmParams p;
     p.d = *dd;
     t2v_gemm_desc& d = p.d;
     if (!d.a1) { d.c1 = 0; d.lda1 = 0; }
@@ -1121,7 +1271,6 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
              (d.o_stride1 % 8 == 0) && (!d.residual || (d.ldr % 8 == 0 && (uintptr_t)d.residual % 16 == 0)) &&
              (!d.bias || (uintptr_t)d.bias % 16 == 0) && (!d.rowvec || ((uintptr_t)d.rowvec % 16 == 0 && d.ld_rowvec % 4 == 0));
     if (d.act == T2V_ACT_GEGLU) T2V_REQUIRE(p.vec4, T2V_ESHAPE, "t2v_gemm: GEGLU needs 8-byte aligned rows");
-    hipStream_t s = (hipStream_t)stream;
 
     // ---- tile configuration -------------------------------------------------------------------------
     int cfg = g_force_cfg ? g_force_cfg : d.tile_cfg;
@@ -1156,6 +1305,55 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     p.splits = splits;
     p.ws = (float*)d.ws;
     p.debug = g_debug;
+    cfg_out = cfg;
+    fuse = (d.rowstat_out ? 1 : 0) | (d.colstat_out ? 2 : 0) | (d.lnf_stats ? 4 : 0);
+    fuse_cfg = 0;
+    fuse_ok = false;
+    if (fuse) {
+        T2V_REQUIRE(fuse == 1 || fuse == 2 || fuse == 4, T2V_EINVAL, "t2v_gemm: one of rowstat_out / colstat_out / lnf_stats per launch");
+        T2V_REQUIRE(!d.ln_out && d.batch == 1, T2V_EINVAL, "t2v_gemm: fused statistics: no batch, no LayerNorm second output");
+        if (fuse == 1)
+            T2V_REQUIRE(d.N % 32 == 0 && d.ld_rowstat >= d.N / 16 && d.ld_rowstat % 4 == 0 && (uintptr_t)d.rowstat_out % 16 == 0 &&
+                            d.act == T2V_ACT_NONE, T2V_ESHAPE, "t2v_gemm: rowstat_out needs N % 32 == 0, ld_rowstat >= N / 16 (% 4), no activation");
+        if (fuse == 2)
+            T2V_REQUIRE(d.M % 32 == 0 && d.N % 2 == 0 && (uintptr_t)d.colstat_out % 16 == 0 && d.act != T2V_ACT_GEGLU, T2V_ESHAPE,
+                        "t2v_gemm: colstat_out needs M % 32 == 0");
+        if (fuse == 4)
+            T2V_REQUIRE(d.mode == T2V_GEMM_LINEAR && !d.a1 && d.lnf_s && d.bias && d.lnf_nblk > 0 && d.lnf_nblk % 2 == 0 && d.lnf_nblk <= 40 &&
+                            d.c0 == 32 * d.lnf_nblk && d.lnf_ld >= 2 * d.lnf_nblk && d.lnf_ld % 4 == 0 && (uintptr_t)d.lnf_stats % 16 == 0 &&
+                            (uintptr_t)d.lnf_s % 16 == 0 && !d.residual && !d.rowvec && !d.drop_thr && d.act != T2V_ACT_SILU,
+                        T2V_ESHAPE, "t2v_gemm: lnf_stats: LINEAR over C = 32 lnf_nblk <= 1280 channels, lnf_s and bias given, no residual / "
+                                    "row vector / dropout");
+        fuse_cfg = t2v_gemm_fuse_tile(cfg, d.act);
+        // the fused epilogue rides on the fast kernels of one K split; GEGLU needs a 64-wide wave tile (its value / gate pairs)
+        fuse_ok = fuse_cfg != 0 && p.splits == 1 && gemm_is_fast(p) && !(d.act == T2V_ACT_GEGLU && kCfg[fuse_cfg].wtn < 64);
+        if (fuse_ok) { p.nk = p.K / kCfg[fuse_cfg].bk; p.nk_per_split = p.nk; }
+        return T2V_OK;
+    }
+    return T2V_OK;
+}
+
+extern "C" int t2v_gemm_fuse_supported(const t2v_gemm_desc* dd) {
+    GemmParams p;
+    int cfg = 0, fuse = 0, fuse_cfg = 0;
+    bool ok = false;
+    const int rc = gemm_prepare(dd, p, cfg, fuse, fuse_cfg, ok);
+    if (rc != T2V_OK) return rc;
+    return (fuse && ok) ? 1 : 0;
+}
+
+extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
+    GemmParams p;
+    int cfg = 0, fuse = 0, fuse_cfg = 0;
+    bool fuse_ok = false;
+    const int rc = gemm_prepare(dd, p, cfg, fuse, fuse_cfg, fuse_ok);
+    if (rc != T2V_OK) return rc;
+    t2v_gemm_desc& d = p.d;
+    hipStream_t s = (hipStream_t)stream;
+    if (fuse) {
+        T2V_REQUIRE(fuse_ok, T2V_ESHAPE, "t2v_gemm: this launch cannot carry fused statistics (ask t2v_gemm_fuse_supported first)");
+        return t2v_gemm_launch_fused(fuse_cfg, fuse, p, s);
+    }
     if (d.ln_out) {  // LayerNorm second output: only the full-row 160x320 FAST kernels carry it
         cfg = 23;
         p.nk = p.K / kCfg[cfg].bk;

@@ -167,6 +167,48 @@ __device__ __forceinline__ void gn_finish_unit(const float* partial, int unit, i
     __syncthreads();
 }
 
+// partial[unit][blk][value = 2*group + stat] from the COLUMN STATISTICS the producing t2v_gemm launches left behind
+// (t2v_gemm_desc::colstat_out: cs[slab of 32 rows][channel][2] = (sum, sumsq) of the bf16 outputs; a virtual concat has one
+// array per part): the statistics pass of GroupNorm without reading the tensor (1/8 of its bytes).  Block (blk, unit) adds the
+// unit's 32-row slabs [blk * slabs_per_blk, ...) per channel in slab order, then one thread per value adds its group's channels
+// in channel order: deterministic, same output format as gn_partial_kernel.
+__global__ __launch_bounds__(256) void gn_partial_cs_kernel(const float* cs0, int c0, const float* cs1, int c1, int slabs_per_unit,
+                                                            int slabs_per_blk, int groups, float* partial) {
+    extern __shared__ float sred[];  // [C][2]
+    const int C = c0 + c1, cpg = C / groups;
+    const int unit = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+    const int s0 = blk * slabs_per_blk, s1 = min(s0 + slabs_per_blk, slabs_per_unit);
+    const long long first = (long long)unit * slabs_per_unit;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float* src = c < c0 ? cs0 + 2 * c : cs1 + 2 * (c - c0);
+        const long long ldc = c < c0 ? 2LL * c0 : 2LL * c1;
+        float a = 0.f, q = 0.f;
+        int sl = s0;
+        for (; sl + 4 <= s1; sl += 4) {  // four loads in flight, added in slab order
+            float2 v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = *(const float2*)(src + (first + sl + e) * ldc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a += v[e].x; q += v[e].y; }
+        }
+        for (; sl < s1; ++sl) {
+            const float2 v = *(const float2*)(src + (first + sl) * ldc);
+            a += v.x; q += v.y;
+        }
+        sred[2 * c] = a;
+        sred[2 * c + 1] = q;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < groups * 2; i += 256) {
+        const float* src = sred + (long long)(i >> 1) * cpg * 2 + (i & 1);
+        float a0 = 0.f, a1 = 0.f;
+        int c = 0;
+        for (; c + 2 <= cpg; c += 2) { a0 += src[2 * c]; a1 += src[2 * c + 2]; }
+        if (c < cpg) a0 += src[2 * c];
+        partial[((long long)unit * nblk + blk) * groups * 2 + i] = a0 + a1;
+    }
+}
+
 // one block per unit: stats[unit][group] = (mean, rstd) and, when coef != null, the per-channel affine
 // coef[unit][0][c] = rstd*gamma[c], coef[unit][1][c] = beta[c] - mean*rstd*gamma[c] the apply pass streams with
 __global__ __launch_bounds__(1024) void gn_final_kernel(const float* partial, int nslab, int groups, int C, float inv_count, float eps,
@@ -725,6 +767,39 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
     hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1,
                        rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)coef, (const float*)nullptr, 0, 0.f, 0.f,
                        gamma, beta, silu, (bf16_t*)out, ldo);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+
+// GroupNorm(+SiLU) on the column statistics of the producing GEMMs: [statistics from cs: gn_partial_cs_kernel] + [apply pass whose
+// blocks finish the unit's statistics themselves].  Two launches, the tensor is read once.
+constexpr int GN_CS_BLOCKS = 80;  // statistics blocks per unit (<= gn_fuse_slabs: the apply pass finishes them per block)
+extern "C" long long t2v_group_norm_cs_ws_floats(int n_units, int rows_per_unit, int groups) {
+    (void)rows_per_unit;
+    return (long long)n_units * GN_CS_BLOCKS * 2 * groups;
+}
+extern "C" int t2v_group_norm_cs(const float* cs0, const float* cs1, const void* x0, int c0, int ld0, const void* x1, int c1, int ld1,
+                                 int n_units, int rows_per_unit, int groups, float eps, const float* gamma, const float* beta, int silu,
+                                 float* ws, void* out, int ldo, void* stream) {
+    int rc = gn_check(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups);
+    if (rc) return rc;
+    T2V_REQUIRE(ws && gamma && beta && out && ldo % 8 == 0 && cs0, T2V_EINVAL, "t2v_group_norm_cs: bad argument");
+    if (!x1) { c1 = 0; ld1 = 0; }
+    T2V_REQUIRE(rows_per_unit % 32 == 0 && (c1 == 0 || cs1) && GN_CS_BLOCKS <= gn_fuse_slabs(groups), T2V_ESHAPE,
+                "t2v_group_norm_cs: rows_per_unit must be a multiple of the 32-row statistics slab");
+    T2V_REQUIRE((uintptr_t)cs0 % 8 == 0 && (!cs1 || (uintptr_t)cs1 % 8 == 0), T2V_ESHAPE, "t2v_group_norm_cs: unaligned statistics");
+    hipStream_t s = (hipStream_t)stream;
+    const int C = c0 + c1, nslab = gn_nslab(C, rows_per_unit, groups), slab_rows = gn_slab_rows(C, rows_per_unit, groups);
+    const int slabs_per_unit = rows_per_unit / 32;
+    const int slabs_per_blk = (slabs_per_unit + GN_CS_BLOCKS - 1) / GN_CS_BLOCKS;
+    const int nblk = (slabs_per_unit + slabs_per_blk - 1) / slabs_per_blk;
+    const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / groups));
+    hipLaunchKernelGGL(gn_partial_cs_kernel, dim3(nblk, n_units), dim3(256), (size_t)2 * C * sizeof(float), s, cs0, c0, cs1, c1,
+                       slabs_per_unit, slabs_per_blk, groups, ws);
+    T2V_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
+                       ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, nblk,
+                       inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }

@@ -33,6 +33,7 @@ class BufferPool:
         self.device = device
         self.free = collections.defaultdict(list)
         self.live = {}
+        self.links = {}
         self.bytes = 0
 
     def get(self, rows, cols, dtype, zero=False):
@@ -49,20 +50,28 @@ class BufferPool:
         self.live[t.data_ptr()] = (nbytes, base)
         return t
 
+    def link(self, t, side):
+        """``side`` (another pool buffer: the statistics a producing GEMM wrote next to ``t``) is released together with ``t``."""
+        self.links.setdefault(t.data_ptr(), []).append(side)
+
     def put(self, *tensors):
         for t in tensors:
             if t is None:
                 continue
             nbytes, base = self.live.pop(t.data_ptr())
             self.free[nbytes].append(base)
+            for side in self.links.pop(t.data_ptr(), ()):
+                self.put(side)
 
 
 class Act:
     """A token-major activation: one tensor, or two channel-concatenated parts (virtual concat)."""
 
-    def __init__(self, parts, n_img, h, w):
+    def __init__(self, parts, n_img, h, w, cs=None):
         self.parts = parts if isinstance(parts, (list, tuple)) else [parts]
         self.n_img, self.h, self.w = n_img, h, w
+        # per part: the column statistics [rows / 32, C, 2] its producing GEMM wrote (t2v_gemm colstat_out), or None
+        self.cs = list(cs) if cs is not None else [None] * len(self.parts)
 
     @property
     def t(self):
@@ -199,6 +208,31 @@ class Packer:
             return wp, bp.detach().to(self.device, torch.float32).contiguous()
         return self._memo(("geglu", id(proj)), make)
 
+    def mat_lnf(self, mods, norm, tag):
+        """LayerNorm folded into the Linear(s) that consume it (t2v_gemm lnf_*): (W' = cat(W) diag(gamma) in the weight dtype,
+        s = row sums of the ROUNDED W' (fp32: what the matrix cores multiply the mean with), t = b + cat(W) beta (fp32))."""
+        def make():
+            w = torch.cat([self.wb(m)[0].detach().float().reshape(self.wb(m)[0].shape[0], -1) for m in mods], dim=0).to(self.device)
+            b = torch.cat([(self.wb(m)[1].detach().float() if self.wb(m)[1] is not None else torch.zeros(self.wb(m)[0].shape[0]))
+                           .to(self.device) for m in mods])
+            gamma, beta = norm.weight.detach().float().to(self.device), norm.bias.detach().float().to(self.device)
+            wp = (w * gamma[None, :]).to(self.wdtype).contiguous()
+            return wp, wp.float().sum(dim=1).contiguous(), (b + w @ beta).contiguous()
+        return self._memo((tag, id(norm)) + tuple(id(m) for m in mods), make)
+
+    def geglu_lnf(self, proj, norm):
+        """``geglu`` pack (64-row groups [32 value | 32 gate]) of the LayerNorm-folded GEGLU projection: (W', s, t)."""
+        def make():
+            wp, s_vec, t_vec = self.mat_lnf([proj], norm, "geglu_lnf_src")
+            inner = wp.shape[0] // 2
+            assert inner % 32 == 0
+
+            def pack(v):
+                a, g = v[:inner].reshape(inner // 32, 32, -1), v[inner:].reshape(inner // 32, 32, -1)
+                return torch.cat([a, g], dim=1).reshape(2 * inner, -1)
+            return pack(wp).contiguous(), pack(s_vec[:, None]).reshape(-1).contiguous(), pack(t_vec[:, None]).reshape(-1).contiguous()
+        return self._memo(("geglu_lnf", id(proj), id(norm)), make)
+
     def small_conv(self, mod, cin_pad=None):
         """fp32 [cout][9][cin] for the direct small-Cin conv."""
         def make():
@@ -265,17 +299,44 @@ class _Engine:
         """GroupNorm(+SiLU) of an Act (possibly a virtual concat) -> new single-part tensor."""
         ops = self.ops
         G = norm.num_groups
-        ws = self.buf(1, max(ops.group_norm_ws_floats(units, rows_per_unit, G, x.C), 1), torch.float32)
         eps = norm.eps if eps is None else eps
         out = self.buf(x.M, x.C)
-        ops.group_norm(x.parts[0], x.p1, units, rows_per_unit, eps, self.pk.f32(norm.weight), self.pk.f32(norm.bias),
-                       silu, ws, out, G)
+        if self.fuse_gn and all(c is not None for c in x.cs) and rows_per_unit % 32 == 0:
+            # the producing GEMMs left per-slab column statistics: no statistics pass over the tensor
+            ws = self.buf(1, max(ops.group_norm_cs_ws_floats(units, rows_per_unit, G), 1), torch.float32)
+            ops.group_norm_cs(x.cs[0], x.cs[1] if len(x.cs) > 1 else None, x.parts[0], x.p1, units, rows_per_unit, eps,
+                              self.pk.f32(norm.weight), self.pk.f32(norm.bias), silu, ws, out, G)
+        else:
+            ws = self.buf(1, max(ops.group_norm_ws_floats(units, rows_per_unit, G, x.C), 1), torch.float32)
+            ops.group_norm(x.parts[0], x.p1, units, rows_per_unit, eps, self.pk.f32(norm.weight), self.pk.f32(norm.bias),
+                           silu, ws, out, G)
         self.pool.put(ws)
         return out
 
-    def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None, ln=None):
+    # Normalisation statistics as by-products of the producing GEMMs (t2v_gemm rowstat_out / colstat_out) and LayerNorm folded
+    # into the consuming GEMM (lnf_*): set by the engines that use them (UNetEngine); T2V_FUSE_GN=0 / T2V_FOLD_LN=0 switch back
+    # to the standalone statistics passes / LayerNorm launches.
+    fuse_gn = False
+    fold_ln = False
+
+    def _colstat_for(self, a0, w, out, **kw):
+        """A column-statistics buffer for this launch's output if the launch can carry it (linked to ``out`` in the pool)."""
+        M, N = kw["M"], kw["N"]
+        if not self.fuse_gn or M % 32 or out.dtype != self.adt:
+            return None
+        cs = self.buf(M // 32, 2 * N, torch.float32)
+        if not self.ops.gemm_fuse_supported(a0, w, out, colstat=cs, **kw):
+            self.pool.put(cs)
+            return None
+        self.pool.link(out, cs)
+        return cs
+
+    def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None, ln=None,
+               want_cs=False, want_rs=False, lnf=None):
         """``ln``: (LayerNorm module, destination buffer) — LayerNorm(out) as a second output of the same launch (t2v_gemm ln_*
-        fields; N == 320 only, see ``ln_fusable``)."""
+        fields; N == 320 only, see ``ln_fusable``).  ``want_cs`` / ``want_rs``: also write the column / row statistics of the
+        output where the launch can (returned as ``self.last_cs`` / ``self.last_rs``, None otherwise).  ``lnf``: (row statistics
+        of ``a``, eps, s) — ``w`` / ``bias`` are a LayerNorm-folded pack (``Packer.mat_lnf``) and ``a`` the un-normalised rows."""
         w = self.pk.mat(mod) if w is None else w
         bias = self.pk.bias(mod) if isinstance(bias, str) else bias
         N = w.shape[0] if N is None else N
@@ -283,7 +344,25 @@ class _Engine:
         if ln is not None:
             norm, dst = ln
             ln = (self.pk.f32(norm.weight), self.pk.f32(norm.bias), norm.eps, dst)
-        self.ops.gemm(a, w, out, M=a.shape[0], N=N, bias=bias, residual=residual, act=act, **({"ln": ln} if ln is not None else {}))
+        kw = dict(M=a.shape[0], N=N, bias=bias, residual=residual, act=act, **({"ln": ln} if ln is not None else {}))
+        self.last_cs = self.last_rs = None
+        if lnf is not None:
+            kw["lnf"] = lnf
+            if not self.ops.gemm_fuse_supported(a, w, out, **kw):   # the caller falls back to LayerNorm + the plain pack
+                self.pool.put(out)
+                return None
+        elif want_cs:
+            self.last_cs = self._colstat_for(a, w, out, **kw)
+            if self.last_cs is not None:
+                kw["colstat"] = self.last_cs
+        elif want_rs and self.fold_ln and N % 32 == 0 and out.dtype == self.adt:
+            rs = self.buf(a.shape[0], N // 16, torch.float32)
+            if self.ops.gemm_fuse_supported(a, w, out, rowstat=rs, **kw):
+                self.pool.link(out, rs)
+                self.last_rs = kw["rowstat"] = rs
+            else:
+                self.pool.put(rs)
+        self.ops.gemm(a, w, out, **kw)
         return out
 
     # LayerNorm as a by-product of the GEMM that produces its input.  Opt-in (T2V_FUSE_LN=1): measured on MI355X it removes 30
@@ -297,9 +376,11 @@ class _Engine:
         wide_ok = C == 320 or not getattr(self.ops, "is_native", False)
         return self.fuse_ln and wide_ok and tuple(norm.normalized_shape) == (C,) and norm.elementwise_affine
 
-    def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto"):
+    def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto",
+             want_cs=True):
         """3x3 / strided / upsampled / temporal conv of an Act (virtual concat allowed); ``w`` / ``bias`` override the
-        module's packed forward weights (data-gradient convs pass the flipped / transposed pack and no bias)."""
+        module's packed forward weights (data-gradient convs pass the flipped / transposed pack and no bias).  With
+        ``fuse_gn`` the launch also writes its output's column statistics for the GroupNorm that follows every conv of the UNet."""
         w = self.pk.conv(mod) if w is None else w
         bias = self.pk.bias(mod) if isinstance(bias, str) else bias
         N = w.shape[0]
@@ -311,9 +392,13 @@ class _Engine:
             ho, wo = x.h, x.w
         M = x.n_img * ho * wo
         out = self.buf(M, N, out_dtype)
-        self.ops.gemm(x.parts[0], w, out, M=M, N=N, a1=x.p1, mode=mode, n_img=x.n_img, h=x.h, wd=x.w, frames=frames,
-                      bias=bias, rowvec=rowvec, rowvec_div=rowvec_div, residual=residual)
-        return Act(out, x.n_img, ho, wo)
+        kw = dict(M=M, N=N, a1=x.p1, mode=mode, n_img=x.n_img, h=x.h, wd=x.w, frames=frames, bias=bias, rowvec=rowvec,
+                  rowvec_div=rowvec_div, residual=residual)
+        cs = self._colstat_for(x.parts[0], w, out, **kw) if want_cs else None
+        if cs is not None:
+            kw["colstat"] = cs
+        self.ops.gemm(x.parts[0], w, out, **kw)
+        return Act(out, x.n_img, ho, wo, cs=[cs])
 
     # ---- plan management --------------------------------------------------------------------------------
     def _check_weights(self, module, skip=()):
@@ -352,6 +437,11 @@ class UNetEngine(_Engine):
     def __init__(self, model, ops):
         super().__init__(ops)
         self.model = model
+        # the inference engine takes GroupNorm statistics from the producing GEMMs' epilogues and folds the LayerNorms into the
+        # GEMMs that consume them (the gradient engine, a subclass, keeps the standalone kernels: its tape saves their inputs)
+        if type(self) is UNetEngine:
+            self.fuse_gn = os.environ.get("T2V_FUSE_GN", "1") == "1"
+            self.fold_ln = os.environ.get("T2V_FOLD_LN", "1") == "1"
 
     @on_tensor_device
     def __call__(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None):
@@ -494,7 +584,7 @@ class UNetEngine(_Engine):
         h = self.run_sequential(m.middle_block, h)
         for block in m.output_blocks:
             skip = hs.pop()
-            h = self.run_sequential(block, Act([h.t, skip.t], h.n_img, h.h, h.w), release=[h.t, skip.t])
+            h = self.run_sequential(block, Act([h.t, skip.t], h.n_img, h.h, h.w, cs=[h.cs[0], skip.cs[0]]), release=[h.t, skip.t])
         # ---- out: GroupNorm -> SiLU -> conv to 4 channels, fp32, back to (b c f h w) ------------------------------
         t = self.gn(h, m.out[0], B * F, H * W, True)
         y = self.conv(Act(t, h.n_img, h.h, h.w), m.out[2], nt.GEMM_CONV3X3, out_dtype=torch.float32)
@@ -599,9 +689,11 @@ class UNetEngine(_Engine):
         if attn.dim_head != 64:
             raise nt.NativeError(f"native attention kernels need dim_head == 64 (got {attn.dim_head})")
 
-    def transformer_block(self, blk, y, x_geom, temporal, ln1=None):
+    def transformer_block(self, blk, y, x_geom, temporal, ln1=None, rs=None):
         """BasicTransformerBlock on token rows y [M, C] (attention.py:300-311).  ``ln1``: norm1(y) if the GEMM that produced y
-        already wrote it (the buffer then serves the block's other two LayerNorms as well)."""
+        already wrote it (the buffer then serves the block's other two LayerNorms as well).  ``rs``: the row statistics of y its
+        producer wrote (``fold_ln``): a LayerNorm whose consumer is ONE GEMM over the normalised rows (temporal q|k|v, the text
+        cross-attention's q, the GEGLU projection) is then folded into that GEMM — no LayerNorm launch, no normalised tensor."""
         ops, pk = self.ops, self.pk
         B, F = self.B, self.F
         M, C = y.shape
@@ -609,15 +701,37 @@ class UNetEngine(_Engine):
         a1, a2 = blk.attn1, blk.attn2
         self._check_heads(a1)
         inner = a1.heads * a1.dim_head
-        ln = self.buf(M, C) if ln1 is None else ln1
-        fuse2, fuse3 = self.ln_fusable(C, blk.norm2), self.ln_fusable(C, blk.norm3)
+        box = {"ln": ln1}
+        fold = self.fold_ln and ln1 is None
+        fuse2, fuse3 = (self.ln_fusable(C, blk.norm2) and not fold), (self.ln_fusable(C, blk.norm3) and not fold)
+
+        def ln_buf():
+            if box["ln"] is None:
+                box["ln"] = self.buf(M, C)
+            return box["ln"]
 
         def lnorm(norm, src):
-            ops.layernorm(src, pk.f32(norm.weight), pk.f32(norm.bias), norm.eps, ln)
-            return ln
+            ops.layernorm(src, pk.f32(norm.weight), pk.f32(norm.bias), norm.eps, ln_buf())
+            return box["ln"]
 
-        def temporal_attn(attn, src):
-            qkv = self.linear(src, None, w=pk.cat_mats([attn.to_q, attn.to_k, attn.to_v], "qkv"), bias=None)
+        def foldable(norm, stats):
+            return (fold and stats is not None and tuple(norm.normalized_shape) == (C,) and norm.elementwise_affine and
+                    C % 64 == 0 and C <= 1280)
+
+        def folded(src, norm, stats, pack, act=nt.ACT_NONE):
+            """The GEMM that consumes LayerNorm(src), run on the raw rows with the LayerNorm folded in — or None where the fold
+            does not apply or the launch cannot carry it (the caller then normalises first)."""
+            if not foldable(norm, stats):
+                return None
+            wp, s_vec, t_vec = pack()
+            return self.linear(src, None, w=wp, bias=t_vec, act=act, lnf=(stats, norm.eps, s_vec))
+
+        def temporal_attn(attn, norm, src, stats):
+            # q | k | v of LayerNorm(src) as ONE GEMM
+            qkv = folded(src, norm, stats, lambda: pk.mat_lnf([attn.to_q, attn.to_k, attn.to_v], norm, "qkv_lnf"))
+            if qkv is None:
+                qkv = self.linear(lnorm(norm, src) if src is not box["ln"] else src, None,
+                                  w=pk.cat_mats([attn.to_q, attn.to_k, attn.to_v], "qkv"), bias=None)
             o = self.buf(M, inner)
             probs = None
             if attn.record_attn_probs:
@@ -642,8 +756,10 @@ class UNetEngine(_Engine):
             self.pool.put(qk, vt)
             return o
 
-        def cross_attn(attn, src):
-            q = self.linear(src, attn.to_q, bias=None)
+        def cross_attn(attn, norm, src, stats):
+            q = folded(src, norm, stats, lambda: pk.mat_lnf([attn.to_q], norm, "q_lnf"))
+            if q is None:
+                q = self.linear(lnorm(norm, src) if src is not box["ln"] else src, attn.to_q, bias=None)
             k, vt, kp, vt_stride = self.context_kv(attn)
             o = self.buf(M, inner)
             ops.attn_spatial(q, k, vt, kp, o, n_img, hw, self.ctx_len, attn.heads, F, attn.scale, vt_stride)
@@ -652,61 +768,63 @@ class UNetEngine(_Engine):
 
         # attn1: self attention (spatial or temporal).  Every consumer of a LayerNorm output has been launched before the next
         # producer overwrites the shared buffer (stream order), fused or not.
-        src = ln if ln1 is not None else lnorm(blk.norm1, y)
-        o = temporal_attn(a1, src) if temporal else spatial_self_attn(a1, src)
-        y1 = self.linear(o, a1.to_out[0], residual=y, ln=(blk.norm2, ln) if fuse2 else None)
+        if temporal:
+            o = temporal_attn(a1, blk.norm1, ln1 if ln1 is not None else y, rs)
+        else:  # two consumers (q|k and V^T, the latter with the tokens as its column operand): the LayerNorm stays a launch
+            o = spatial_self_attn(a1, ln1 if ln1 is not None else lnorm(blk.norm1, y))
+        y1 = self.linear(o, a1.to_out[0], residual=y, ln=(blk.norm2, ln_buf()) if fuse2 else None, want_rs=fold)
+        rs1 = self.last_rs
         self.pool.put(o)
         # attn2: temporal self attention again, or text cross attention
-        src = ln if fuse2 else lnorm(blk.norm2, y1)
-        o = temporal_attn(a2, src) if temporal else cross_attn(a2, src)
-        y2 = self.linear(o, a2.to_out[0], residual=y1, ln=(blk.norm3, ln) if fuse3 else None)
+        src = box["ln"] if fuse2 else y1
+        o = temporal_attn(a2, blk.norm2, src, rs1) if temporal else cross_attn(a2, blk.norm2, src, rs1)
+        y2 = self.linear(o, a2.to_out[0], residual=y1, ln=(blk.norm3, ln_buf()) if fuse3 else None, want_rs=fold)
+        rs2 = self.last_rs
         self.pool.put(o, y1)
         # GEGLU feed-forward
-        src = ln if fuse3 else lnorm(blk.norm3, y2)
         proj = blk.ff.net[0]
         assert hasattr(proj, "proj"), "non-gated FeedForward is not built by the VideoCrafter2 config"
-        wg, bg = pk.geglu(proj.proj)
-        g = self.linear(src, None, w=wg, bias=bg, act=nt.ACT_GEGLU)
+        g = folded(y2, blk.norm3, rs2, lambda: pk.geglu_lnf(proj.proj, blk.norm3), act=nt.ACT_GEGLU)
+        if g is None:
+            src = box["ln"] if fuse3 else lnorm(blk.norm3, y2)
+            wg, bg = pk.geglu(proj.proj)
+            g = self.linear(src, None, w=wg, bias=bg, act=nt.ACT_GEGLU)
         y3 = self.linear(g, blk.ff.net[2], residual=y2)
-        self.pool.put(g, y2, ln)
+        self.pool.put(g, y2, box["ln"])
         return y3
 
-    def _proj_in_with_ln(self, t, proj_in, blocks):
-        """proj_in (a Linear: use_linear=True) and, where the tile holds whole rows, norm1 of the first block from the same launch."""
+    def _proj_in_with_ln(self, t, proj_in, blocks, temporal):
+        """proj_in (a Linear: use_linear=True) and, where the tile holds whole rows, norm1 of the first block from the same launch
+        — or, with ``fold_ln`` in a temporal transformer, the row statistics its first (folded) LayerNorm needs."""
         blk0 = blocks[0] if len(blocks) else None
         C = leaf_out_channels(proj_in)
+        if self.fold_ln:
+            y = self.linear(t, proj_in, want_rs=temporal and blk0 is not None)
+            return y, None, self.last_rs
         is_linear = isinstance(proj_in, nn.Linear) or isinstance(getattr(proj_in, "linear", None), nn.Linear)  # (or LoRA-injected)
         if blk0 is not None and is_linear and self.ln_fusable(C, blk0.norm1):
             ln1 = self.buf(t.shape[0], C)
-            return self.linear(t, proj_in, ln=(blk0.norm1, ln1)), ln1
-        return self.linear(t, proj_in), None
+            return self.linear(t, proj_in, ln=(blk0.norm1, ln1)), ln1, None
+        return self.linear(t, proj_in), None, None
+
+    def _transformer(self, tr, x, units, rows_per_unit, temporal):
+        t = self.gn(x, tr.norm, units, rows_per_unit, False)
+        y, ln1, rs = self._proj_in_with_ln(t, tr.proj_in, tr.transformer_blocks, temporal)
+        self.pool.put(t)
+        for i, blk in enumerate(tr.transformer_blocks):
+            if i > 0 and self.fold_ln:
+                rs = None   # (depth > 1: the previous block's feed-forward output carries no statistics; its norm1 is a launch)
+            ny = self.transformer_block(blk, y, (x.n_img, x.h * x.w), temporal=temporal, ln1=ln1, rs=rs)
+            ln1 = None
+            self.pool.put(y)
+            y = ny
+        out = self.linear(y, tr.proj_out, residual=x.t, want_cs=True)   # the next layer starts with a GroupNorm
+        cs = self.last_cs
+        self.pool.put(y)
+        return Act(out, x.n_img, x.h, x.w, cs=[cs])
 
     def spatial_transformer(self, st, x):
-        B, F = self.B, self.F
-        hw = x.h * x.w
-        t = self.gn(x, st.norm, B * F, hw, False)
-        y, ln1 = self._proj_in_with_ln(t, st.proj_in, st.transformer_blocks)
-        self.pool.put(t)
-        for blk in st.transformer_blocks:
-            ny = self.transformer_block(blk, y, (x.n_img, hw), temporal=False, ln1=ln1)
-            ln1 = None
-            self.pool.put(y)
-            y = ny
-        out = self.linear(y, st.proj_out, residual=x.t)
-        self.pool.put(y)
-        return Act(out, x.n_img, x.h, x.w)
+        return self._transformer(st, x, self.B * self.F, x.h * x.w, temporal=False)
 
     def temporal_transformer(self, tt, x):
-        B, F = self.B, self.F
-        hw = x.h * x.w
-        t = self.gn(x, tt.norm, B, F * hw, False)
-        y, ln1 = self._proj_in_with_ln(t, tt.proj_in, tt.transformer_blocks)
-        self.pool.put(t)
-        for blk in tt.transformer_blocks:
-            ny = self.transformer_block(blk, y, (x.n_img, hw), temporal=True, ln1=ln1)
-            ln1 = None
-            self.pool.put(y)
-            y = ny
-        out = self.linear(y, tt.proj_out, residual=x.t)
-        self.pool.put(y)
-        return Act(out, x.n_img, x.h, x.w)
+        return self._transformer(tt, x, self.B, self.F * x.h * x.w, temporal=True)

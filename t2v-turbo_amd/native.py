@@ -38,6 +38,8 @@ class GemmDesc(C.Structure):
         ("drop_seed", C.c_void_p), ("drop_thr", C.c_uint), ("drop_site", C.c_uint), ("drop_inv_keep", C.c_float),
         ("drop_ncols", C.c_int), ("drop_col0", C.c_int),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p), ("ld_ln_out", C.c_int),
+        ("rowstat_out", C.c_void_p), ("ld_rowstat", C.c_int), ("colstat_out", C.c_void_p),
+        ("lnf_stats", C.c_void_p), ("lnf_ld", C.c_int), ("lnf_nblk", C.c_int), ("lnf_eps", C.c_float), ("lnf_s", C.c_void_p),
     ]
 
 
@@ -52,6 +54,7 @@ _SIGS = {
     "t2v_init": (C.c_int, []),
     "t2v_last_error": (C.c_char_p, []),
     "t2v_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "t2v_gemm_fuse_supported": (C.c_int, [C.POINTER(GemmDesc)]),
     "t2v_gemm_force_config": (C.c_int, [C.c_int]),
     "t2v_gemm_force_split": (C.c_int, [C.c_int]),
     "t2v_gemm_num_configs": (C.c_int, []),
@@ -66,6 +69,9 @@ _SIGS = {
     "t2v_group_norm_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "t2v_group_norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "t2v_group_norm_cs_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "t2v_group_norm_cs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "t2v_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                 C.c_void_p, C.c_int, C.c_void_p]),
     "t2v_softmax_rows": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -243,12 +249,26 @@ class HipOps:
                 _check(rc, name)
 
     # -- ops ----------------------------------------------------------------------------------------
-    def gemm(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
-             rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
-             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None, ln=None):
+    def gemm(self, a0, w, out, **kw):
         """``dropout``: (p, seed tensor [1] int64 on the device, site, ncols, col0) — the mask of ``dropout()`` over a
         [M, ncols] matrix whose columns col0 .. col0 + N are this launch's output, applied to alpha*acc + bias before the
-        residual (include/t2v_hip.h)."""
+        residual (include/t2v_hip.h).  ``rowstat`` / ``colstat``: fp32 tensors that receive the row / column statistics of the
+        output for the next LayerNorm / GroupNorm; ``lnf``: (producer's rowstat [M, ld], eps, s [N] fp32) — this launch consumes a
+        LayerNorm folded into its weights (t2v_gemm_desc::lnf_*).  Ask ``gemm_fuse_supported`` (same arguments) first."""
+        self._call("t2v_gemm", C.byref(self._gemm_desc(a0, w, out, **kw)))  # the byref object holds a reference to d: a recording keeps its descriptors alive
+
+    def gemm_fuse_supported(self, a0, w, out, **kw):
+        """Would ``gemm`` with these arguments honour its rowstat / colstat / lnf request?  (Resolves tile and split-K as the
+        launch does; launches nothing.)"""
+        rc = self.lib.t2v_gemm_fuse_supported(C.byref(self._gemm_desc(a0, w, out, **kw)))
+        if rc < 0:
+            _check(rc, "t2v_gemm_fuse_supported")
+        return rc == 1
+
+    def _gemm_desc(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
+                   rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
+                   a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None, ln=None,
+                   rowstat=None, colstat=None, lnf=None):
         d = GemmDesc()
         d.a0, d.c0, d.lda0 = _p(a0), a0.shape[1], _row_stride(a0)
         if a1 is not None:
@@ -285,9 +305,19 @@ class HipOps:
         if ln is not None:  # (gamma fp32 [N], beta fp32 [N], eps, out2 bf16 [M, N]): LayerNorm(out) as a second output (N == 320)
             gamma, beta, eps, out2 = ln
             d.ln_gamma, d.ln_beta, d.ln_eps, d.ln_out, d.ld_ln_out = _p(gamma), _p(beta), float(eps), _p(out2), _row_stride(out2)
+        if rowstat is not None:   # fp32 [M, ld]: (sum, sumsq) per 32-column block of every output row
+            assert rowstat.dtype == torch.float32 and rowstat.shape[0] == M
+            d.rowstat_out, d.ld_rowstat = _p(rowstat), _row_stride(rowstat)
+        if colstat is not None:   # fp32 [M / 32, N, 2]: (sum, sumsq) per column of every 32-row slab
+            assert colstat.dtype == torch.float32 and colstat.is_contiguous() and colstat.numel() == (M // 32) * N * 2
+            d.colstat_out = _p(colstat)
+        if lnf is not None:
+            stats, eps, s_vec = lnf
+            assert stats.dtype == torch.float32 and s_vec.dtype == torch.float32 and stats.shape[0] == M
+            d.lnf_stats, d.lnf_ld, d.lnf_nblk, d.lnf_eps, d.lnf_s = _p(stats), _row_stride(stats), a0.shape[1] // 32, float(eps), _p(s_vec)
         ws = self.workspace(a0.device)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
-        self._call("t2v_gemm", C.byref(d))  # the byref object holds a reference to d: a recording keeps its descriptors alive
+        return d
 
     def conv_small(self, x, n_img, h, w, wgt, bias, out):
         self._call("t2v_conv3x3_small_cin", _p(x), n_img, h, w, x.shape[1], _p(wgt), _p(bias), out.shape[1], _p(out))
@@ -310,6 +340,15 @@ class HipOps:
 
     def group_norm(self, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32):
         self._call("t2v_group_norm", _p(x0), x0.shape[1], _row_stride(x0), _p(x1),
+                   0 if x1 is None else x1.shape[1], 0 if x1 is None else _row_stride(x1),
+                   n_units, rows_per_unit, groups, eps, _p(gamma), _p(beta), int(silu), _p(ws), _p(out), _row_stride(out))
+
+    def group_norm_cs_ws_floats(self, n_units, rows_per_unit, groups):
+        return int(self.lib.t2v_group_norm_cs_ws_floats(n_units, rows_per_unit, groups))
+
+    def group_norm_cs(self, cs0, cs1, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32):
+        """GroupNorm(+SiLU) on the column statistics the producing GEMMs wrote (``gemm(colstat=...)``): no statistics pass."""
+        self._call("t2v_group_norm_cs", _p(cs0), _p(cs1), _p(x0), x0.shape[1], _row_stride(x0), _p(x1),
                    0 if x1 is None else x1.shape[1], 0 if x1 is None else _row_stride(x1),
                    n_units, rows_per_unit, groups, eps, _p(gamma), _p(beta), int(silu), _p(ws), _p(out), _row_stride(out))
 

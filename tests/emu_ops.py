@@ -36,8 +36,12 @@ class EmuOps:
     # ------------------------------------------------------------------------------------ gemm
     def gemm(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
              rowvec=None, rowvec_div=0, residual=None, act=nt.ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
-             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None, ln=None):
+             a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None, ln=None,
+             rowstat=None, colstat=None, lnf=None):
         self._log("gemm")
+        if rowstat is not None or colstat is not None or lnf is not None:
+            assert self.gemm_fuse_supported(a0, w, out, M=M, N=N, a1=a1, mode=mode, bias=bias, rowvec=rowvec, residual=residual, act=act,
+                                            alpha=alpha, batch=batch, dropout=dropout, ln=ln, rowstat=rowstat, colstat=colstat, lnf=lnf)
         if ln is not None:
             assert batch == 1 and act == nt.ACT_NONE and alpha == 1.0, "LN output: no batch / activation / alpha (the device kernel: N == 320)"
         # device-side argument rules (csrc/gemm.hip, t2v_gemm): operand row strides, batch strides and base addresses
@@ -89,6 +93,14 @@ class EmuOps:
                 y = y.permute(0, 2, 3, 1).reshape(-1, N)
             assert y.shape[0] == M, (y.shape, M)
             y = y * alpha
+            if lnf is not None:  # LayerNorm folded into the GEMM: raw rows in A, W diag(gamma) in W, statistics from the producer
+                stats, eps_ln, s_vec = lnf
+                nb = cin // 32
+                st = stats.float()[:, :2 * nb].reshape(M, nb, 2)
+                mean = st[:, :, 0].sum(dim=1) / cin
+                var = (st[:, :, 1].sum(dim=1) / cin - mean * mean).clamp_min(0.0)
+                rstd = 1.0 / torch.sqrt(var + eps_ln)
+                y = rstd[:, None] * (y - mean[:, None] * s_vec.float()[None, :N])
             if bias is not None:
                 y = y + bias.float()[None, :N]
             if dropout is not None and dropout[0] > 0:  # the dropout epilogue of t2v_gemm: the mask of dropout() on its column block
@@ -109,9 +121,33 @@ class EmuOps:
             if act == nt.ACT_SILU:
                 y = F.silu(y)
             _strided(out, M, n_out, out.stride(0), o_off).copy_(y.to(out.dtype))
+            if rowstat is not None:  # (sum, sumsq) of the fp32 epilogue values per row and 32-column block
+                yb = y.reshape(M, N // 32, 32)
+                rowstat[:, :2 * (N // 32)] = torch.stack([yb.sum(dim=2), (yb * yb).sum(dim=2)], dim=2).reshape(M, -1)
+            if colstat is not None:  # (sum, sumsq) per column of every 32-row slab, of the values as stored (output dtype)
+                yo = y.to(out.dtype).float().reshape(M // 32, 32, n_out)
+                colstat.view(M // 32, n_out, 2).copy_(torch.stack([yo.sum(dim=1), (yo * yo).sum(dim=1)], dim=2))
             if ln is not None:  # LayerNorm of the fp32 epilogue values (before they are rounded to the output dtype), second output
                 gamma, beta, eps, out2 = ln
                 out2[:, :N] = F.layer_norm(y, (N,), gamma.float(), beta.float(), eps).to(out2.dtype)
+
+    def gemm_fuse_supported(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, bias=None, rowvec=None, residual=None,
+                            act=nt.ACT_NONE, alpha=1.0, batch=1, dropout=None, ln=None, rowstat=None, colstat=None, lnf=None, **_):
+        """The argument rules of t2v_gemm_fuse_supported (csrc/gemm.hip) that do not depend on the tile: the emulated backend
+        takes the fused form wherever the descriptor allows it, so that the CPU suite covers the dataflow at every width."""
+        n_req = sum(x is not None for x in (rowstat, colstat, lnf))
+        if n_req != 1 or batch != 1 or ln is not None or alpha != 1.0 or (dropout is not None and dropout[0] > 0):
+            return False
+        n_out = N // 2 if act == nt.ACT_GEGLU else N
+        if out.dtype != self.act_dtype or n_out % 16 or N % 16:
+            return False
+        if rowstat is not None:
+            return N % 32 == 0 and act == nt.ACT_NONE and rowstat.stride(0) >= N // 16 and rowstat.stride(0) % 4 == 0
+        if colstat is not None:
+            return M % 32 == 0 and act != nt.ACT_GEGLU
+        cin = a0.shape[1]
+        return (mode == nt.GEMM_LINEAR and a1 is None and bias is not None and residual is None and rowvec is None and cin % 64 == 0
+                and cin <= 1280 and act != nt.ACT_SILU and lnf[0].stride(0) >= cin // 16 and lnf[0].stride(0) % 4 == 0)
 
     def conv_small(self, x, n_img, h, w, wgt, bias, out):
         self._log("conv_small")
@@ -158,6 +194,27 @@ class EmuOps:
         stats = torch.empty(n_units, groups * 2)
         self.gn_stats(x0, x1, n_units, rows_per_unit, eps, ws, stats, groups)
         self.gn_apply(x0, x1, n_units, rows_per_unit, stats, gamma, beta, silu, out, groups)
+
+    def group_norm_cs_ws_floats(self, n_units, rows_per_unit, groups):
+        return 8
+
+    def group_norm_cs(self, cs0, cs1, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32):
+        """GroupNorm(+SiLU) with the statistics taken from the producers' column statistics cs [rows / 32, C, 2]."""
+        self._log("group_norm_cs")
+        assert rows_per_unit % 32 == 0 and (x1 is None) == (cs1 is None)
+        x = self._cat(x0, x1)
+        C = x.shape[1]
+        cs = cs0.float().view(-1, x0.shape[1], 2)
+        if cs1 is not None:
+            cs = torch.cat([cs, cs1.float().view(-1, x1.shape[1], 2)], dim=1)
+        assert cs.shape[0] == n_units * rows_per_unit // 32
+        sums = cs.view(n_units, rows_per_unit // 32, groups, C // groups, 2).sum(dim=(1, 3))    # [units, groups, 2]
+        cnt = rows_per_unit * (C // groups)
+        mean = sums[:, :, 0] / cnt
+        var = (sums[:, :, 1] / cnt - mean * mean).clamp_min(0.0)
+        stats = torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=2).reshape(n_units, groups * 2)
+        self.gn_apply(x0, x1, n_units, rows_per_unit, stats, gamma, beta, silu, out, groups)
+        self.calls.pop()   # (one logical op)
 
     # ------------------------------------------------------------------------------------ backward pieces
     def gn_bwd_ws_floats(self, n_units, rows_per_unit, groups=32):
@@ -448,7 +505,7 @@ class ReplayOps:
     Python closures every time.  Catches what only that mode can get wrong: state that lives in Python during recording but
     not during a replay, buffers recycled between the forward and backward lists, inputs that are not static."""
     is_native = True
-    _PURE = ("gn_ws_floats", "gn_bwd_ws_floats", "group_norm_ws_floats", "dropout_keep", "masks", "calls", "strict")
+    _PURE = ("gn_ws_floats", "gn_bwd_ws_floats", "group_norm_ws_floats", "group_norm_cs_ws_floats", "gemm_fuse_supported", "dropout_keep", "masks", "calls", "strict")
 
     def __init__(self, inner=None):
         self.inner = inner or EmuOps(strict=True)

@@ -39,6 +39,7 @@ struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
 
 typedef void* hipStream_t;
 typedef int hipError_t;

@@ -153,7 +153,7 @@ def test_unet_engine_with_layernorm_fused_into_the_producing_gemm():
     for fuse in (False, True):
         ops = EmuOps()
         eng = UNetEngine(m, ops)
-        eng.fuse_ln = fuse
+        eng.fuse_ln, eng.fold_ln = fuse, False      # (the default since round 3 is the fold below, which supersedes this form)
         with torch.no_grad():
             y = eng(g["x"], g["ts"], g["ctx"], 16, g["tc"], None)
         assert rel_l2(y, g["y"]) < 2e-5, fuse
@@ -162,3 +162,34 @@ def test_unet_engine_with_layernorm_fused_into_the_producing_gemm():
     assert counts[False]["layernorm"] == n_ln and counts[True]["gemm"] == counts[False]["gemm"]
     # init_attn's proj_in is a Conv1d (openaimodel3d.py:439-453): its first LayerNorm stays a launch of its own
     assert 0 < counts[True]["layernorm"] <= 2
+
+
+def test_unet_engine_norm_statistics_from_the_producing_gemms():
+    """The inference engine's default dataflow since round 3: GroupNorm statistics come from the column statistics the producing
+    GEMMs write (no statistics pass), and every LayerNorm with a single consuming GEMM (temporal q|k|v, text cross-attention q,
+    the GEGLU projection) is folded into that GEMM on the raw rows (no LayerNorm launch, no normalised tensor).  Against the
+    reference golden on the emulated backend, and launch counts against the un-fused dataflow."""
+    from t2v_turbo_amd.unet3d import SpatialTransformer
+    for fixture, extra in (("unet_tiny", {}), ("unet_tiny_mg_b2", {"motion_cond_proj_dim": 256})):
+        g = load(fixture)
+        m = UNetModel(**tiny_unet_params(**extra)).eval()
+        m.load_state_dict(synth_state_dict(manifest(fixture)), strict=True)
+        kw = dict(fps=g["fps"].item() if "fps" in g else 16)
+        args = (g["x"], g["ts"], g["ctx"], 8 if fixture.endswith("b2") else 16, g["tc"], g.get("mc"))
+        counts = {}
+        for fused in (False, True):
+            ops = EmuOps()
+            eng = UNetEngine(m, ops)
+            eng.fuse_gn = eng.fold_ln = fused
+            with torch.no_grad():
+                y = eng(*args)
+            assert rel_l2(y, g["y"]) < 2e-5, (fixture, fused)
+            counts[fused] = {name: ops.calls.count(name) for name in ("layernorm", "gemm", "group_norm", "group_norm_cs")}
+        n_ln = sum(1 for mod in m.modules() if isinstance(mod, torch.nn.LayerNorm))
+        n_sp = sum(len(mod.transformer_blocks) for mod in m.modules() if isinstance(mod, SpatialTransformer))
+        assert counts[False]["layernorm"] == n_ln and counts[False]["group_norm_cs"] == 0
+        assert counts[True]["layernorm"] == n_sp          # only the spatial self-attention's norm1 (two consumers) stays a launch
+        assert counts[True]["gemm"] == counts[False]["gemm"]
+        # GroupNorm: every statistics unit of >= 32 rows whose input came out of a GEMM takes the producer's statistics
+        n_gn = counts[False]["group_norm"]
+        assert counts[True]["group_norm"] + counts[True]["group_norm_cs"] == n_gn and counts[True]["group_norm_cs"] > n_gn // 3

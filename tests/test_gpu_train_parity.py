@@ -330,7 +330,9 @@ def run_trainer_route(dev, emu_factory, loss_tol, cos_min):
                                 autocast_dtype=torch.bfloat16 if on_gpu else None, **kw)
         g2 = sync.flat.clone()
     box = student._engine_box
-    assert box.grad is not None and box.enc is not None, "student forward / target forward did not run on the gradient engine"
+    # eval-mode student (no dropout): the grad-mode forward lands on the gradient engine, the no-grad target forward on the
+    # inference engine with the LoRA branch merged at pack time (train mode would take the gradient engine's forward-only twin)
+    assert box.grad is not None and (box.enc is not None or box.engine is not None), "the student did not run on the native engines"
     assert not on_gpu or teacher._engine_box.engine is not None, "the teacher did not run on the inference engine"
     assert len(box.grad.plans) == 1 and box.grad._last["fwd_id"] >= 2, "step 2 must replay step 1's recorded plan"
     assert float((p1 - p0).abs().mean()) > 1e-2, "the optimizer did not move the parameters"

@@ -202,3 +202,31 @@ def test_optimizer_and_scheduler_kernels_on_the_real_library(full_ops):
     ops.lincomb3(x, y, z, [0.5], [-1.5], [2.0], o_s)
     emu.lincomb3(x, y, z, [0.5], [-1.5], [2.0], o_e)
     assert torch.allclose(o_s, o_e, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("c0,c1,units,rows,silu", [(320, 0, 2, 64, True), (128, 64, 1, 160, True), (64, 64, 3, 32, False)])
+def test_group_norm_from_the_producers_column_statistics(full_ops, c0, c1, units, rows, silu):
+    """t2v_group_norm_cs (csrc/norm.hip): GroupNorm whose statistics come from per-32-row column sums (what t2v_gemm's colstat_out
+    writes) instead of a pass over the tensor — single tensors and virtual concats, several units, against the plain GroupNorm."""
+    from tests.emu_ops import EmuOps
+    sim, emu = full_ops(), EmuOps()
+    gen = torch.Generator().manual_seed(c0 + rows)
+    C, M = c0 + c1, units * rows
+    x0 = (torch.randn(M, c0, generator=gen) * 1.3 + 0.4).bfloat16()
+    x1 = (torch.randn(M, c1, generator=gen) * 0.7 - 0.2).bfloat16() if c1 else None
+    gamma, beta = torch.randn(C, generator=gen) * 0.2 + 1.0, torch.randn(C, generator=gen) * 0.1
+
+    def colstats(t):
+        v = t.float().reshape(M // 32, 32, -1)
+        return torch.stack([v.sum(1), (v * v).sum(1)], dim=2).contiguous()
+
+    cs0, cs1 = colstats(x0), (colstats(x1) if c1 else None)
+    out_s = torch.full((M, C), float("nan"), dtype=torch.bfloat16)
+    ws = torch.zeros(max(sim.group_norm_cs_ws_floats(units, rows, 32), 1))
+    sim.group_norm_cs(cs0, cs1, x0, x1, units, rows, 1e-5, gamma, beta, silu, ws, out_s)
+    out_e = torch.zeros(M, C)
+    emu.group_norm(x0.float(), None if x1 is None else x1.float(), units, rows, 1e-5, gamma, beta, silu, None, out_e)
+    assert torch.isfinite(out_s.float()).all() and rel_l2(out_s.float(), out_e) < 4e-3
+    out_e2 = torch.zeros(M, C)
+    emu.group_norm_cs(cs0, cs1, x0.float(), None if x1 is None else x1.float(), units, rows, 1e-5, gamma, beta, silu, None, out_e2)
+    assert rel_l2(out_e2, out_e) < 1e-5

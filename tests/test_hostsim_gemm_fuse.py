@@ -1,0 +1,149 @@
+"""The fused-statistics variants of t2v_gemm (csrc/gemm_fuse.hip) on the host SIMT simulator: row statistics for the next
+LayerNorm, column statistics per 32-row slab for the next GroupNorm, and the LayerNorm folded into the consuming GEMM
+(attention.py:300-311 / openaimodel3d.py:223-254 without the normalisation passes) — every tile id that carries them, against
+the emulated backend, before any of it ran on hardware.  The calibration of the simulator is tests/test_hostsim_gemm.py."""
+import os
+import shutil
+import sys
+
+import pytest
+import torch
+
+from t2v_turbo_amd import native as nt
+from tests.emu_ops import EmuOps
+from tests.util import rel_l2
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim"))
+
+BF16_TOL = 4e-3
+FUSED_TILES = [4, 5, 7, 9, 11, 12, 16, 17, 19, 20, 23, 31]
+EMU = EmuOps()
+
+
+def _rt(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).bfloat16().float()
+
+
+def _bf(t):
+    return None if t is None else t.bfloat16().contiguous()
+
+
+@pytest.fixture(scope="module")
+def sim():
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    import build as hostsim_build
+    from tests.test_hostsim_kernels import HostSimOps
+    ops = HostSimOps(hostsim_build.build_gemm())
+    ops.tune, ops._ws = {}, {}
+    return ops
+
+
+@pytest.mark.parametrize("cfg", FUSED_TILES)
+def test_row_statistics_of_the_output(sim, cfg):
+    """Producer of a LayerNorm input: out-projection with bias and residual (fast kernel: the accumulators start there)."""
+    M, N, K = 200, 320, 128
+    a, w, b, res = _rt(M, K, seed=1), _rt(N, K, seed=2, scale=K ** -0.5), _rt(N, seed=3), _rt(M, N, seed=4)
+    out_s = torch.full((M, N), float("nan"), dtype=torch.bfloat16)
+    rs_s = torch.full((M, 2 * (N // 32) + 4), 7.0)
+    out_e, rs_e = torch.zeros(M, N), torch.zeros(M, 2 * (N // 32) + 4)
+    kw = dict(M=M, N=N, bias=b)
+    assert sim.gemm_fuse_supported(_bf(a), _bf(w), out_s, residual=_bf(res), rowstat=rs_s, tile_cfg=cfg, **kw)
+    sim.gemm(_bf(a), _bf(w), out_s, residual=_bf(res), rowstat=rs_s, tile_cfg=cfg, **kw)
+    EMU.gemm(a, w, out_e, residual=res, rowstat=rs_e, **kw)
+    assert rel_l2(out_s.float(), out_e) < BF16_TOL
+    nb = N // 32
+    assert rel_l2(rs_s[:, :2 * nb], rs_e[:, :2 * nb]) < 1e-4
+    assert float(rs_s[:, 2 * nb:].min()) == 7.0 and float(rs_s[:, 2 * nb:].max()) == 7.0   # nothing written past the blocks
+    # the statistics give the LayerNorm of the stored rows
+    st = rs_s[:, :2 * nb].reshape(M, nb, 2)
+    mean = st[:, :, 0].sum(1) / N
+    var = st[:, :, 1].sum(1) / N - mean * mean
+    assert torch.allclose(mean, out_e.mean(1), atol=2e-3) and torch.allclose(var, out_e.var(1, unbiased=False), rtol=2e-2, atol=1e-3)
+
+
+@pytest.mark.parametrize("cfg", FUSED_TILES)
+def test_column_statistics_per_slab(sim, cfg):
+    """Producer of a GroupNorm input: 3x3 conv with the time-embedding row vector, and a (3,1,1) conv with a residual; the
+    statistics must be those of the bf16 values the kernel stored (what the consumer reads), slab by slab."""
+    n, h, w, c0, N = 2, 8, 8, 64, 192          # M = 128: four slabs
+    M = n * h * w
+    x, wt, b = _rt(M, c0, seed=1), _rt(N, 9 * c0, seed=2, scale=(9 * c0) ** -0.5), _rt(N, seed=3)
+    rv = _rt(n, N, seed=4)
+    out_s = torch.full((M, N), float("nan"), dtype=torch.bfloat16)
+    cs_s = torch.full((M // 32, N, 2), float("nan"))
+    out_e, cs_e = torch.zeros(M, N), torch.zeros(M // 32, N, 2)
+    kw = dict(M=M, N=N, mode=nt.GEMM_CONV3X3, n_img=n, h=h, wd=w, bias=b, rowvec_div=h * w)
+    assert sim.gemm_fuse_supported(_bf(x), _bf(wt), out_s, rowvec=rv, colstat=cs_s, tile_cfg=cfg, **kw)
+    sim.gemm(_bf(x), _bf(wt), out_s, rowvec=rv, colstat=cs_s, tile_cfg=cfg, **kw)
+    EMU.gemm(x, wt, out_e, rowvec=rv, colstat=cs_e, **kw)
+    assert rel_l2(out_s.float(), out_e) < BF16_TOL
+    stored = out_s.float().reshape(M // 32, 32, N)
+    want = torch.stack([stored.sum(1), (stored * stored).sum(1)], dim=2)
+    assert torch.isfinite(cs_s).all() and rel_l2(cs_s, want) < 1e-5      # exactly the stored values' sums (fp32 order aside)
+    assert rel_l2(cs_s, cs_e) < 2e-2
+    # temporal conv + residual, M = 2 clips x 4 frames x 8 pixels = 64 rows, N not a multiple of the wave tile
+    F, hw, C = 4, 8, 64
+    M2 = 2 * F * hw
+    x2, w2, r2 = _rt(M2, C, seed=5), _rt(320, 3 * C, seed=6, scale=(3 * C) ** -0.5), _rt(M2, 320, seed=7)
+    o2 = torch.full((M2, 320), float("nan"), dtype=torch.bfloat16)
+    cs2 = torch.full((M2 // 32, 320, 2), float("nan"))
+    kw2 = dict(M=M2, N=320, mode=nt.GEMM_TCONV3, n_img=2 * F, h=2, wd=4, frames=F)
+    sim.gemm(_bf(x2), _bf(w2), o2, residual=_bf(r2), colstat=cs2, tile_cfg=cfg, **kw2)
+    st2 = o2.float().reshape(M2 // 32, 32, 320)
+    assert rel_l2(cs2, torch.stack([st2.sum(1), (st2 * st2).sum(1)], dim=2)) < 1e-5
+
+
+def _ln_fold_operands(M, C, N, seed, geglu=False):
+    """Raw rows x, LayerNorm affine, consumer Linear -> what the folded launch takes and what the unfolded reference gives."""
+    x = _rt(M, C, seed=seed) * 1.5 + 0.3
+    gamma, beta = _rt(C, seed=seed + 1) * 0.2 + 1.0, _rt(C, seed=seed + 2) * 0.1
+    W, b = _rt(N, C, seed=seed + 3, scale=C ** -0.5), _rt(N, seed=seed + 4)
+    wp = (W * gamma[None, :]).bfloat16().float()           # W diag(gamma), as packed (bf16)
+    s_vec = wp.sum(dim=1)                                   # row sums of the PACKED weights
+    t_vec = b + W @ beta
+    ref = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5) @ W.t() + b
+    if geglu:   # packed [32 value | 32 gate] column groups: emulate on the packed columns directly
+        g = ref.reshape(M, N // 64, 2, 32)
+        ref = (g[:, :, 0] * torch.nn.functional.gelu(g[:, :, 1])).reshape(M, N // 2)
+    return x, wp, s_vec, t_vec, ref
+
+
+@pytest.mark.parametrize("cfg", FUSED_TILES)
+@pytest.mark.parametrize("C,N,geglu", [(320, 192, False), (128, 256, True), (512, 128, False)])
+def test_layernorm_folded_into_the_consumer(sim, cfg, C, N, geglu):
+    if geglu and cfg in (5, 9, 23, 31):
+        pytest.skip("GEGLU needs 64-wide wave tiles in N")
+    M = 200
+    x, wp, s_vec, t_vec, ref = _ln_fold_operands(M, C, N, seed=10 + C, geglu=geglu)
+    # the producer's statistics: any launch that writes x with rowstat — here an identity GEMM would do; take the emulation
+    nb = C // 32
+    xb = x.reshape(M, nb, 32)
+    stats = torch.zeros(M, 2 * nb + 4)
+    stats[:, :2 * nb] = torch.stack([xb.sum(2), (xb * xb).sum(2)], dim=2).reshape(M, -1)
+    act = nt.ACT_GEGLU if geglu else nt.ACT_NONE
+    n_out = N // 2 if geglu else N
+    out_s = torch.full((M, n_out), float("nan"), dtype=torch.bfloat16)
+    out_e = torch.zeros(M, n_out)
+    kw = dict(M=M, N=N, bias=t_vec, act=act, lnf=(stats, 1e-5, s_vec))
+    assert sim.gemm_fuse_supported(_bf(x), _bf(wp), out_s, tile_cfg=cfg, **kw)
+    sim.gemm(_bf(x), _bf(wp), out_s, tile_cfg=cfg, **kw)
+    EMU.gemm(x, wp, out_e, **kw)
+    assert torch.isfinite(out_s.float()).all()
+    assert rel_l2(out_s.float(), out_e) < BF16_TOL
+    assert rel_l2(out_e, ref) < 6e-3          # the folded form IS LayerNorm -> Linear (up to the bf16 rounding of W diag(gamma))
+
+
+def test_unsupported_requests_are_refused_not_ignored(sim):
+    M, N, K = 64, 64, 64
+    a, w = _bf(_rt(M, K)), _bf(_rt(N, K))
+    out32 = torch.zeros(M, N)                                   # fp32 output: generic epilogue, no fused statistics
+    cs = torch.zeros(M // 32, N, 2)
+    assert not sim.gemm_fuse_supported(a, w, out32, M=M, N=N, colstat=cs)
+    with pytest.raises(nt.NativeError):
+        sim.gemm(a, w, out32, M=M, N=N, colstat=cs)
+    out = torch.zeros(M, N, dtype=torch.bfloat16)
+    a4, w4 = _bf(_rt(M, 4 * K)), _bf(_rt(N, 4 * K))
+    assert sim.gemm_fuse_supported(a4, w4, out, M=M, N=N, colstat=cs)
+    assert not sim.gemm_fuse_supported(a4, w4, out, M=M, N=N, colstat=cs, split_k=2)   # split-K: the reduce kernel finishes, not the tile
