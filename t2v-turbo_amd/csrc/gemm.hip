@@ -104,7 +104,6 @@ struct Epi {
     const t2v_gemm_desc* d;
     long long o_off;
     int n_out, vec;
-    float ln_r = 1.f, ln_rmu = 0.f;  // LayerNorm folded into this GEMM (FUSE bit 4): rstd and rstd * mean of the row being finished
     // pre_res: the run's 16 residual values already in registers (issued for the whole wave tile before the first
     // store, so their latency is paid once instead of once per run behind the previous run's stores)
     // FAST: every run is a full, 16-byte aligned run (host-checked: vector-aligned operands, n_out % 16 == 0): the
@@ -118,34 +117,11 @@ struct Epi {
         store<FAST>(v, gm, ch_out);
     }
     // everything up to the final values of the run (v is updated in place)
-    template <bool FAST = false, bool LNF = false>
+    template <bool FAST = false>
     __device__ __forceinline__ void compute(float* v, float* gate, int gm, int ch_in, int ch_out, bool has_pre = false,
                                             uint4 pre0 = uint4{0, 0, 0, 0}, uint4 pre1 = uint4{0, 0, 0, 0}) const {
         const t2v_gemm_desc& dd = *d;
         const bool full = FAST || (vec && ch_out + 16 <= n_out);
-        if constexpr (LNF) {
-            // out = rstd * (acc - mean * s[n]) + t[n]: the consumer of a LayerNorm computed on the raw rows (W holds W diag(gamma),
-            // s its row sums, bias = t = b + W beta); value and gate columns of a GEGLU projection alike
-            static_assert(FAST, "the LayerNorm fold lives in the fast kernels (accumulators start at zero there)");
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 s4 = *(const float4*)(dd.lnf_s + ch_in + 4 * q), t4 = *(const float4*)(dd.bias + ch_in + 4 * q);
-                v[4 * q] = fmaf(ln_r, v[4 * q], fmaf(-ln_rmu, s4.x, t4.x));
-                v[4 * q + 1] = fmaf(ln_r, v[4 * q + 1], fmaf(-ln_rmu, s4.y, t4.y));
-                v[4 * q + 2] = fmaf(ln_r, v[4 * q + 2], fmaf(-ln_rmu, s4.z, t4.z));
-                v[4 * q + 3] = fmaf(ln_r, v[4 * q + 3], fmaf(-ln_rmu, s4.w, t4.w));
-            }
-            if (gate) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4 s4 = *(const float4*)(dd.lnf_s + ch_in + 32 + 4 * q), t4 = *(const float4*)(dd.bias + ch_in + 32 + 4 * q);
-                    gate[4 * q] = fmaf(ln_r, gate[4 * q], fmaf(-ln_rmu, s4.x, t4.x));
-                    gate[4 * q + 1] = fmaf(ln_r, gate[4 * q + 1], fmaf(-ln_rmu, s4.y, t4.y));
-                    gate[4 * q + 2] = fmaf(ln_r, gate[4 * q + 2], fmaf(-ln_rmu, s4.z, t4.z));
-                    gate[4 * q + 3] = fmaf(ln_r, gate[4 * q + 3], fmaf(-ln_rmu, s4.w, t4.w));
-                }
-            }
-        }
         // FAST kernels (alpha == 1, host-checked) start their accumulators at bias (+ rowvec + residual when there is no
         // gate), so those terms cost nothing here and the residual's latency hides under the main loop
         constexpr bool FOLD = FAST;
@@ -761,13 +737,43 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
         char* st = smem + wave * (32 * P);
         char* st_w = st + frow * P + hi * 32;
         bf16_t* obase = (bf16_t*)d.out + o_off;
+        // LayerNorm fold: out = rstd * (acc - mean * s[n]) + t[n] (W holds W diag(gamma), s its row sums, bias = t = b + W beta;
+        // value and gate columns of a GEGLU projection alike).  s / t of a 32-column block depend on the column only: wave tiles
+        // with several row slabs load them ONCE (the loads of slab i+1 cannot move above the stores of slab i: possible alias).
+        constexpr bool LN_HOIST = F_LNF && TM > 1;
+        float4 lns[LN_HOIST ? TN : 1][4], lnt[LN_HOIST ? TN : 1][4];
+        if constexpr (LN_HOIST) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = min(ch_lane + j * 32 + 4 * q, d.N - 4);
+                    lns[j][q] = *(const float4*)(d.lnf_s + ch);
+                    lnt[j][q] = *(const float4*)(d.bias + ch);
+                }
+        }
+        auto ln_fold = [&](float* v, int j, float r, float rmu) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 s4, t4;
+                if constexpr (LN_HOIST) { s4 = lns[j][q]; t4 = lnt[j][q]; }
+                else {
+                    const int ch = min(ch_lane + j * 32 + 4 * q, d.N - 4);
+                    s4 = *(const float4*)(d.lnf_s + ch);
+                    t4 = *(const float4*)(d.bias + ch);
+                }
+                v[4 * q] = fmaf(r, v[4 * q], fmaf(-rmu, s4.x, t4.x));
+                v[4 * q + 1] = fmaf(r, v[4 * q + 1], fmaf(-rmu, s4.y, t4.y));
+                v[4 * q + 2] = fmaf(r, v[4 * q + 2], fmaf(-rmu, s4.z, t4.z));
+                v[4 * q + 3] = fmaf(r, v[4 * q + 3], fmaf(-rmu, s4.w, t4.w));
+            }
+        };
         if (d.act == T2V_ACT_GEGLU) {
             epi.n_out = d.N / 2;
             if constexpr (TN >= 2 && TN % 2 == 0) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int gm = m0 + wave_m * WTM + i * 32 + frow;
-                    if constexpr (F_LNF) { epi.ln_r = lnr[i]; epi.ln_rmu = lnrm[i]; }
                     asm volatile("" ::: "memory");
 #pragma unroll
                     for (int u = 0; u < TN / 2; ++u) {
@@ -775,7 +781,8 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 #pragma unroll
                         for (int e = 0; e < 16; ++e) { v[e] = acc[i][2 * u][e]; gt[e] = acc[i][2 * u + 1][e]; }
                         const int ch_out = (n0 + wave_n * WTN) / 2 + u * 32 + 16 * hi;
-                        if (gm < d.M && ch_out < epi.n_out) epi.template compute<true, F_LNF>(v, gt, gm, ch_lane + u * 64, ch_out);
+                        if constexpr (F_LNF) { ln_fold(v, 2 * u, lnr[i], lnrm[i]); ln_fold(gt, 2 * u + 1, lnr[i], lnrm[i]); }
+                        if (gm < d.M && ch_out < epi.n_out) epi.template compute<true>(v, gt, gm, ch_lane + u * 64, ch_out);
                         *(uint4*)(st_w + u * 64) = pack8(v);
                         *(uint4*)(st_w + u * 64 + 16) = pack8(v + 8);
                     }
@@ -850,27 +857,42 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int gm = m0 + wave_m * WTM + i * 32 + frow;
-            if constexpr (F_LNF) { epi.ln_r = lnr[i]; epi.ln_rmu = lnrm[i]; }
             asm volatile("" ::: "memory");
+            float rs1[F_ROW ? TN : 1], rs2[F_ROW ? TN : 1];
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float v[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
-                if (gm < d.M && ch_lane + j * 32 < d.N) epi.template compute<true, F_LNF>(v, nullptr, gm, ch_lane + j * 32, ch_lane + j * 32);
+                if constexpr (F_LNF) ln_fold(v, j, lnr[i], lnrm[i]);
+                if (gm < d.M && ch_lane + j * 32 < d.N) epi.template compute<true>(v, nullptr, gm, ch_lane + j * 32, ch_lane + j * 32);
                 if constexpr (F_ROW) {
                     // (sum, sum of squares) of this row over the 32-column block j of the wave tile: the lane's 16 fp32 epilogue
                     // values plus its partner's (lane ^ 32 holds the block's other 16 channels), in a fixed order
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
-                    s1 += __shfl_xor(s1, 32, 64);
-                    s2 += __shfl_xor(s2, 32, 64);
-                    if (hi == 0 && gm < d.M && ch_lane + j * 32 < d.N)
-                        *(float2*)(d.rowstat_out + (long long)gm * d.ld_rowstat + 2 * (((n0 + wave_n * WTN) >> 5) + j)) = make_float2(s1, s2);
+                    rs1[j] = s1 + __shfl_xor(s1, 32, 64);
+                    rs2[j] = s2 + __shfl_xor(s2, 32, 64);
                 }
                 *(uint4*)(st_w + j * 64) = pack8(v);
                 *(uint4*)(st_w + j * 64 + 16) = pack8(v + 8);
+            }
+            if constexpr (F_ROW) {  // one store per PAIR of blocks where the wave tile starts on an even block (16-byte aligned)
+                float* rp = d.rowstat_out + (long long)gm * d.ld_rowstat + 2 * ((n0 + wave_n * WTN) >> 5);
+                if (hi == 0 && gm < d.M) {
+                    if constexpr (TN % 2 == 0 && WTN % 64 == 0) {
+#pragma unroll
+                        for (int j = 0; j < TN; j += 2) {
+                            if (ch_lane + j * 32 + 32 < d.N) *(float4*)(rp + 2 * j) = make_float4(rs1[j], rs2[j], rs1[j + 1], rs2[j + 1]);
+                            else if (ch_lane + j * 32 < d.N) *(float2*)(rp + 2 * j) = make_float2(rs1[j], rs2[j]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            if (ch_lane + j * 32 < d.N) *(float2*)(rp + 2 * j) = make_float2(rs1[j], rs2[j]);
+                    }
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if constexpr (F_COL) {
@@ -1074,7 +1096,7 @@ int t2v_gemm_launch_ln(int cfg, GemmParams& p, hipStream_t s);  // the 160x320 t
 // kernels' code must not depend on them.  t2v_gemm_fuse_tile maps a tile id to the id whose fused variants exist (same workgroup
 // tile where possible), 0 if none.
 int t2v_gemm_launch_fused(int cfg, int fuse, GemmParams& p, hipStream_t s);
-int t2v_gemm_fuse_tile(int cfg, int act);
+int t2v_gemm_fuse_tile(int cfg, int act, int fuse);
 #ifdef T2V_GEMM_FUSE_ONLY
 namespace {
 template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE>
@@ -1088,7 +1110,8 @@ int launch_fused(int fuse, GemmParams& p, hipStream_t s) {
 }
 }  // namespace
 // tiles with fused variants: one per workgroup-tile shape the tuned table uses for the UNet's norm producers / consumers
-int t2v_gemm_fuse_tile(int cfg, int act) {
+int t2v_gemm_fuse_tile(int cfg, int act, int fuse) {
+    if (fuse == 4 && cfg == 19) cfg = 7;  // the 4-waves-per-SIMD 256x128 tile has no registers to spare for the fold: its 2-per-SIMD twin
     switch (cfg) {
         case 1: case 4: case 10: case 18: case 26: case 30: case 33: return 4;     // 128x128
         case 31: case 32: return act == T2V_ACT_GEGLU ? 4 : 31;                   // 128x128, eight waves (32-wide wave tiles: no GEGLU)
@@ -1324,7 +1347,7 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
                             (uintptr_t)d.lnf_s % 16 == 0 && !d.residual && !d.rowvec && !d.drop_thr && d.act != T2V_ACT_SILU,
                         T2V_ESHAPE, "t2v_gemm: lnf_stats: LINEAR over C = 32 lnf_nblk <= 1280 channels, lnf_s and bias given, no residual / "
                                     "row vector / dropout");
-        fuse_cfg = t2v_gemm_fuse_tile(cfg, d.act);
+        fuse_cfg = t2v_gemm_fuse_tile(cfg, d.act, fuse);
         // the fused epilogue rides on the fast kernels of one K split; GEGLU needs a 64-wide wave tile (its value / gate pairs)
         fuse_ok = fuse_cfg != 0 && p.splits == 1 && gemm_is_fast(p) && !(d.act == T2V_ACT_GEGLU && kCfg[fuse_cfg].wtn < 64);
         if (fuse_ok) { p.nk = p.K / kCfg[fuse_cfg].bk; p.nk_per_split = p.nk; }

@@ -3,8 +3,9 @@ UNet uses (implicit-GEMM 3x3 convs with folded nearest-x2 upsampling, two-phase 
 the mid AttnBlock as two batched GEMMs + a row softmax).  Replaces the per-frame Python loop of
 ``LatentDiffusion.decode_first_stage_2DAE`` (reference lvdm/models/ddpm3d.py:666-679) ->
 ``AutoencoderKL.decode`` (autoencoder.py:110-113) -> ``Decoder.forward`` (ae_modules.py:602-641)."""
-import torch
+import os
 
+import torch
 
 from . import native as nt
 from .native import on_tensor_device
@@ -16,6 +17,10 @@ class VAEDecodeEngine(_Engine):
     def __init__(self, vae, ops):
         super().__init__(ops)
         self.vae = vae
+        # GroupNorm statistics from the producing convs' epilogues (engine._Engine.gn): the decoder's 128-channel norms at
+        # 320x512 are pure bandwidth.  The gradient engine (a subclass) keeps the standalone statistics it saves for its backward.
+        if type(self).__name__ in ("VAEDecodeEngine", "VAEEncodeEngine"):
+            self.fuse_gn = os.environ.get("T2V_FUSE_GN", "1") == "1"
 
     @on_tensor_device
     def decode_frames(self, z, scale):
@@ -150,9 +155,10 @@ class VAEDecodeEngine(_Engine):
         o = self.buf(n_img * seq, c)
         ops.gemm(s, vt, o, M=seq, N=c, batch=n_img, a_strides=(seq * kp, 0), w_strides=(c * kp, 0),
                  o_strides=(seq * c, 0), bias=pk.bias(ab.v))
-        out = self.linear(o, ab.proj_out, residual=x.t)
+        out = self.linear(o, ab.proj_out, residual=x.t, want_cs=True)
+        cs = self.last_cs
         self.pool.put(t, q, k, vt, s, o, x.t)
-        return Act(out, n_img, x.h, x.w)
+        return Act(out, n_img, x.h, x.w, cs=[cs])
 
 
 class VAEEncodeEngine(VAEDecodeEngine):

@@ -249,19 +249,27 @@ def test_unet_full_width_c2_config_vs_oracle():
     err = rel_l2(ys[0], ref)
     print(f"full-width C2 parity: rel-L2 {err:.3e}")
     assert err < E2E_TOL, err
-    # the opt-in LayerNorm-in-the-GEMM-epilogue form (engine.fuse_ln, 30 launches fewer at these widths): same network
-    n_plain = len(next(iter(eng.plans.values()))["rec"])
-    eng.fuse_ln = True
-    eng.plans.clear()
-    try:
-        with torch.no_grad():
-            y_f = model(x, ts, context=ctx, fps=16, timestep_cond=tc).float().cpu()
-        n_fused = len(next(iter(eng.plans.values()))["rec"])
-    finally:
-        eng.fuse_ln = False
+    # the default dataflow takes GroupNorm statistics from the producing GEMMs and folds 83 of the 99 LayerNorms into their consumers;
+    # switched off (T2V_FUSE_GN=0 / T2V_FOLD_LN=0 in the environment, or the engine attributes) it is the round-2 network: same
+    # numbers within two bf16 roundings; and the opt-in LayerNorm-as-second-output form on top of that (30 launches fewer)
+    n_default = len(next(iter(eng.plans.values()))["rec"])
+    outs = {}
+    for tag, flags in (("plain", dict(fuse_gn=False, fold_ln=False, fuse_ln=False)), ("ln_second_output", dict(fuse_gn=False, fold_ln=False, fuse_ln=True))):
+        for k, v in flags.items():
+            setattr(eng, k, v)
         eng.plans.clear()
-    assert n_fused == n_plain - 30
-    assert rel_l2(y_f, ref) < E2E_TOL and rel_l2(y_f, ys[0]) < E2E_TOL   # two bf16 roundings of one network: each ~1.7e-2 from fp32
+        try:
+            with torch.no_grad():
+                outs[tag] = (model(x, ts, context=ctx, fps=16, timestep_cond=tc).float().cpu(), len(next(iter(eng.plans.values()))["rec"]))
+        finally:
+            eng.fuse_gn = eng.fold_ln = True
+            eng.fuse_ln = False
+            eng.plans.clear()
+    n_plain = outs["plain"][1]
+    print(f"launches per step: default {n_default}, plain {n_plain}, LayerNorm as second output {outs['ln_second_output'][1]}")
+    assert n_default < n_plain and outs["ln_second_output"][1] == n_plain - 30
+    for tag, (y_v, _) in outs.items():
+        assert rel_l2(y_v, ref) < E2E_TOL and rel_l2(y_v, ys[0]) < E2E_TOL, tag   # bf16 roundings of one network: each ~1.7e-2 from fp32
 
 
 def test_unet_full_width_motion_cond_config_c4_vs_oracle():

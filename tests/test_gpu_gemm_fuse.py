@@ -60,8 +60,9 @@ def test_column_statistics(hip, cfg):
     cs_h = torch.full((M // 32, N, 2), float("nan"), device="cuda")
     out_e, cs_e = torch.zeros(M, N), torch.zeros(M // 32, N, 2)
     kw = dict(M=M, N=N, mode=nt.GEMM_CONV3X3, n_img=n, h=h, wd=w, rowvec_div=h * w)
-    assert hip.gemm_fuse_supported(_d(x), _d(wt), out_h, bias=_d(b, torch.float32), rowvec=_d(rv, torch.float32), colstat=cs_h, tile_cfg=cfg, **kw)
-    hip.gemm(_d(x), _d(wt), out_h, bias=_d(b, torch.float32), rowvec=_d(rv, torch.float32), colstat=cs_h, tile_cfg=cfg, **kw)
+    hk = dict(kw, tile_cfg=cfg, split_k=1)   # (a 24-tile launch with K = 1152: the heuristic would split K, and a split launch carries no statistics)
+    assert hip.gemm_fuse_supported(_d(x), _d(wt), out_h, bias=_d(b, torch.float32), rowvec=_d(rv, torch.float32), colstat=cs_h, **hk)
+    hip.gemm(_d(x), _d(wt), out_h, bias=_d(b, torch.float32), rowvec=_d(rv, torch.float32), colstat=cs_h, **hk)
     EMU.gemm(x, wt, out_e, bias=b, rowvec=rv, colstat=cs_e, **kw)
     torch.cuda.synchronize()
     assert rel_l2(out_h.float().cpu(), out_e) < BF16_TOL
