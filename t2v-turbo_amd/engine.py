@@ -318,6 +318,12 @@ class _Engine:
     # to the standalone statistics passes / LayerNorm launches.
     fuse_gn = False
     fold_ln = False
+    # Measured on MI355X (profiles/r03_fuse_ab.csv): the fold pays where the consuming GEMM is as wide as the rows it normalises
+    # (the text cross-attention's q: +1.2 / +1.9 / +2.6 us on the launch and +2.3 / +0.7 / +0.4 us on the producer against a
+    # 13.8 / 8.7 / 8.3 us LayerNorm at the three levels) and LOSES on the wide consumers — q|k|v (+17 us at the 320-channel
+    # level) and the GEGLU projection (+50 us): every N-tile of the consumer re-loads its rows' statistics and re-scales in its
+    # epilogue, the serial tail of a workgroup.  T2V_FOLD_LN_WIDE=1 folds those too (for the record, not for speed).
+    fold_ln_wide = os.environ.get("T2V_FOLD_LN_WIDE", "0") == "1"
 
     def _colstat_for(self, a0, w, out, **kw):
         """A column-statistics buffer for this launch's output if the launch can carry it (linked to ``out`` in the pool)."""
@@ -718,6 +724,8 @@ class UNetEngine(_Engine):
             return (fold and stats is not None and tuple(norm.normalized_shape) == (C,) and norm.elementwise_affine and
                     C % 64 == 0 and C <= 1280)
 
+        wide = fold and self.fold_ln_wide   # q|k|v and the GEGLU projection (see fold_ln_wide)
+
         def folded(src, norm, stats, pack, act=nt.ACT_NONE):
             """The GEMM that consumes LayerNorm(src), run on the raw rows with the LayerNorm folded in — or None where the fold
             does not apply or the launch cannot carry it (the caller then normalises first)."""
@@ -728,7 +736,7 @@ class UNetEngine(_Engine):
 
         def temporal_attn(attn, norm, src, stats):
             # q | k | v of LayerNorm(src) as ONE GEMM
-            qkv = folded(src, norm, stats, lambda: pk.mat_lnf([attn.to_q, attn.to_k, attn.to_v], norm, "qkv_lnf"))
+            qkv = folded(src, norm, stats if wide else None, lambda: pk.mat_lnf([attn.to_q, attn.to_k, attn.to_v], norm, "qkv_lnf"))
             if qkv is None:
                 qkv = self.linear(lnorm(norm, src) if src is not box["ln"] else src, None,
                                   w=pk.cat_mats([attn.to_q, attn.to_k, attn.to_v], "qkv"), bias=None)
@@ -772,19 +780,20 @@ class UNetEngine(_Engine):
             o = temporal_attn(a1, blk.norm1, ln1 if ln1 is not None else y, rs)
         else:  # two consumers (q|k and V^T, the latter with the tokens as its column operand): the LayerNorm stays a launch
             o = spatial_self_attn(a1, ln1 if ln1 is not None else lnorm(blk.norm1, y))
-        y1 = self.linear(o, a1.to_out[0], residual=y, ln=(blk.norm2, ln_buf()) if fuse2 else None, want_rs=fold)
+        # row statistics only where the next LayerNorm will be folded: the spatial block's norm2 (-> cross-attention q)
+        y1 = self.linear(o, a1.to_out[0], residual=y, ln=(blk.norm2, ln_buf()) if fuse2 else None, want_rs=fold and (wide or not temporal))
         rs1 = self.last_rs
         self.pool.put(o)
         # attn2: temporal self attention again, or text cross attention
         src = box["ln"] if fuse2 else y1
         o = temporal_attn(a2, blk.norm2, src, rs1) if temporal else cross_attn(a2, blk.norm2, src, rs1)
-        y2 = self.linear(o, a2.to_out[0], residual=y1, ln=(blk.norm3, ln_buf()) if fuse3 else None, want_rs=fold)
+        y2 = self.linear(o, a2.to_out[0], residual=y1, ln=(blk.norm3, ln_buf()) if fuse3 else None, want_rs=wide)
         rs2 = self.last_rs
         self.pool.put(o, y1)
         # GEGLU feed-forward
         proj = blk.ff.net[0]
         assert hasattr(proj, "proj"), "non-gated FeedForward is not built by the VideoCrafter2 config"
-        g = folded(y2, blk.norm3, rs2, lambda: pk.geglu_lnf(proj.proj, blk.norm3), act=nt.ACT_GEGLU)
+        g = folded(y2, blk.norm3, rs2 if wide else None, lambda: pk.geglu_lnf(proj.proj, blk.norm3), act=nt.ACT_GEGLU)
         if g is None:
             src = box["ln"] if fuse3 else lnorm(blk.norm3, y2)
             wg, bg = pk.geglu(proj.proj)
@@ -799,7 +808,7 @@ class UNetEngine(_Engine):
         blk0 = blocks[0] if len(blocks) else None
         C = leaf_out_channels(proj_in)
         if self.fold_ln:
-            y = self.linear(t, proj_in, want_rs=temporal and blk0 is not None)
+            y = self.linear(t, proj_in, want_rs=temporal and blk0 is not None and self.fold_ln_wide)
             return y, None, self.last_rs
         is_linear = isinstance(proj_in, nn.Linear) or isinstance(getattr(proj_in, "linear", None), nn.Linear)  # (or LoRA-injected)
         if blk0 is not None and is_linear and self.ln_fusable(C, blk0.norm1):

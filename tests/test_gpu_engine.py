@@ -249,7 +249,7 @@ def test_unet_full_width_c2_config_vs_oracle():
     err = rel_l2(ys[0], ref)
     print(f"full-width C2 parity: rel-L2 {err:.3e}")
     assert err < E2E_TOL, err
-    # the default dataflow takes GroupNorm statistics from the producing GEMMs and folds 83 of the 99 LayerNorms into their consumers;
+    # the default dataflow takes GroupNorm statistics from the producing GEMMs and folds the 16 text cross-attention LayerNorms into their q GEMMs;
     # switched off (T2V_FUSE_GN=0 / T2V_FOLD_LN=0 in the environment, or the engine attributes) it is the round-2 network: same
     # numbers within two bf16 roundings; and the opt-in LayerNorm-as-second-output form on top of that (30 launches fewer)
     n_default = len(next(iter(eng.plans.values()))["rec"])

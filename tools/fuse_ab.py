@@ -17,6 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+FORCE_TILES = [int(v) for v in os.environ.get("T2V_AB_TILES", "").split(",") if v]
+
+
 def main():
     from t2v_turbo_amd import native as nt
     from t2v_turbo_amd.native import HipOps
@@ -61,6 +64,12 @@ def main():
             kw = dict(M=M, N=N, bias=b, act=act, lnf=(rs, 1e-5, s_vec))
             ok = ops.gemm_fuse_supported(y, w, out, **kw)
             print(f"{lvl},{name},ln_fold{'' if ok else '(unsupported)'},{timeit(lambda: ops.gemm(y, w, out, **kw)) if ok else float('nan'):.2f}")
+            for cfg in FORCE_TILES:   # the fold on other tiles than the tuned one (the tuning was done for the plain launch)
+                if act == nt.ACT_GEGLU and cfg in (5, 9, 23, 31):
+                    continue
+                kw2 = dict(kw, tile_cfg=cfg, split_k=1)
+                if ops.gemm_fuse_supported(y, w, out, **kw2):
+                    print(f"{lvl},{name},ln_fold@tile{cfg},{timeit(lambda: ops.gemm(y, w, out, **kw2)):.2f}")
         # GroupNorm producers / consumers
         n_img, h, wd = 16, {2560: 40, 640: 20, 160: 10}[hw], {2560: 64, 640: 32, 160: 16}[hw]
         w3, w1 = rnd(C, 9 * C, scale=(9 * C) ** -0.5), rnd(C, 3 * C, scale=(3 * C) ** -0.5)
