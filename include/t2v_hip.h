@@ -147,6 +147,21 @@ int t2v_gemm_force_config(int cfg);
 int t2v_gemm_force_split(int splits);
 int t2v_gemm_num_configs(void);
 
+/* The GEGLU feed-forward of a BasicTransformerBlock, LayerNorm and residual included, in ONE launch:
+ *     out = x + W2 . [value . gelu(gate)] + b2,   [value | gate] = W1 . LayerNorm(x) + b1
+ * (lvdm/modules/attention.py:300-311 `x = self.ff(self.norm3(x)) + x`, :516-542 FeedForward / GEGLU).  The 4C-wide hidden
+ * activation never reaches memory.  x, out: bf16 [M][ld] (not in place); C = 320 (and 64 for tests): t2v_ffn_fused_supported.
+ * The weights come PRE-PACKED in MFMA fragment order, LayerNorm's affine folded into W1 / b1 (W1 diag(gamma), b1 + W1 beta):
+ *   w1p bf16 [C/8 chunks][4 row tiles: value a | gate a | value b | gate b][C/32 k-steps][64 lanes][8]:
+ *       lane l = W1'[row][32 s + 8 (l >> 4) .. +8], row = (gate ? 4C : 0) + 32 chunk + 16 (b ? 1 : 0) + (l & 15)
+ *   b1p fp32 [C/8][4][16] in the same row order
+ *   w2p bf16 [C/8 chunks][C/16 row tiles][64 lanes][8]: lane l = W2[16 t + (l & 15)][32 chunk + h], h = 4 (l >> 4) + e for
+ *       e < 4 (pair a), 16 + 4 (l >> 4) + e - 4 for e >= 4 (pair b)
+ *   b2 fp32 [C] */
+int t2v_ffn_fused_supported(int C);
+int t2v_ffn_fused(const void* x, int ldx, int M, int C, const void* w1p, const float* b1p, const void* w2p, const float* b2,
+                  float ln_eps, void* out, int ldo, void* stream);
+
 /* direct 3x3 s1 p1 conv for tiny Cin (the 4-channel latent): x bf16 [M][cin] (cin <= 8),
  * w fp32 [cout][9][cin], bias fp32 [cout], out bf16 [M][cout].
  * Replaces input_blocks.0 (openaimodel3d.py:435) and Decoder.conv_in (ae_modules.py:550-552). */

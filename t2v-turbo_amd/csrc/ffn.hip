@@ -167,7 +167,8 @@ void ffn_fused_kernel(const bf16_t* __restrict__ x, int ldx, int M, const bf16_t
         bf16x4s_t Pa[FFN_CT], Pb[FFN_CT];
         constexpr int GS = (2 * KS) / FFN_CT > 0 ? (2 * KS) / FFN_CT : 1;   // pieces of pair b per GEGLU column tile of pair a
         constexpr int G2 = RT / FFN_CT > 0 ? RT / FFN_CT : 1;               // row tiles of GEMM2 half a per GEGLU column tile of pair b
-        static_assert(GS * (FFN_CT - 1) + 1 < 2 * KS && G2 * (FFN_CT - 1) + 1 < RT, "every GEGLU tile must have a slot");
+        constexpr int GO = GS > 1 ? 1 : 0, G2O = G2 > 1 ? 1 : 0;           // slot offset inside a group (after the group's first piece)
+        static_assert(GS * (FFN_CT - 1) + GO < 2 * KS && G2 * (FFN_CT - 1) + G2O < RT, "every GEGLU tile must have a slot");
         auto geglu_tile = [&](int pair, int c, bf16x4s_t* P) {   // value * gelu(gate) of one pair and column tile, packed: a 16-deep B fragment
             const float* bl = (const float*)(smem + buf * G::BUF + G::BIAS_OFF) + 4 * kg;   // rows 4 kg .. +3 of [value a | gate a | value b | gate b]
             const float4 bv = *(const float4*)(bl + 32 * pair), bg = *(const float4*)(bl + 32 * pair + 16);
@@ -187,7 +188,7 @@ void ffn_fused_kernel(const bf16_t* __restrict__ x, int ldx, int M, const bf16_t
             const int T = n / KS, sk = n % KS;
 #pragma unroll
             for (int c = 0; c < FFN_CT; ++c) S[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[n % 3], X[c][sk], S[T][c], 0, 0, 0);
-            if (n >= 2 * KS && (n - 2 * KS) % GS == 1 && (n - 2 * KS) / GS < FFN_CT) geglu_tile(0, (n - 2 * KS) / GS, Pa);
+            if (n >= 2 * KS && (n - 2 * KS) % GS == GO && (n - 2 * KS) / GS < FFN_CT) geglu_tile(0, (n - 2 * KS) / GS, Pa);
             __builtin_amdgcn_sched_barrier(0);
         }
         // GEMM2 as two 16-deep halves over all row tiles: a W2 piece holds [4 k of pair a | 4 k of pair b] per lane, each pass
@@ -201,7 +202,7 @@ void ffn_fused_kernel(const bf16_t* __restrict__ x, int ldx, int M, const bf16_t
             if (t + 2 < RT) r2[(t + 2) % 3] = *(const bf16x4s_t*)(w2b + (t + 2) * 1024);
 #pragma unroll
             for (int c = 0; c < FFN_CT; ++c) O[t][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(r2[t % 3], Pa[c], O[t][c], 0, 0, 0);
-            if (t % G2 == 1 && t / G2 < FFN_CT) geglu_tile(1, t / G2, Pb);
+            if (t % G2 == G2O && t / G2 < FFN_CT) geglu_tile(1, t / G2, Pb);
             __builtin_amdgcn_sched_barrier(0);
         }
         r2[0] = *(const bf16x4s_t*)(w2b + 8);

@@ -233,6 +233,17 @@ class Packer:
             return pack(wp).contiguous(), pack(s_vec[:, None]).reshape(-1).contiguous(), pack(t_vec[:, None]).reshape(-1).contiguous()
         return self._memo(("geglu_lnf", id(proj), id(norm)), make)
 
+    def ffn(self, ff, norm):
+        """Packed operands of t2v_ffn_fused for FeedForward ``ff`` (GEGLU projection + output Linear) behind LayerNorm ``norm``."""
+        def make():
+            proj, lin = ff.net[0].proj, ff.net[2]
+            (w1, b1), (w2, b2) = self.wb(proj), self.wb(lin)
+            dev = self.device
+            return nt.ffn_pack(w1.detach().to(dev), None if b1 is None else b1.detach().to(dev), w2.detach().to(dev),
+                               None if b2 is None else b2.detach().to(dev), norm.weight.detach().to(dev), norm.bias.detach().to(dev),
+                               self.wdtype)
+        return self._memo(("ffn", id(ff), id(norm)), make)
+
     def small_conv(self, mod, cin_pad=None):
         """fp32 [cout][9][cin] for the direct small-Cin conv."""
         def make():
@@ -324,6 +335,9 @@ class _Engine:
     # level) and the GEGLU projection (+50 us): every N-tile of the consumer re-loads its rows' statistics and re-scales in its
     # epilogue, the serial tail of a workgroup.  T2V_FOLD_LN_WIDE=1 folds those too (for the record, not for speed).
     fold_ln_wide = os.environ.get("T2V_FOLD_LN_WIDE", "0") == "1"
+    # BasicTransformerBlock's feed-forward (LayerNorm, GEGLU projection, output projection, residual) as ONE launch where the
+    # kernel exists (csrc/ffn.hip: C = 320, the level whose 105 MB hidden activation costs the most)
+    fuse_ff = False
 
     def _colstat_for(self, a0, w, out, **kw):
         """A column-statistics buffer for this launch's output if the launch can carry it (linked to ``out`` in the pool)."""
@@ -448,6 +462,7 @@ class UNetEngine(_Engine):
         if type(self) is UNetEngine:
             self.fuse_gn = os.environ.get("T2V_FUSE_GN", "1") == "1"
             self.fold_ln = os.environ.get("T2V_FOLD_LN", "1") == "1"
+            self.fuse_ff = os.environ.get("T2V_FUSE_FF", "1") == "1"
 
     @on_tensor_device
     def __call__(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None):
@@ -793,6 +808,15 @@ class UNetEngine(_Engine):
         # GEGLU feed-forward
         proj = blk.ff.net[0]
         assert hasattr(proj, "proj"), "non-gated FeedForward is not built by the VideoCrafter2 config"
+        if (self.fuse_ff and ops.ffn_fused_supported(C) and tuple(blk.norm3.normalized_shape) == (C,) and blk.norm3.elementwise_affine
+                and not fuse3 and leaf_out_channels(blk.ff.net[2]) == C and leaf_out_channels(proj.proj) == 8 * C):
+            # LayerNorm -> GEGLU projection -> output projection -> + residual as ONE launch (csrc/ffn.hip): the 4C-wide hidden
+            # activation stays in registers
+            w1p, b1p, w2p, b2f = pk.ffn(blk.ff, blk.norm3)
+            y3 = self.buf(M, C)
+            ops.ffn_fused(y2, w1p, b1p, w2p, b2f, blk.norm3.eps, y3)
+            self.pool.put(y2, box["ln"])
+            return y3
         g = folded(y2, blk.norm3, rs2 if wide else None, lambda: pk.geglu_lnf(proj.proj, blk.norm3), act=nt.ACT_GEGLU)
         if g is None:
             src = box["ln"] if fuse3 else lnorm(blk.norm3, y2)

@@ -58,6 +58,9 @@ _SIGS = {
     "t2v_gemm_force_config": (C.c_int, [C.c_int]),
     "t2v_gemm_force_split": (C.c_int, [C.c_int]),
     "t2v_gemm_num_configs": (C.c_int, []),
+    "t2v_ffn_fused_supported": (C.c_int, [C.c_int]),
+    "t2v_ffn_fused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                C.c_void_p, C.c_int, C.c_void_p]),
     "t2v_conv3x3_small_cin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_void_p, C.c_void_p]),
     "t2v_gn_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
@@ -170,6 +173,34 @@ def _p(t):
 def _row_stride(t):
     assert t.dim() == 2 and (t.shape[1] == 1 or t.stride(1) == 1), "expected a row-major 2-D view"
     return t.stride(0)
+
+
+def ffn_pack(w1, b1, w2, b2, gamma, beta, wdtype):
+    """Weights of ``t2v_ffn_fused`` (include/t2v_hip.h): the GEGLU projection [8C, C] / [8C] (value rows, then gate rows), the
+    output projection [C, 4C] / [C] and the affine of the LayerNorm in front of them -> (w1p, b1p, w2p, b2) in MFMA fragment
+    order, the affine folded into the first projection."""
+    C, inner = w2.shape[0], w2.shape[1]
+    assert w1.shape == (2 * inner, C) and inner % 32 == 0 and C % 32 == 0
+    dev = w1.device
+    w1f = w1.float() * gamma.float()[None, :]
+    b1f = (b1.float() if b1 is not None else torch.zeros(2 * inner, device=dev)) + w1.float() @ beta.float()
+    nch, ks, rt = inner // 32, C // 32, C // 16
+    lane = torch.arange(64, device=dev)
+    col, kg = lane & 15, lane >> 4
+    j = torch.arange(nch, device=dev)[:, None, None]
+    tile = torch.arange(4, device=dev)[None, :, None]
+    row0 = (tile % 2) * inner + 32 * j + 16 * (tile // 2)                      # [nch, 4, 1]: first row of a tile
+    rows = row0 + col[None, None, :]                                           # [nch, 4, 64]
+    e = torch.arange(8, device=dev)
+    cols = 32 * torch.arange(ks, device=dev)[:, None, None] + 8 * kg[None, :, None] + e[None, None, :]   # [ks, 64, 8]
+    w1p = w1f[rows[:, :, None, :, None], cols[None, None, :, :, :]].to(wdtype).contiguous()            # [nch, 4, ks, 64, 8]
+    b1p = b1f[row0 + torch.arange(16, device=dev)[None, None, :]].float().contiguous()                   # [nch, 4, 16]
+    orow = 16 * torch.arange(rt, device=dev)[:, None] + col[None, :]                                     # [rt, 64]
+    h = torch.where(e[None, :] < 4, 4 * kg[:, None] + e[None, :], 16 + 4 * kg[:, None] + e[None, :] - 4)  # [64, 8]
+    hid = 32 * torch.arange(nch, device=dev)[:, None, None] + h[None, :, :]                               # [nch, 64, 8]
+    w2p = w2.float()[orow[None, :, :, None], hid[:, None, :, :]].to(wdtype).contiguous()                  # [nch, rt, 64, 8]
+    b2f = (b2.float() if b2 is not None else torch.zeros(C, device=dev)).contiguous()
+    return w1p, b1p, w2p, b2f
 
 
 def on_tensor_device(fn):
@@ -318,6 +349,14 @@ class HipOps:
         ws = self.workspace(a0.device)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         return d
+
+    def ffn_fused_supported(self, C_):
+        return bool(self.lib.t2v_ffn_fused_supported(int(C_)))
+
+    def ffn_fused(self, x, w1p, b1p, w2p, b2, eps, out):
+        """out = x + FF(LayerNorm(x)) (GEGLU feed-forward) in one launch; packed weights: ``ffn_pack`` (include/t2v_hip.h)."""
+        self._call("t2v_ffn_fused", _p(x), _row_stride(x), x.shape[0], x.shape[1], _p(w1p), _p(b1p), _p(w2p), _p(b2), float(eps),
+                   _p(out), _row_stride(out))
 
     def conv_small(self, x, n_img, h, w, wgt, bias, out):
         self._call("t2v_conv3x3_small_cin", _p(x), n_img, h, w, x.shape[1], _p(wgt), _p(bias), out.shape[1], _p(out))

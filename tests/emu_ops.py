@@ -149,6 +149,40 @@ class EmuOps:
         return (mode == nt.GEMM_LINEAR and a1 is None and bias is not None and residual is None and rowvec is None and cin % 64 == 0
                 and cin <= 1280 and act != nt.ACT_SILU and lnf[0].stride(0) >= cin // 16 and lnf[0].stride(0) % 4 == 0)
 
+    def ffn_fused_supported(self, C):
+        return C % 32 == 0   # (the device kernel: C = 320 and 64; the emulation takes any width the layout allows)
+
+    def ffn_fused(self, x, w1p, b1p, w2p, b2, eps, out):
+        """out = x + W2 (value * gelu(gate)) + b2 with [value | gate] = W1' LayerNorm_noaffine(x) + b1' — decoded from the PACKED
+        operands by the layout rules of include/t2v_hip.h (an independent restatement of native.ffn_pack's index maps)."""
+        self._log("ffn_fused")
+        M, C = x.shape
+        nch, four, ks, _, _ = w1p.shape
+        inner, rt = 32 * nch, C // 16
+        assert four == 4 and ks == C // 32 and w2p.shape == (nch, rt, 64, 8) and b1p.shape == (nch, 4, 16)
+        w1 = torch.zeros(2 * inner, C)
+        b1 = torch.zeros(2 * inner)
+        w2 = torch.zeros(C, inner)
+        lanes = torch.arange(64)
+        for jc in range(nch):    # piece by piece, by the layout rules of the header (vectorised over the 64 lanes of a piece)
+            for T in range(4):
+                r0 = (T % 2) * inner + 32 * jc + 16 * (T // 2)
+                b1[r0:r0 + 16] = b1p[jc, T].float()
+                rows = r0 + (lanes & 15)
+                for s_ in range(ks):
+                    cols = 32 * s_ + 8 * (lanes >> 4)
+                    w1[rows[:, None], cols[:, None] + torch.arange(8)[None, :]] = w1p[jc, T, s_].float()
+            for t in range(rt):
+                orow = 16 * t + (lanes & 15)
+                ha = 32 * jc + 4 * (lanes >> 4)
+                w2[orow[:, None], ha[:, None] + torch.arange(4)[None, :]] = w2p[jc, t, :, :4].float()
+                w2[orow[:, None], 16 + ha[:, None] + torch.arange(4)[None, :]] = w2p[jc, t, :, 4:].float()
+        xf = x.float()
+        xn = F.layer_norm(xf, (C,), None, None, eps)
+        hcat = xn @ w1.t() + b1
+        g = hcat[:, :inner] * F.gelu(hcat[:, inner:])
+        out.copy_((xf + g @ w2.t() + b2.float()).to(out.dtype))
+
     def conv_small(self, x, n_img, h, w, wgt, bias, out):
         self._log("conv_small")
         cin, cout = x.shape[1], out.shape[1]
@@ -505,7 +539,7 @@ class ReplayOps:
     Python closures every time.  Catches what only that mode can get wrong: state that lives in Python during recording but
     not during a replay, buffers recycled between the forward and backward lists, inputs that are not static."""
     is_native = True
-    _PURE = ("gn_ws_floats", "gn_bwd_ws_floats", "group_norm_ws_floats", "group_norm_cs_ws_floats", "gemm_fuse_supported", "dropout_keep", "masks", "calls", "strict")
+    _PURE = ("gn_ws_floats", "gn_bwd_ws_floats", "group_norm_ws_floats", "group_norm_cs_ws_floats", "gemm_fuse_supported", "ffn_fused_supported", "dropout_keep", "masks", "calls", "strict")
 
     def __init__(self, inner=None):
         self.inner = inner or EmuOps(strict=True)

@@ -38,6 +38,7 @@ struct uint2 { unsigned x, y; };
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 

@@ -153,7 +153,7 @@ def test_unet_engine_with_layernorm_fused_into_the_producing_gemm():
     for fuse in (False, True):
         ops = EmuOps()
         eng = UNetEngine(m, ops)
-        eng.fuse_ln, eng.fold_ln = fuse, False      # (the default since round 3 is the fold below, which supersedes this form)
+        eng.fuse_ln, eng.fold_ln, eng.fuse_ff = fuse, False, False   # (the default since round 3 is the dataflow of the next test)
         with torch.no_grad():
             y = eng(g["x"], g["ts"], g["ctx"], 16, g["tc"], None)
         assert rel_l2(y, g["y"]) < 2e-5, fuse
@@ -181,7 +181,8 @@ def test_unet_engine_norm_statistics_from_the_producing_gemms():
             ops = EmuOps()
             eng = UNetEngine(m, ops)
             eng.fuse_gn = eng.fold_ln = eng.fold_ln_wide = fused    # (wide: also q|k|v and the GEGLU projection — off by default on the
-            with torch.no_grad():                                    #  device, where it measured slower; the dataflow is pinned here)
+            eng.fuse_ff = False                                      #  device, where it measured slower; the dataflow is pinned here)
+            with torch.no_grad():
                 y = eng(*args)
             assert rel_l2(y, g["y"]) < 2e-5, (fixture, fused)
             counts[fused] = {name: ops.calls.count(name) for name in ("layernorm", "gemm", "group_norm", "group_norm_cs")}
@@ -195,8 +196,10 @@ def test_unet_engine_norm_statistics_from_the_producing_gemms():
         eng = UNetEngine(m, ops)
         with torch.no_grad():
             y = eng(*args)
-        assert rel_l2(y, g["y"]) < 2e-5 and eng.fold_ln and not eng.fold_ln_wide
-        assert ops.calls.count("layernorm") == n_ln - n_sp
+        assert rel_l2(y, g["y"]) < 2e-5 and eng.fold_ln and not eng.fold_ln_wide and eng.fuse_ff
+        n_blocks = sum(1 for mod in m.modules() if type(mod).__name__ == "BasicTransformerBlock")
+        # ... and every feed-forward (LayerNorm + GEGLU projection + output projection + residual) is ONE launch
+        assert ops.calls.count("ffn_fused") == n_blocks and ops.calls.count("layernorm") == n_ln - n_sp - n_blocks
         # GroupNorm: every statistics unit of >= 32 rows whose input came out of a GEMM takes the producer's statistics
         n_gn = counts[False]["group_norm"]
         assert counts[True]["group_norm"] + counts[True]["group_norm_cs"] == n_gn and counts[True]["group_norm_cs"] > n_gn // 3

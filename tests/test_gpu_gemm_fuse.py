@@ -154,3 +154,31 @@ def test_group_norm_from_column_statistics(hip, c0, c1, units, rows, silu):
                       gamma.cuda(), beta.cuda(), silu, ws, out2)
     torch.cuda.synchronize()
     assert torch.equal(out2, out_h)
+
+
+@pytest.mark.parametrize("C,M", [(64, 200), (320, 250), (320, 40960)])
+def test_fused_feed_forward(hip, C, M):
+    """t2v_ffn_fused (csrc/ffn.hip) on MI355X: out = x + FF(LayerNorm(x)) in one launch, against the emulation (decoding the packed
+    operands) and the plain arithmetic of attention.py:300-311,516-542."""
+    gen = torch.Generator().manual_seed(C + M)
+    inner = 4 * C
+    x = (torch.randn(M, C, generator=gen) * 1.2 + 0.3).bfloat16()
+    w1 = (torch.randn(2 * inner, C, generator=gen) * C ** -0.5).bfloat16().float()
+    b1 = torch.randn(2 * inner, generator=gen) * 0.1
+    w2 = (torch.randn(C, inner, generator=gen) * inner ** -0.5).bfloat16().float()
+    b2 = torch.randn(C, generator=gen) * 0.1
+    gamma, beta = torch.randn(C, generator=gen) * 0.2 + 1.0, torch.randn(C, generator=gen) * 0.1
+    assert hip.ffn_fused_supported(C)
+    pk = nt.ffn_pack(w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), gamma.cuda(), beta.cuda(), torch.bfloat16)
+    out_h = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    hip.ffn_fused(x.cuda(), *pk, 1e-5, out_h)
+    torch.cuda.synchronize()
+    xf = x.float()
+    h = torch.nn.functional.layer_norm(xf, (C,), gamma, beta, 1e-5) @ w1.t() + b1
+    ref = xf + (h[:, :inner] * torch.nn.functional.gelu(h[:, inner:])) @ w2.t() + b2
+    got = out_h.float().cpu()
+    assert torch.isfinite(got).all() and rel_l2(got, ref) < 8e-3
+    out2 = torch.zeros_like(out_h)
+    hip.ffn_fused(x.cuda(), *pk, 1e-5, out2)
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out_h)

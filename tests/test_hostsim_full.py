@@ -230,3 +230,32 @@ def test_group_norm_from_the_producers_column_statistics(full_ops, c0, c1, units
     out_e2 = torch.zeros(M, C)
     emu.group_norm_cs(cs0, cs1, x0.float(), None if x1 is None else x1.float(), units, rows, 1e-5, gamma, beta, silu, None, out_e2)
     assert rel_l2(out_e2, out_e) < 1e-5
+
+
+@pytest.mark.parametrize("C,M", [(64, 200), (320, 250), (64, 192)])
+def test_fused_feed_forward_kernel(full_ops, C, M):
+    """t2v_ffn_fused (csrc/ffn.hip): LayerNorm -> GEGLU projection -> output projection -> + residual in one launch, the packed
+    fragment-order weights from native.ffn_pack — against the emulation (which decodes the packed operands by the header's layout
+    rules) and against the plain module arithmetic; ragged last workgroup / wave included."""
+    from tests.emu_ops import EmuOps
+    sim, emu = full_ops(), EmuOps()
+    gen = torch.Generator().manual_seed(C + M)
+    inner = 4 * C
+    x = (torch.randn(M, C, generator=gen) * 1.2 + 0.3).bfloat16()
+    w1 = (torch.randn(2 * inner, C, generator=gen) * C ** -0.5).bfloat16().float()
+    b1 = torch.randn(2 * inner, generator=gen) * 0.1
+    w2 = (torch.randn(C, inner, generator=gen) * inner ** -0.5).bfloat16().float()
+    b2 = torch.randn(C, generator=gen) * 0.1
+    gamma, beta = torch.randn(C, generator=gen) * 0.2 + 1.0, torch.randn(C, generator=gen) * 0.1
+    assert sim.ffn_fused_supported(C)
+    pk = nt.ffn_pack(w1, b1, w2, b2, gamma, beta, torch.bfloat16)
+    out_s = torch.full((M, C), float("nan"), dtype=torch.bfloat16)
+    sim.ffn_fused(x, *pk, 1e-5, out_s)
+    out_e = torch.zeros(M, C)
+    emu.ffn_fused(x.float(), *[t.float() for t in pk], 1e-5, out_e)
+    xf = x.float()
+    h = torch.nn.functional.layer_norm(xf, (C,), gamma, beta, 1e-5) @ w1.t() + b1
+    ref = xf + (h[:, :inner] * torch.nn.functional.gelu(h[:, inner:])) @ w2.t() + b2
+    assert torch.isfinite(out_s.float()).all()
+    assert rel_l2(out_e, ref) < 5e-3                    # (the packed W1 diag(gamma) is rounded to bf16)
+    assert rel_l2(out_s.float(), out_e) < 6e-3          # bf16 normalised rows and hidden activations inside the kernel

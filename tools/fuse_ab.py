@@ -70,6 +70,19 @@ def main():
                 kw2 = dict(kw, tile_cfg=cfg, split_k=1)
                 if ops.gemm_fuse_supported(y, w, out, **kw2):
                     print(f"{lvl},{name},ln_fold@tile{cfg},{timeit(lambda: ops.gemm(y, w, out, **kw2)):.2f}")
+        # the feed-forward: LayerNorm + GEGLU projection + output projection (+ residual) as three launches vs t2v_ffn_fused
+        if ops.ffn_fused_supported(C):
+            w1, b1 = rnd(8 * C, C, scale=C ** -0.5), rnd(8 * C, dtype=torch.float32)
+            w2, b2 = rnd(C, 4 * C, scale=(4 * C) ** -0.5), rnd(C, dtype=torch.float32)
+            hbuf, o3 = torch.empty(M, 4 * C, dtype=torch.bfloat16, device=dev), torch.empty(M, C, dtype=torch.bfloat16, device=dev)
+            pk = nt.ffn_pack(w1, b1, w2, b2, gamma, beta, torch.bfloat16)
+
+            def three():
+                ops.layernorm(y, gamma, beta, 1e-5, ln)
+                ops.gemm(ln, w1, hbuf, M=M, N=8 * C, bias=b1, act=nt.ACT_GEGLU)
+                ops.gemm(hbuf, w2, o3, M=M, N=C, bias=b2, residual=y)
+            print(f"{lvl},feed_forward,three_launches,{timeit(three):.2f}")
+            print(f"{lvl},feed_forward,fused,{timeit(lambda: ops.ffn_fused(y, *pk, 1e-5, o3)):.2f}")
         # GroupNorm producers / consumers
         n_img, h, wd = 16, {2560: 40, 640: 20, 160: 10}[hw], {2560: 64, 640: 32, 160: 16}[hw]
         w3, w1 = rnd(C, 9 * C, scale=(9 * C) ** -0.5), rnd(C, 3 * C, scale=(3 * C) ** -0.5)
