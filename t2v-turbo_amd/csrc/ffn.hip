@@ -24,6 +24,13 @@
 //
 // Algorithmic work: 2 * M * (2 * 4C * C + 4C * C) FLOP; HBM bytes: 2 * M * C * 2 (x in, out) + the packed weights once.
 #include "common.h"
+#include <cstdlib>
+
+#ifdef T2V_FFN_NOPIN   // diagnostic build: leave the issue order of reads / MFMAs / GEGLU arithmetic to the compiler
+#define FFN_PIN() ((void)0)
+#else
+#define FFN_PIN() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 namespace {
 
@@ -50,11 +57,11 @@ __device__ __forceinline__ float ffn_gelu(float x) {
     return x * fmaf(xc, q, 0.5f);
 }
 
-constexpr int FFN_WAVES = 4, FFN_CT = 3;                 // waves per workgroup, 16-token column tiles per wave
-constexpr int FFN_TOK = FFN_WAVES * FFN_CT * 16;         // tokens per workgroup (192)
+constexpr int FFN_WAVES = 4;                             // waves per workgroup (one per SIMD); a wave owns CT 16-token column tiles
 
-template <int C>
+template <int C, int CT>
 struct FfnGeom {
+    static constexpr int TOK = FFN_WAVES * CT * 16;      // tokens per workgroup
     static constexpr int KS = C / 32;                     // k-steps of the first GEMM (contraction over C)
     static constexpr int RT = C / 16;                     // 16-row output tiles of the second GEMM
     static constexpr int NCH = C / 8;                     // hidden chunks of 32 (hidden = 4C)
@@ -66,12 +73,12 @@ struct FfnGeom {
     static constexpr int SMEM = (2 * BUF > FFN_WAVES * STAGE) ? 2 * BUF : FFN_WAVES * STAGE;
 };
 
-template <int C>
+template <int C, int FFN_CT>
 __global__ __launch_bounds__(FFN_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void ffn_fused_kernel(const bf16_t* __restrict__ x, int ldx, int M, const bf16_t* __restrict__ w1p, const float* __restrict__ b1p,
                       const bf16_t* __restrict__ w2p, const float* __restrict__ b2, float eps, bf16_t* __restrict__ out, int ldo) {
-    using G = FfnGeom<C>;
-    constexpr int KS = G::KS, RT = G::RT, NCH = G::NCH;
+    using G = FfnGeom<C, FFN_CT>;
+    constexpr int KS = G::KS, RT = G::RT, NCH = G::NCH, FFN_TOK = G::TOK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,7 +101,12 @@ void ffn_fused_kernel(const bf16_t* __restrict__ x, int ldx, int M, const bf16_t
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b1p + (size_t)chunk * 64 + lane),
                                              (__attribute__((address_space(3))) void*)(smem + buf * G::BUF + G::BIAS_OFF), 4, 0, 0);
     };
-    issue(0, 0);
+    // Every workgroup streams the SAME weights: walking the chunks in the same order, the 32 CUs of an XCD would ask its L2 for
+    // the same lines at the same time (one channel at a time instead of all of them).  Each workgroup therefore starts at its own
+    // chunk and wraps around (the order of the fp32 accumulation over chunks differs between workgroups, never between runs).
+    const int rot = blockIdx.x % NCH;
+    auto chunk_of = [&](int j) { const int c = j + rot; return c >= NCH ? c - NCH : c; };
+    issue(chunk_of(0), 0);
 
     // ---- x rows -> LayerNorm (no affine: gamma / beta are folded into W1 / b1 on the host) -> bf16 B fragments -----------------
     // lane (col, kg) holds channels [32 s + 8 kg, +8) of token col for every k-step s: a row lives in the 4 lanes of its quartet
@@ -154,11 +166,13 @@ void ffn_fused_kernel(const bf16_t* __restrict__ x, int ldx, int M, const bf16_t
     typedef __attribute__((__vector_size__(4 * sizeof(short)))) short bf16x4s_t;
     for (int j = 0; j < NCH; ++j) {
         const int buf = j & 1;
-        if (j + 1 < NCH) issue(j + 1, buf ^ 1);
+        if (j + 1 < NCH) issue(chunk_of(j + 1), buf ^ 1);
         const char* wb = smem + buf * G::BUF + lane * 16;
-        bf16x8_t ring[3];
-        ring[0] = *(const bf16x8_t*)(wb);
-        ring[1] = *(const bf16x8_t*)(wb + 1024);
+        // fragment rings: a piece feeds only CT MFMAs (16 cycles each), the LDS round trip is > 100 cycles: RD - 1 pieces in flight
+        constexpr int RD1 = FFN_CT >= 3 ? 4 : 6, RD2 = FFN_CT >= 3 ? 6 : 8;
+        bf16x8_t ring[RD1];
+#pragma unroll
+        for (int n = 0; n < RD1 - 1; ++n) ring[n] = *(const bf16x8_t*)(wb + n * 1024);
         f32x4_t S[4][FFN_CT];
 #pragma unroll
         for (int T = 0; T < 4; ++T)
@@ -184,35 +198,37 @@ void ffn_fused_kernel(const bf16_t* __restrict__ x, int ldx, int M, const bf16_t
         // keep the issue order as written — the compiler otherwise hoists every fragment read to the top and spills
 #pragma unroll
         for (int n = 0; n < G::W1_PIECES; ++n) {
-            if (n + 2 < G::W1_PIECES) ring[(n + 2) % 3] = *(const bf16x8_t*)(wb + (n + 2) * 1024);
+            if (n + RD1 - 1 < G::W1_PIECES) ring[(n + RD1 - 1) % RD1] = *(const bf16x8_t*)(wb + (n + RD1 - 1) * 1024);
             const int T = n / KS, sk = n % KS;
 #pragma unroll
-            for (int c = 0; c < FFN_CT; ++c) S[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[n % 3], X[c][sk], S[T][c], 0, 0, 0);
+            for (int c = 0; c < FFN_CT; ++c) S[T][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[n % RD1], X[c][sk], S[T][c], 0, 0, 0);
             if (n >= 2 * KS && (n - 2 * KS) % GS == GO && (n - 2 * KS) / GS < FFN_CT) geglu_tile(0, (n - 2 * KS) / GS, Pa);
-            __builtin_amdgcn_sched_barrier(0);
+            FFN_PIN();
         }
         // GEMM2 as two 16-deep halves over all row tiles: a W2 piece holds [4 k of pair a | 4 k of pair b] per lane, each pass
         // reads its 8 bytes (ds_read_b64) through its own ring; pair b's GEGLU is dealt out between half a's row tiles
         const char* w2b = wb + G::W1_PIECES * 1024;
-        bf16x4s_t r2[3];
-        r2[0] = *(const bf16x4s_t*)(w2b);
-        r2[1] = *(const bf16x4s_t*)(w2b + 1024);
+        bf16x4s_t r2[RD2];
+#pragma unroll
+        for (int t = 0; t < RD2 - 1; ++t)
+            if (t < RT) r2[t] = *(const bf16x4s_t*)(w2b + t * 1024);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            if (t + 2 < RT) r2[(t + 2) % 3] = *(const bf16x4s_t*)(w2b + (t + 2) * 1024);
+            if (t + RD2 - 1 < RT) r2[(t + RD2 - 1) % RD2] = *(const bf16x4s_t*)(w2b + (t + RD2 - 1) * 1024);
 #pragma unroll
-            for (int c = 0; c < FFN_CT; ++c) O[t][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(r2[t % 3], Pa[c], O[t][c], 0, 0, 0);
+            for (int c = 0; c < FFN_CT; ++c) O[t][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(r2[t % RD2], Pa[c], O[t][c], 0, 0, 0);
             if (t % G2 == G2O && t / G2 < FFN_CT) geglu_tile(1, t / G2, Pb);
-            __builtin_amdgcn_sched_barrier(0);
+            FFN_PIN();
         }
-        r2[0] = *(const bf16x4s_t*)(w2b + 8);
-        r2[1] = *(const bf16x4s_t*)(w2b + 1024 + 8);
+#pragma unroll
+        for (int t = 0; t < RD2 - 1; ++t)
+            if (t < RT) r2[t] = *(const bf16x4s_t*)(w2b + t * 1024 + 8);
 #pragma unroll
         for (int t = 0; t < RT; ++t) {
-            if (t + 2 < RT) r2[(t + 2) % 3] = *(const bf16x4s_t*)(w2b + (t + 2) * 1024 + 8);
+            if (t + RD2 - 1 < RT) r2[(t + RD2 - 1) % RD2] = *(const bf16x4s_t*)(w2b + (t + RD2 - 1) * 1024 + 8);
 #pragma unroll
-            for (int c = 0; c < FFN_CT; ++c) O[t][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(r2[t % 3], Pb[c], O[t][c], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int c = 0; c < FFN_CT; ++c) O[t][c] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(r2[t % RD2], Pb[c], O[t][c], 0, 0, 0);
+            FFN_PIN();
         }
         // my share of chunk j+1 has landed, and (after the barrier) everybody's; everybody is also done reading buffer `buf`
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -249,16 +265,17 @@ void ffn_fused_kernel(const bf16_t* __restrict__ x, int ldx, int M, const bf16_t
     }
 }
 
-template <int C>
+template <int C, int FFN_CT>
 int ffn_launch(const void* x, int ldx, int M, const void* w1p, const float* b1p, const void* w2p, const float* b2, float eps, void* out,
                int ldo, hipStream_t s) {
-    using G = FfnGeom<C>;
+    using G = FfnGeom<C, FFN_CT>;
+    constexpr int FFN_TOK = G::TOK;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)ffn_fused_kernel<C>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        hipFuncSetAttribute((const void*)ffn_fused_kernel<C, FFN_CT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL((ffn_fused_kernel<C>), dim3((M + FFN_TOK - 1) / FFN_TOK), dim3(FFN_WAVES * 64), G::SMEM, s, (const bf16_t*)x, ldx, M,
+    hipLaunchKernelGGL((ffn_fused_kernel<C, FFN_CT>), dim3((M + FFN_TOK - 1) / FFN_TOK), dim3(FFN_WAVES * 64), G::SMEM, s, (const bf16_t*)x, ldx, M,
                        (const bf16_t*)w1p, b1p, (const bf16_t*)w2p, b2, eps, (bf16_t*)out, ldo);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
@@ -276,9 +293,12 @@ extern "C" int t2v_ffn_fused(const void* x, int ldx, int M, int C, const void* w
                 "t2v_ffn_fused: operands must be 16-byte aligned");
     T2V_REQUIRE(x != out, T2V_EINVAL, "t2v_ffn_fused: in-place operation is not supported (the epilogue re-reads x as the residual)");
     hipStream_t s = (hipStream_t)stream;
+    static const int ct = getenv("T2V_FFN_CT") ? atoi(getenv("T2V_FFN_CT")) : 3;   // column tiles per wave (2: 128-token workgroups)
     switch (C) {
-        case 320: return ffn_launch<320>(x, ldx, M, w1p, b1p, w2p, b2, ln_eps, out, ldo, s);
-        case 64: return ffn_launch<64>(x, ldx, M, w1p, b1p, w2p, b2, ln_eps, out, ldo, s);
+        case 320: return ct == 2 ? ffn_launch<320, 2>(x, ldx, M, w1p, b1p, w2p, b2, ln_eps, out, ldo, s)
+                                 : ffn_launch<320, 3>(x, ldx, M, w1p, b1p, w2p, b2, ln_eps, out, ldo, s);
+        case 64: return ct == 2 ? ffn_launch<64, 2>(x, ldx, M, w1p, b1p, w2p, b2, ln_eps, out, ldo, s)
+                                : ffn_launch<64, 3>(x, ldx, M, w1p, b1p, w2p, b2, ln_eps, out, ldo, s);
         default: T2V_REQUIRE(false, T2V_ESHAPE, "t2v_ffn_fused: built for C = 320 (and 64, the test width)");
     }
     return T2V_OK;

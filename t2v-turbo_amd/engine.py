@@ -336,7 +336,10 @@ class _Engine:
     # epilogue, the serial tail of a workgroup.  T2V_FOLD_LN_WIDE=1 folds those too (for the record, not for speed).
     fold_ln_wide = os.environ.get("T2V_FOLD_LN_WIDE", "0") == "1"
     # BasicTransformerBlock's feed-forward (LayerNorm, GEGLU projection, output projection, residual) as ONE launch where the
-    # kernel exists (csrc/ffn.hip: C = 320, the level whose 105 MB hidden activation costs the most)
+    # kernel exists (csrc/ffn.hip: C = 320, the level whose 105 MB hidden activation costs the most).  Correct on MI355X and
+    # SLOWER than the three launches it replaces (212-220 us against 186-195 us at M = 40960; profiles/r03_ffn_fused_pmc.csv:
+    # the matrix cores are busy 29 % of the time, the GEGLU / register-shuffle VALU work and the waits do not overlap them with
+    # one wave per SIMD, and two do not fit: 120 + 240 + 48 registers of operands per lane).  Opt-in: T2V_FUSE_FF=1.
     fuse_ff = False
 
     def _colstat_for(self, a0, w, out, **kw):
@@ -462,7 +465,7 @@ class UNetEngine(_Engine):
         if type(self) is UNetEngine:
             self.fuse_gn = os.environ.get("T2V_FUSE_GN", "1") == "1"
             self.fold_ln = os.environ.get("T2V_FOLD_LN", "1") == "1"
-            self.fuse_ff = os.environ.get("T2V_FUSE_FF", "1") == "1"
+            self.fuse_ff = os.environ.get("T2V_FUSE_FF", "0") == "1"
 
     @on_tensor_device
     def __call__(self, x, timesteps, context, fps=16, timestep_cond=None, motion_cond=None):

@@ -194,9 +194,11 @@ def test_unet_engine_norm_statistics_from_the_producing_gemms():
         # the device default folds only the text cross-attention's q: one LayerNorm per spatial block gone
         ops = EmuOps()
         eng = UNetEngine(m, ops)
+        assert not eng.fuse_ff      # opt-in on the device (measured slower than three launches); its dataflow is pinned here
+        eng.fuse_ff = True
         with torch.no_grad():
             y = eng(*args)
-        assert rel_l2(y, g["y"]) < 2e-5 and eng.fold_ln and not eng.fold_ln_wide and eng.fuse_ff
+        assert rel_l2(y, g["y"]) < 2e-5 and eng.fold_ln and not eng.fold_ln_wide
         n_blocks = sum(1 for mod in m.modules() if type(mod).__name__ == "BasicTransformerBlock")
         # ... and every feed-forward (LayerNorm + GEGLU projection + output projection + residual) is ONE launch
         assert ops.calls.count("ffn_fused") == n_blocks and ops.calls.count("layernorm") == n_ln - n_sp - n_blocks
