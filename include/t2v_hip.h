@@ -183,11 +183,14 @@ int t2v_gn_apply(const void* x0, int c0, int ld0, const void* x1, int c1, int ld
                  int rows_per_unit, int groups, const float* stats, const float* gamma,
                  const float* beta, int silu, void* out, int ldo, void* stream);
 /* GroupNorm(+SiLU) in one call (what the engines use): statistics + normalise, 2 launches for tensors with few row slabs,
- * 3 otherwise.  ws: t2v_group_norm_ws_floats(n_units, rows_per_unit, groups, c0 + c1) floats. */
+ * 3 otherwise.  ws: t2v_group_norm_ws_floats(n_units, rows_per_unit, groups, c0 + c1) floats.
+ * prefetch / prefetch_bytes (NULL / 0 = off): a buffer the NEXT launch will stream — the weights of the conv that follows every
+ * GroupNorm of the UNet — touched with streaming loads by the normalise pass so that it sits in the 256 MB Infinity Cache when
+ * that launch starts (a UNet step walks 2.8 GB of weights: nothing survives from the previous step).  Hint only. */
 long long t2v_group_norm_ws_floats(int n_units, int rows_per_unit, int groups, int channels);
 int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units, int rows_per_unit,
                    int groups, float eps, const float* gamma, const float* beta, int silu, float* ws, void* out, int ldo,
-                   void* stream);
+                   const void* prefetch, long long prefetch_bytes, void* stream);
 
 /* GroupNorm(+SiLU) whose statistics pass reads the column statistics the producing t2v_gemm launches wrote
  * (t2v_gemm_desc::colstat_out) instead of the tensor: cs0 [rows/32][c0][2] for x0, cs1 [rows/32][c1][2] for the second part of
@@ -196,7 +199,7 @@ int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, int c1, int 
 long long t2v_group_norm_cs_ws_floats(int n_units, int rows_per_unit, int groups);
 int t2v_group_norm_cs(const float* cs0, const float* cs1, const void* x0, int c0, int ld0, const void* x1, int c1, int ld1,
                       int n_units, int rows_per_unit, int groups, float eps, const float* gamma, const float* beta, int silu,
-                      float* ws, void* out, int ldo, void* stream);
+                      float* ws, void* out, int ldo, const void* prefetch, long long prefetch_bytes, void* stream);
 
 /* LayerNorm over the channel dim, eps, affine; bf16 in/out (attention.py:279-281). */
 int t2v_layernorm(const void* x, int ldx, int M, int C, const float* gamma, const float* beta,

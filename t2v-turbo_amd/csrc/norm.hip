@@ -240,11 +240,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0,
                                                        int ld1, int rows_per_unit, int groups, int slab_rows, const float* stats,
                                                        const float* coef, const float* partial, int nslab_stats, float inv_count,
                                                        float eps, const float* gamma, const float* beta, int silu, bf16_t* out,
-                                                       int ldo) {
+                                                       int ldo, const char* pf, long long pf_lines) {
     const int C = c0 + c1, cpg = C / groups;
     const GnGeom g = gn_geom(C);
     const int unit = blockIdx.y, slab = blockIdx.x;
     const int tid = threadIdx.x;
+    // Prefetch for the NEXT launch (the conv whose weights `pf` points at, up to tens of MB that the 256 MB Infinity Cache has
+    // not seen since the previous step): every block touches its share of the 128-byte lines with streaming (nt) loads issued
+    // before its own work; the values are only looked at after it, so their latency costs nothing here and the conv's first
+    // K steps find the weights on the memory side of the fabric instead of in HBM.
+    unsigned pf_acc = 0;
+    if (pf_lines > 0) {
+        const long long nb = (long long)gridDim.x * gridDim.y, b = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long long per = (pf_lines + nb - 1) / nb;
+        const long long l1 = min(pf_lines, (b + 1) * per);
+        for (long long l = b * per + tid; l < l1; l += 256) pf_acc |= __builtin_nontemporal_load((const unsigned*)(pf + (l << 7)));
+    }
     const int cx = tid % g.tx, ry = tid / g.tx;
     __shared__ double sh[MODE == 2 ? 256 : 1];
     __shared__ float sm[MODE == 2 ? 128 : 1], sr[MODE == 2 ? 128 : 1];
@@ -313,6 +324,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0,
             }
         }
     }
+    if (pf_lines > 0 && pf_acc == 0x7fc1a55au && ldo < 0) out[0] = 0;   // (never true: keeps the prefetch loads alive)
 }
 
 #ifndef T2V_HOSTSIM
@@ -630,7 +642,7 @@ extern "C" int t2v_gn_apply(const void* x0, int c0, int ld0, const void* x1, int
     const int C = c0 + c1;
     hipLaunchKernelGGL(gn_apply_kernel<0>, dim3(gn_nslab(C, rows_per_unit, groups), n_units), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, rows_per_unit, groups, gn_slab_rows(C, rows_per_unit, groups),
-                       stats, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0.f, gamma, beta, silu, (bf16_t*)out, ldo);
+                       stats, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0.f, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)nullptr, 0LL);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
@@ -716,7 +728,7 @@ extern "C" int t2v_gn_coop_enable(int) { return T2V_OK; }
 // tensors with few slabs, an apply pass whose blocks finish the statistics themselves (2 launches instead of 3).
 extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units,
                               int rows_per_unit, int groups, float eps, const float* gamma, const float* beta, int silu,
-                              float* ws, void* out, int ldo, void* stream) {
+                              float* ws, void* out, int ldo, const void* prefetch, long long prefetch_bytes, void* stream) {
     int rc = gn_check(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups);
     if (rc) return rc;
     T2V_REQUIRE(ws && gamma && beta && out && ldo % 8 == 0, T2V_EINVAL, "t2v_group_norm: bad argument");
@@ -747,7 +759,7 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
         T2V_CHECK_LAUNCH();
         hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
                            ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, stat_nslab,
-                           inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo);
+                           inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
         T2V_CHECK_LAUNCH();
         return T2V_OK;
     }
@@ -756,7 +768,7 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
     if (nslab <= gn_fuse_slabs(groups)) {
         hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
                            ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, nslab,
-                           inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo);
+                           inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
         T2V_CHECK_LAUNCH();
         return T2V_OK;
     }
@@ -766,7 +778,7 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
     T2V_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1,
                        rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)coef, (const float*)nullptr, 0, 0.f, 0.f,
-                       gamma, beta, silu, (bf16_t*)out, ldo);
+                       gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
@@ -780,7 +792,7 @@ extern "C" long long t2v_group_norm_cs_ws_floats(int n_units, int rows_per_unit,
 }
 extern "C" int t2v_group_norm_cs(const float* cs0, const float* cs1, const void* x0, int c0, int ld0, const void* x1, int c1, int ld1,
                                  int n_units, int rows_per_unit, int groups, float eps, const float* gamma, const float* beta, int silu,
-                                 float* ws, void* out, int ldo, void* stream) {
+                                 float* ws, void* out, int ldo, const void* prefetch, long long prefetch_bytes, void* stream) {
     int rc = gn_check(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups);
     if (rc) return rc;
     T2V_REQUIRE(ws && gamma && beta && out && ldo % 8 == 0 && cs0, T2V_EINVAL, "t2v_group_norm_cs: bad argument");
@@ -799,7 +811,7 @@ extern "C" int t2v_group_norm_cs(const float* cs0, const float* cs1, const void*
     T2V_CHECK_LAUNCH();
     hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
                        ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, nblk,
-                       inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo);
+                       inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }

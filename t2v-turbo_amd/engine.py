@@ -306,8 +306,13 @@ class _Engine:
     def buf(self, rows, cols, dtype=None, zero=False):
         return self.pool.get(rows, cols, dtype or self.adt, zero)
 
-    def gn(self, x, norm, units, rows_per_unit, silu, eps=None):
-        """GroupNorm(+SiLU) of an Act (possibly a virtual concat) -> new single-part tensor."""
+    # the normalise pass of a GroupNorm also touches the weights of the conv that follows it (t2v_group_norm `prefetch`)
+    prefetch_weights = os.environ.get("T2V_PREFETCH", "1") == "1"
+
+    def gn(self, x, norm, units, rows_per_unit, silu, eps=None, then=None):
+        """GroupNorm(+SiLU) of an Act (possibly a virtual concat) -> new single-part tensor.  ``then``: the packed weight tensor
+        of the launch that consumes the result (prefetched toward the Infinity Cache by the normalise pass)."""
+        pf = {"prefetch": then} if (then is not None and self.prefetch_weights and getattr(self.ops, "is_native", False)) else {}
         ops = self.ops
         G = norm.num_groups
         eps = norm.eps if eps is None else eps
@@ -316,11 +321,11 @@ class _Engine:
             # the producing GEMMs left per-slab column statistics: no statistics pass over the tensor
             ws = self.buf(1, max(ops.group_norm_cs_ws_floats(units, rows_per_unit, G), 1), torch.float32)
             ops.group_norm_cs(x.cs[0], x.cs[1] if len(x.cs) > 1 else None, x.parts[0], x.p1, units, rows_per_unit, eps,
-                              self.pk.f32(norm.weight), self.pk.f32(norm.bias), silu, ws, out, G)
+                              self.pk.f32(norm.weight), self.pk.f32(norm.bias), silu, ws, out, G, **pf)
         else:
             ws = self.buf(1, max(ops.group_norm_ws_floats(units, rows_per_unit, G, x.C), 1), torch.float32)
             ops.group_norm(x.parts[0], x.p1, units, rows_per_unit, eps, self.pk.f32(norm.weight), self.pk.f32(norm.bias),
-                           silu, ws, out, G)
+                           silu, ws, out, G, **pf)
         self.pool.put(ws)
         return out
 
@@ -610,7 +615,7 @@ class UNetEngine(_Engine):
             skip = hs.pop()
             h = self.run_sequential(block, Act([h.t, skip.t], h.n_img, h.h, h.w, cs=[h.cs[0], skip.cs[0]]), release=[h.t, skip.t])
         # ---- out: GroupNorm -> SiLU -> conv to 4 channels, fp32, back to (b c f h w) ------------------------------
-        t = self.gn(h, m.out[0], B * F, H * W, True)
+        t = self.gn(h, m.out[0], B * F, H * W, True, then=self.pk.conv(m.out[2]))
         y = self.conv(Act(t, h.n_img, h.h, h.w), m.out[2], nt.GEMM_CONV3X3, out_dtype=torch.float32)
         ops.tokens_to_ncfhw(y.t, out)
 
@@ -645,11 +650,11 @@ class UNetEngine(_Engine):
         B, F = self.B, self.F
         hw = x.h * x.w
         off, cout = self.emb_off[id(rb)], rb.out_channels
-        t = self.gn(x, rb.in_layers[0], B * F, hw, True)
+        t = self.gn(x, rb.in_layers[0], B * F, hw, True, then=self.pk.conv(rb.in_layers[2]))
         h1 = self.conv(Act(t, x.n_img, x.h, x.w), rb.in_layers[2], nt.GEMM_CONV3X3,
                        rowvec=self.emb_all[:, off:off + cout], rowvec_div=F * hw)
         self.pool.put(t)
-        t2 = self.gn(h1, rb.out_layers[0], B * F, hw, True)
+        t2 = self.gn(h1, rb.out_layers[0], B * F, hw, True, then=self.pk.conv(rb.out_layers[3]))
         self.pool.put(h1.t)
         if isinstance(rb.skip_connection, nn.Identity):
             skip, own_skip = x.t, False
@@ -674,7 +679,7 @@ class UNetEngine(_Engine):
         hw = h2.h * h2.w
         y = h2
         for i, stage in enumerate((tc.conv1, tc.conv2, tc.conv3, tc.conv4)):
-            tt = self.gn(y, stage[0], B, F * hw, True)
+            tt = self.gn(y, stage[0], B, F * hw, True, then=self.pk.conv(stage[-1]))
             ny = self.conv(Act(tt, h2.n_img, h2.h, h2.w), stage[-1], nt.GEMM_TCONV3, frames=F,
                            residual=h2.t if i == 3 else None)
             self.pool.put(tt)
@@ -844,7 +849,7 @@ class UNetEngine(_Engine):
         return self.linear(t, proj_in), None, None
 
     def _transformer(self, tr, x, units, rows_per_unit, temporal):
-        t = self.gn(x, tr.norm, units, rows_per_unit, False)
+        t = self.gn(x, tr.norm, units, rows_per_unit, False, then=self.pk.mat(tr.proj_in))
         y, ln1, rs = self._proj_in_with_ln(t, tr.proj_in, tr.transformer_blocks, temporal)
         self.pool.put(t)
         for i, blk in enumerate(tr.transformer_blocks):

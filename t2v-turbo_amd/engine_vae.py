@@ -117,10 +117,10 @@ class VAEDecodeEngine(_Engine):
     def resnet_block(self, rb, x):
         """ResnetBlock with temb=None (ae_modules.py:183-203); consumes (frees) its input."""
         hw = x.h * x.w
-        t1 = self.gn(x, rb.norm1, x.n_img, hw, True)
+        t1 = self.gn(x, rb.norm1, x.n_img, hw, True, then=self.pk.conv(rb.conv1))
         h1 = self.conv(Act(t1, x.n_img, x.h, x.w), rb.conv1, nt.GEMM_CONV3X3)
         self.pool.put(t1)
-        t2 = self.gn(h1, rb.norm2, x.n_img, hw, True)
+        t2 = self.gn(h1, rb.norm2, x.n_img, hw, True, then=self.pk.conv(rb.conv2))
         self.pool.put(h1.t)
         skip, own = x.t, False
         if rb.in_channels != rb.out_channels:

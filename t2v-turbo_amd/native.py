@@ -71,10 +71,12 @@ _SIGS = {
                                C.c_void_p]),
     "t2v_group_norm_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "t2v_group_norm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+                                 C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong,
+                                 C.c_void_p]),
     "t2v_group_norm_cs_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "t2v_group_norm_cs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                    C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+                                    C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                    C.c_longlong, C.c_void_p]),
     "t2v_layernorm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float,
                                 C.c_void_p, C.c_int, C.c_void_p]),
     "t2v_softmax_rows": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -377,19 +379,26 @@ class HipOps:
     def group_norm_ws_floats(self, n_units, rows_per_unit, groups, channels):
         return int(self.lib.t2v_group_norm_ws_floats(n_units, rows_per_unit, groups, channels))
 
-    def group_norm(self, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32):
+    @staticmethod
+    def _pf(t):
+        """(pointer, bytes) of a contiguous tensor the next launch will stream (``prefetch=`` of the GroupNorm ops), or (None, 0)."""
+        return (None, 0) if t is None else (t.data_ptr(), t.numel() * t.element_size())
+
+    def group_norm(self, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32, prefetch=None):
         self._call("t2v_group_norm", _p(x0), x0.shape[1], _row_stride(x0), _p(x1),
                    0 if x1 is None else x1.shape[1], 0 if x1 is None else _row_stride(x1),
-                   n_units, rows_per_unit, groups, eps, _p(gamma), _p(beta), int(silu), _p(ws), _p(out), _row_stride(out))
+                   n_units, rows_per_unit, groups, eps, _p(gamma), _p(beta), int(silu), _p(ws), _p(out), _row_stride(out),
+                   *self._pf(prefetch))
 
     def group_norm_cs_ws_floats(self, n_units, rows_per_unit, groups):
         return int(self.lib.t2v_group_norm_cs_ws_floats(n_units, rows_per_unit, groups))
 
-    def group_norm_cs(self, cs0, cs1, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32):
+    def group_norm_cs(self, cs0, cs1, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32, prefetch=None):
         """GroupNorm(+SiLU) on the column statistics the producing GEMMs wrote (``gemm(colstat=...)``): no statistics pass."""
         self._call("t2v_group_norm_cs", _p(cs0), _p(cs1), _p(x0), x0.shape[1], _row_stride(x0), _p(x1),
                    0 if x1 is None else x1.shape[1], 0 if x1 is None else _row_stride(x1),
-                   n_units, rows_per_unit, groups, eps, _p(gamma), _p(beta), int(silu), _p(ws), _p(out), _row_stride(out))
+                   n_units, rows_per_unit, groups, eps, _p(gamma), _p(beta), int(silu), _p(ws), _p(out), _row_stride(out),
+                   *self._pf(prefetch))
 
     def layernorm(self, x, gamma, beta, eps, out):
         self._call("t2v_layernorm", _p(x), _row_stride(x), x.shape[0], x.shape[1], _p(gamma), _p(beta), eps, _p(out),

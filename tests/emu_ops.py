@@ -223,7 +223,7 @@ class EmuOps:
     def group_norm_ws_floats(self, n_units, rows_per_unit, groups, channels):
         return 8
 
-    def group_norm(self, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32):
+    def group_norm(self, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32, prefetch=None):
         self._log("group_norm")
         stats = torch.empty(n_units, groups * 2)
         self.gn_stats(x0, x1, n_units, rows_per_unit, eps, ws, stats, groups)
@@ -232,7 +232,7 @@ class EmuOps:
     def group_norm_cs_ws_floats(self, n_units, rows_per_unit, groups):
         return 8
 
-    def group_norm_cs(self, cs0, cs1, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32):
+    def group_norm_cs(self, cs0, cs1, x0, x1, n_units, rows_per_unit, eps, gamma, beta, silu, ws, out, groups=32, prefetch=None):
         """GroupNorm(+SiLU) with the statistics taken from the producers' column statistics cs [rows / 32, C, 2]."""
         self._log("group_norm_cs")
         assert rows_per_unit % 32 == 0 and (x1 is None) == (cs1 is None)

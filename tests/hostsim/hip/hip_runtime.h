@@ -351,6 +351,7 @@ inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : 1; }
 inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) hostsim::mfma_16x16x32_bf16((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, x, y, z) hostsim::mfma_16x16x16_bf16((a), (b), (c))
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
