@@ -306,8 +306,11 @@ class _Engine:
     def buf(self, rows, cols, dtype=None, zero=False):
         return self.pool.get(rows, cols, dtype or self.adt, zero)
 
-    # the normalise pass of a GroupNorm also touches the weights of the conv that follows it (t2v_group_norm `prefetch`)
-    prefetch_weights = os.environ.get("T2V_PREFETCH", "1") == "1"
+    # the normalise pass of a GroupNorm can also touch the weights of the conv that follows it (t2v_group_norm `prefetch`: streaming
+    # loads toward the Infinity Cache).  Measured on MI355X, interleaved A/B on one box: 24.16 / 24.15 ms per UNet step with it,
+    # 23.86 / 23.83 without — the GEMMs do not get faster (19.5 vs 19.45 ms: their weights are not what they wait for) and the
+    # GroupNorm passes pay for the extra loads.  Opt-in (T2V_PREFETCH=1), kept as a measured negative result.
+    prefetch_weights = os.environ.get("T2V_PREFETCH", "0") == "1"
 
     def gn(self, x, norm, units, rows_per_unit, silu, eps=None, then=None):
         """GroupNorm(+SiLU) of an Act (possibly a virtual concat) -> new single-part tensor.  ``then``: the packed weight tensor
