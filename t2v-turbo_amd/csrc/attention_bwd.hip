@@ -11,7 +11,8 @@
 //
 // Operands the caller provides next to the token-major rows: K^T, Q^T and dO^T per image ([heads*64][padded sequence], the
 // layout of the forward's V^T buffer; t2v_transpose_pad_bf16 makes them).  Validated on MI355X (tests/test_gpu_unet_grad.py); also runs on the host SIMT
-// simulator (tests/test_hostsim_attention_bwd.py) against the emulated backend; single-buffered LDS tiles (correctness first).
+// simulator (tests/test_hostsim_attention_bwd.py) against the emulated backend.  The LDS tiles are double-buffered: the LDS-DMA of tile
+// t+1 is issued before tile t's MFMAs and waited for (vmcnt(0) + barrier) after them (the first version waited right after issuing).
 #include "common.h"
 
 namespace {
@@ -19,6 +20,14 @@ namespace {
 constexpr int BT = 64;                 // rows per LDS tile (keys or queries)
 constexpr int TILE_BYTES = BT * 128;   // [64][64] bf16, 128-byte rows, 16-byte chunks XOR-swizzled by (row >> 1) & 7
 
+// -DT2V_ABWD_SINGLE (A/B builds): issue the loads of tile t+1 AFTER tile t's MFMAs and wait at once — the first version's exposure
+#ifdef T2V_ABWD_SINGLE
+#define ABWD_EARLY(x)
+#define ABWD_LATE(x) x
+#else
+#define ABWD_EARLY(x) x
+#define ABWD_LATE(x)
+#endif
 __device__ __forceinline__ void dma16b(const void* gsrc, char* lds_dst_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
@@ -64,16 +73,16 @@ __device__ __forceinline__ bf16x8_t pack_b(const f32x16_t& s, int st) {  // 8 ac
     return *(bf16x8_t*)&pu;
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+#ifndef T2V_ABWD_DQ_WPE
+#define T2V_ABWD_DQ_WPE 3  // 163 registers, no scratch: three workgroups per CU (3 x 48 KiB of LDS); left to itself the compiler takes 208 for two
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ABWD_DQ_WPE, T2V_ABWD_DQ_WPE))) void attn_bwd_dq_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                           const bf16_t* __restrict__ v, int ldv, long long v_img_stride, long long v_head_stride,
                                                           const bf16_t* __restrict__ kt, int ld_kt, const bf16_t* __restrict__ dout, int ldo,
                                                           const bf16_t* __restrict__ o, int ldoo, float* __restrict__ l2, float* __restrict__ dsum,
                                                           int ld_stat, bf16_t* __restrict__ dq, int lddq, int seq_q, int seq_kv, int heads,
                                                           float scale, const bf16_t* zero) {
-    __shared__ __attribute__((aligned(16))) char smem[3 * TILE_BYTES];
-    char* sk = smem;
-    char* sv = smem + TILE_BYTES;
-    char* skt = smem + 2 * TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 3 * TILE_BYTES];  // two stages of (K, V, K^T): tile t+1 lands under tile t's MFMAs
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const bf16_t* ktbase = kt + ((long long)img * heads + head) * 64 * ld_kt;
     const int ntile = (seq_kv + BT - 1) / BT;
 
-    auto scores = [&](f32x16_t* s) {  // S^T = K Q^T for the staged key tile; register r of half h2 <-> key 8*hi + h2*32 + (r>>3)*16 + (r&7)
+    auto scores = [&](f32x16_t* s, const char* sk) {  // S^T = K Q^T for the staged key tile; register r of half h2 <-> key 8*hi + h2*32 + (r>>3)*16 + (r&7)
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
@@ -125,13 +134,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     };
     // ---- pass 1: softmax statistics of this lane's query -----------------------------------------------------------------------
     float m_run = -INFINITY, l_run = 0.f;
+    ld.rows(smem, kbase, ldk, 0, seq_kv, zero);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int t = 0; t < ntile; ++t) {
-        __syncthreads();
-        ld.rows(sk, kbase, ldk, t * BT, seq_kv, zero);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        const char* sk = smem + (t & 1) * 3 * TILE_BYTES;
+        ABWD_EARLY(if (t + 1 < ntile) ld.rows(smem + ((t + 1) & 1) * 3 * TILE_BYTES, kbase, ldk, (t + 1) * BT, seq_kv, zero);)
         f32x16_t s[2];
-        scores(s);
+        scores(s, sk);
         const int key_base = t * BT + 8 * hi;
         float mloc = -INFINITY;
 #pragma unroll
@@ -150,6 +160,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             for (int r = 0; r < 16; ++r) lsum += __builtin_amdgcn_exp2f(fmaf(s[h2][r], c2, -m_new * c2));
         l_run = l_run * __builtin_amdgcn_exp2f((m_run - m_new) * c2) + lsum;
         m_run = m_new;
+        ABWD_LATE(if (t + 1 < ntile) ld.rows(smem + ((t + 1) & 1) * 3 * TILE_BYTES, kbase, ldk, (t + 1) * BT, seq_kv, zero);)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile t+1 has landed; every wave is done with tile t
+        __syncthreads();
     }
     const float L = m_run * c2 + log2f(l_run + __shfl_xor(l_run, 32, 64));
     if (q_ok && hi == 0) {
@@ -161,15 +174,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     f32x16_t acc[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    auto stage = [&](int t) {
+        char* b = smem + (t & 1) * 3 * TILE_BYTES;
+        ld.rows(b, kbase, ldk, t * BT, seq_kv, zero);
+        ld.rows(b + TILE_BYTES, vbase, ldv, t * BT, seq_kv, zero);
+        ld.cols(b + 2 * TILE_BYTES, ktbase, ld_kt, t * BT);
+    };
+    stage(0);   // (pass 1 ended on a barrier: both stages are free)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int t = 0; t < ntile; ++t) {
-        __syncthreads();
-        ld.rows(sk, kbase, ldk, t * BT, seq_kv, zero);
-        ld.rows(sv, vbase, ldv, t * BT, seq_kv, zero);
-        ld.cols(skt, ktbase, ld_kt, t * BT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        const char* sk = smem + (t & 1) * 3 * TILE_BYTES;
+        const char* sv = sk + TILE_BYTES;
+        const char* skt = sk + 2 * TILE_BYTES;
+        ABWD_EARLY(if (t + 1 < ntile) stage(t + 1);)
         f32x16_t s[2], dp[2];
-        scores(s);
+        scores(s, sk);
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
@@ -194,6 +214,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
             for (int db = 0; db < 2; ++db)
                 acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(skt, db * 32 + l31, ks * 2 + hi, swz), pb, acc[db], 0, 0, 0);
         }
+        ABWD_LATE(if (t + 1 < ntile) stage(t + 1);)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
     if (q_ok) {
         bf16_t* op = dq + ((long long)img * seq_q + qi) * lddq + head * 64 + 4 * hi;
@@ -209,18 +232,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+#ifndef T2V_ABWD_DKV_WPE
+#define T2V_ABWD_DKV_WPE 2  // waves per SIMD the register budget of the dK / dV kernel is sized for: 256 registers and 20 bytes of scratch per lane instead of 320 and none, and 26 % faster (1072 vs 1345 us at 16 x 2560 x 5 heads, profiles/r03_attn_bwd_ab.csv); -DT2V_ABWD_DKV_WPE=1 for A/B builds
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ABWD_DKV_WPE, T2V_ABWD_DKV_WPE))) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                            const bf16_t* __restrict__ v, int ldv, long long v_img_stride, long long v_head_stride,
                                                            const bf16_t* __restrict__ qt, const bf16_t* __restrict__ dot, int ld_qt,
                                                            const bf16_t* __restrict__ dout, int ldo, const float* __restrict__ l2,
                                                            const float* __restrict__ dsum, int ld_stat, bf16_t* __restrict__ dk, int lddk,
                                                            bf16_t* __restrict__ dv, int lddv, int seq_q, int seq_kv, int heads, float scale,
                                                            const bf16_t* zero) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
-    char* sq = smem;
-    char* sdo = smem + TILE_BYTES;
-    char* sqt = smem + 2 * TILE_BYTES;
-    char* sdot = smem + 3 * TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 4 * TILE_BYTES];  // two stages of (Q, dO, Q^T, dO^T)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
@@ -253,14 +275,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) { ak[0][r] = 0.f; ak[1][r] = 0.f; av[0][r] = 0.f; av[1][r] = 0.f; }
     const int ntile = (seq_q + BT - 1) / BT;
+    auto stage = [&](int t) {
+        char* b = smem + (t & 1) * 4 * TILE_BYTES;
+        ld.rows(b, qbase, ldq, t * BT, seq_q, zero);
+        ld.rows(b + TILE_BYTES, dobase, ldo, t * BT, seq_q, zero);
+        ld.cols(b + 2 * TILE_BYTES, qtbase, ld_qt, t * BT);
+        ld.cols(b + 3 * TILE_BYTES, dotbase, ld_qt, t * BT);
+    };
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int t = 0; t < ntile; ++t) {
-        __syncthreads();
-        ld.rows(sq, qbase, ldq, t * BT, seq_q, zero);
-        ld.rows(sdo, dobase, ldo, t * BT, seq_q, zero);
-        ld.cols(sqt, qtbase, ld_qt, t * BT);
-        ld.cols(sdot, dotbase, ld_qt, t * BT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        const char* sq = smem + (t & 1) * 4 * TILE_BYTES;
+        const char* sdo = sq + TILE_BYTES;
+        const char* sqt = sq + 2 * TILE_BYTES;
+        const char* sdot = sq + 3 * TILE_BYTES;
+        ABWD_EARLY(if (t + 1 < ntile) stage(t + 1);)
         f32x16_t s[2], dp[2];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
@@ -298,6 +328,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16_t* __restr
                 ak[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(sqt, cb * 32 + l31, ks * 2 + hi, swz), db_, ak[cb], 0, 0, 0);
             }
         }
+        ABWD_LATE(if (t + 1 < ntile) stage(t + 1);)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
     }
     if (k_ok) {
         bf16_t* pk_ = dk + ((long long)img * seq_kv + kj) * lddk + head * 64 + 4 * hi;

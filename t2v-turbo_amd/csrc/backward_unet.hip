@@ -389,6 +389,154 @@ __global__ __launch_bounds__(128) void attn_temporal_bwd_kernel(const bf16_t* q,
     }
 }
 
+// Temporal attention backward on the matrix cores: one wave per (clip, pixel, head), F <= 16 frames, head dim 64, no LDS.
+// Every lane fetches ITS 16-byte slices of q_f / k_f / v_f / dO_f (frame f = lane & 15) straight from the token-major buffers,
+// exactly the A / B fragments of v_mfma_f32_16x16x32_bf16 (contraction over the 64 channels):
+//   S^T = K Q^T, dP^T = V dO^T   lane (i = lane&15, g = lane>>4) holds rows j = 4g + r of query column i: softmax statistics
+//                                 (max, sum, rowsum(P dP)) are lane-local + 2 shuffles                         "layout A"
+//   S   = Q K^T, dP   = dO V^T   the same products with the operands swapped: lane (j, g) holds rows i = 4g + r   "layout B"
+//                                 (the statistics of query 4g + r come from lane 4g + r: three ds_bpermute each)
+// The second-stage products contract over the FRAMES (v_mfma_f32_16x16x16_bf16, k = 4g + r), so dS^T (layout A) and dS, P
+// (layout B) are already B operands, and the A operands are the transposed tiles X^T[c][f].  Those come from the matrix core
+// too: X^T tile m = X-fragment(k step m>>1) x E, E the 0/1 matrix that selects channel 16m + n into column n — the result
+// registers (rows f = 4g + r of column n) ARE the A fragment of X^T (row c = 16m + n, k = f); exact, so the bf16 repack is a
+// truncation.  32 MFMAs, ~150 VALU and no LDS traffic per problem; the VALU form above did ~2 800 LDS reads per lane.
+//   dQ^T = K^T dS^T (scale folded into dS), dK^T = Q^T dS, dV^T = dO^T P: lane (row of the output token, g) holds channels
+//   16m + 4g + r — 8-byte stores.
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short tb_bf16x4_t;
+__device__ __forceinline__ tb_bf16x4_t tb_trunc4(f32x4_t t) {   // exact bf16 values held in fp32 -> bf16x4
+    uint2 u;
+    u.x = (__float_as_uint(t[1]) & 0xffff0000u) | (__float_as_uint(t[0]) >> 16);
+    u.y = (__float_as_uint(t[3]) & 0xffff0000u) | (__float_as_uint(t[2]) >> 16);
+    return *(tb_bf16x4_t*)&u;
+}
+__device__ __forceinline__ tb_bf16x4_t tb_round4(float a, float b, float c, float d) {
+    uint2 u;
+    u.x = pack2bf(a, b);
+    u.y = pack2bf(c, d);
+    return *(tb_bf16x4_t*)&u;
+}
+__global__ __launch_bounds__(256) void attn_temporal_bwd_mfma_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                                     const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ dout, int ldo,
+                                                                     const float* __restrict__ dprobs, bf16_t* __restrict__ dq, int ldq2,
+                                                                     bf16_t* __restrict__ dk, int ldk2, bf16_t* __restrict__ dv, int ldv2,
+                                                                     long long total, int F, int hw, int heads, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long prob = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (prob >= total) return;  // wave-uniform
+    const int hd = (int)(prob % heads);
+    const long long bp = prob / heads;
+    const int pix = (int)(bp % hw);
+    const long long clip = bp / hw;
+    const int l15 = lane & 15, g = lane >> 4;
+    const bool f_ok = l15 < F;
+    const long long row = (clip * F + (f_ok ? l15 : 0)) * hw + pix;
+    const int col = hd * 64 + g * 8;
+    // ---- fragments: frame l15, channels 8g .. 8g+7 (k step 0) and 32 + 8g .. (k step 1)
+    bf16x8_t qf[2], kf[2], vf[2], of[2];
+    {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 a0 = z, a1 = z, b0 = z, b1 = z, c0 = z, c1 = z, d0 = z, d1 = z;
+        if (f_ok) {
+            const bf16_t* qp = q + row * ldq + col;
+            const bf16_t* kp = k + row * ldk + col;
+            const bf16_t* vp = v + row * ldv + col;
+            const bf16_t* op = dout + row * ldo + col;
+            a0 = *(const uint4*)qp; a1 = *(const uint4*)(qp + 32);
+            b0 = *(const uint4*)kp; b1 = *(const uint4*)(kp + 32);
+            c0 = *(const uint4*)vp; c1 = *(const uint4*)(vp + 32);
+            d0 = *(const uint4*)op; d1 = *(const uint4*)(op + 32);
+        }
+        qf[0] = *(bf16x8_t*)&a0; qf[1] = *(bf16x8_t*)&a1;
+        kf[0] = *(bf16x8_t*)&b0; kf[1] = *(bf16x8_t*)&b1;
+        vf[0] = *(bf16x8_t*)&c0; vf[1] = *(bf16x8_t*)&c1;
+        of[0] = *(bf16x8_t*)&d0; of[1] = *(bf16x8_t*)&d1;
+    }
+    const f32x4_t zero4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    f32x4_t sT = zero4, dpT = zero4, sB = zero4, dpB = zero4;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        sT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s], qf[s], sT, 0, 0, 0);    // S^T[j][i]
+        dpT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[s], of[s], dpT, 0, 0, 0);  // dP^T[j][i]
+        sB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], kf[s], sB, 0, 0, 0);    // S[i][j]
+        dpB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[s], vf[s], dpB, 0, 0, 0);  // dP[i][j]
+    }
+    const float c2 = scale * 1.4426950408889634f;
+    // ---- layout A: query i = l15, keys j = 4g + r
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (4 * g + r < F) mx = fmaxf(mx, sT[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float pT[4], den = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pT[r] = (4 * g + r < F) ? __builtin_amdgcn_exp2f((sT[r] - mx) * c2) : 0.f;
+        den += pT[r];
+    }
+    den += __shfl_xor(den, 16, 64);
+    den += __shfl_xor(den, 32, 64);
+    const float rden = 1.0f / den;   // F >= 1: the maximum contributes 1
+    float dot = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pT[r] *= rden;
+        if (dprobs && f_ok && 4 * g + r < F) dpT[r] += dprobs[(prob * F + l15) * F + 4 * g + r];
+        dot += pT[r] * dpT[r];
+    }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    const tb_bf16x4_t dsT_b = tb_round4(pT[0] * (dpT[0] - dot) * scale, pT[1] * (dpT[1] - dot) * scale,
+                                        pT[2] * (dpT[2] - dot) * scale, pT[3] * (dpT[3] - dot) * scale);
+    // ---- layout B: key j = l15, queries i = 4g + r (their statistics live in lane i)
+    float pB[4], dsB[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        const float mi = __shfl(mx, i, 64), ri = __shfl(rden, i, 64), di = __shfl(dot, i, 64);
+        float dp = dpB[r];
+        if (dprobs && f_ok && i < F) dp += dprobs[(prob * F + i) * F + l15];
+        pB[r] = f_ok ? __builtin_amdgcn_exp2f((sB[r] - mi) * c2) * ri : 0.f;
+        dsB[r] = pB[r] * (dp - di) * scale;
+    }
+    const tb_bf16x4_t p_b = tb_round4(pB[0], pB[1], pB[2], pB[3]);
+    const tb_bf16x4_t ds_b = tb_round4(dsB[0], dsB[1], dsB[2], dsB[3]);
+    // ---- selection operands: E_h[c][n] = (c == 16h + n) within one 32-channel k step
+    bf16x8_t sel[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint4 w = make_uint4(0, 0, 0, 0);
+        if (g == 2 * h + (l15 >> 3)) {
+            const uint32_t one = (l15 & 1) ? 0x3f800000u : 0x00003f80u;
+            const int wi = (l15 & 7) >> 1;
+            w.x = wi == 0 ? one : 0u; w.y = wi == 1 ? one : 0u; w.z = wi == 2 ? one : 0u; w.w = wi == 3 ? one : 0u;
+        }
+        sel[h] = *(bf16x8_t*)&w;
+    }
+    bf16_t* dqp = dq + row * ldq2 + hd * 64 + 4 * g;
+    bf16_t* dkp = dk + row * ldk2 + hd * 64 + 4 * g;
+    bf16_t* dvp = dv + row * ldv2 + hd * 64 + 4 * g;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const tb_bf16x4_t kT = tb_trunc4(__builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[m >> 1], sel[m & 1], zero4, 0, 0, 0));
+        const tb_bf16x4_t qT = tb_trunc4(__builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[m >> 1], sel[m & 1], zero4, 0, 0, 0));
+        const tb_bf16x4_t oT = tb_trunc4(__builtin_amdgcn_mfma_f32_16x16x32_bf16(of[m >> 1], sel[m & 1], zero4, 0, 0, 0));
+        const f32x4_t gq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kT, dsT_b, zero4, 0, 0, 0);  // dQ^T[16m + 4g + r][i = l15]
+        const f32x4_t gk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT, ds_b, zero4, 0, 0, 0);   // dK^T[..][j = l15]
+        const f32x4_t gv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(oT, p_b, zero4, 0, 0, 0);    // dV^T[..][j = l15]
+        if (f_ok) {
+            uint2 w;
+            w.x = pack2bf(gq[0], gq[1]); w.y = pack2bf(gq[2], gq[3]);
+            *(uint2*)(dqp + 16 * m) = w;
+            w.x = pack2bf(gk[0], gk[1]); w.y = pack2bf(gk[2], gk[3]);
+            *(uint2*)(dkp + 16 * m) = w;
+            w.x = pack2bf(gv[0], gv[1]); w.y = pack2bf(gv[2], gv[3]);
+            *(uint2*)(dvp + 16 * m) = w;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int t2v_gn_bwd2(const void* x, int xc0, int ldx, const void* x1, int xc1, int ldx1, int n_units, int rows_per_unit,
@@ -488,6 +636,16 @@ extern "C" int t2v_attn_temporal_bwd(const void* q, int ldq, const void* k, int 
                 "t2v_attn_temporal_bwd: bad argument");
     T2V_REQUIRE(frames <= TB_F, T2V_ESHAPE, "t2v_attn_temporal_bwd: at most 16 frames");
     const long long total = (long long)n_clips * hw * heads;
+    T2V_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && ldq2 % 4 == 0 && ldk2 % 4 == 0 && ldv2 % 4 == 0, T2V_ESHAPE,
+                "t2v_attn_temporal_bwd: row strides (16-byte fragment loads, 8-byte stores)");
+    static const bool valu = [] { const char* e = getenv("T2V_TATTN_BWD_VALU"); return e && e[0] == '1'; }();  // the first (VALU / LDS) form, kept for A/B runs
+    if (!valu) {
+        hipLaunchKernelGGL(attn_temporal_bwd_mfma_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q,
+                           ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (const bf16_t*)dout, ldo, dprobs, (bf16_t*)dq, ldq2, (bf16_t*)dk,
+                           ldk2, (bf16_t*)dv, ldv2, total, frames, hw, heads, scale);
+        T2V_CHECK_LAUNCH();
+        return T2V_OK;
+    }
     long long blocks = (total + 1) / 2;
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(attn_temporal_bwd_kernel, dim3((unsigned)blocks), dim3(128), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,

@@ -56,12 +56,16 @@ class BufferPool:
 
     def put(self, *tensors):
         for t in tensors:
-            if t is None:
-                continue
-            nbytes, base = self.live.pop(t.data_ptr())
-            self.free[nbytes].append(base)
-            for side in self.links.pop(t.data_ptr(), ()):
-                self.put(side)
+            if t is not None:
+                self.release_ptr(t.data_ptr())
+
+    def release_ptr(self, ptr):
+        if ptr not in self.live:        # (a linked side buffer may already have gone with its owner)
+            return
+        nbytes, base = self.live.pop(ptr)
+        self.free[nbytes].append(base)
+        for side in self.links.pop(ptr, ()):
+            self.put(side)
 
 
 class Act:

@@ -42,6 +42,29 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
     # spatial self-attention backward by the flash-style kernels of csrc/attention_bwd.hip (probabilities never in memory);
     # T2V_FLASH_ATTN_BWD=0 selects the GEMM-formulated one (both validated on MI355X; 342 -> 320 ms per distillation step)
     flash_attn_bwd = os.environ.get("T2V_FLASH_ATTN_BWD", "1") == "1"
+    # activation checkpointing of the reference (lvdm/common.py:96-112 around ResBlock._forward, openaimodel3d.py:223-254, and
+    # BasicTransformerBlock._forward, attention.py:300-311; yaml ``use_checkpoint: true``): with ``checkpoint_blocks`` every
+    # residual block and every spatial / temporal transformer keeps only its INPUT in the forward and re-runs its forward inside
+    # the backward (the counter-based dropout masks regenerate from (seed, site), so the recomputation is the same function).
+    # Same gradients bit for bit, fewer live activations, one more block forward per block.  Default off: the tape of a
+    # full-size step is 43 GB of 288.  T2V_NATIVE_CHECKPOINT=1 turns it on, =model follows the module's own ``use_checkpoint``
+    # (what the reference's yaml sets), or set the attribute before the first forward.
+    _ckpt_env = os.environ.get("T2V_NATIVE_CHECKPOINT", "0")
+    _ckpt_set = None
+
+    @property
+    def checkpoint_blocks(self):
+        if self._ckpt_set is not None:
+            return self._ckpt_set
+        if self._ckpt_env == "model":
+            return bool(getattr(self.model, "use_checkpoint", False))
+        return self._ckpt_env == "1"
+
+    @checkpoint_blocks.setter
+    def checkpoint_blocks(self, on):
+        if bool(on) != self.checkpoint_blocks:
+            self.plans.clear()                      # recorded launch lists are specific to the mode
+        self._ckpt_set = bool(on)
 
     # ---- public: forward with tape, then backward ----------------------------------------------------------------
     def _active_dropouts(self):
@@ -610,15 +633,74 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         if t.data_ptr() in self.pool.live and t.stride(0) == t.shape[1]:
             self.pool.put(t)
 
+    def checkpointed(self, block_t, layer, h):
+        """``block_t(layer, h)`` (one tape entry) with the reference's checkpoint semantics: see ``checkpoint_blocks``."""
+        if not self.checkpoint_blocks:
+            return block_t(layer, h)
+        pool, n_probs = self.pool, len(self.plan["probs"])
+        if self.training_lora and self._active_dropouts():
+            self.context_per_frame()                # shared by every cross-attention: must not belong to one block
+        live0, refs0 = set(pool.live), dict(self.refs)
+        n_tape, n_sites = len(self.tape), len(self.drop_sites)
+        saved0 = {k: g.saved for k, g in getattr(self, "_groups", {}).items()}
+        y = block_t(layer, h)
+        assert len(self.tape) == n_tape + 1 and self.tape[-1][0] == "block"
+        if len(self.plan["probs"]) != n_probs:
+            raise NotImplementedError("native checkpointing of a block that records attention_probs (record_attn_probs)")
+        del self.tape[n_tape:]
+        # nothing the block kept survives the forward, except its output (the next block's input) ...
+        keep = {p.data_ptr() for p in y.parts}
+        ctx_f = getattr(self, "_ctx_f", None)
+        if ctx_f is not None:
+            keep.add(ctx_f.data_ptr())
+        for ptr in [q for q in pool.live if q not in live0 and q not in keep]:
+            pool.release_ptr(ptr)
+        # ... and what it holds of the tensors that were there before it (its input, the shared text context): those holds stay
+        # until this block's backward has run, exactly as on the tape
+        extra = {q: n - refs0.get(q, 0) for q, n in self.refs.items() if q in live0 and n > refs0.get(q, 0)}
+        self.refs.clear()
+        self.refs.update(refs0)
+        for q, n in extra.items():
+            self.refs[q] = self.refs.get(q, 0) + n
+        for k, g in getattr(self, "_groups", {}).items():
+            if g.saved is not saved0.get(k):
+                g.saved = None
+        sites_fwd = self.drop_sites[n_sites:]
+
+        def bwd(dy):
+            outer_tape, outer_sites = self.tape, self.drop_sites
+            self.tape, self.drop_sites = [], outer_sites[:n_sites]   # the block's dropout sites get the numbers they had
+            y2 = block_t(layer, h)
+            assert [(k, m) for _, k, m in self.drop_sites[n_sites:]] == [(k, m) for _, k, m in sites_fwd]
+            sub, self.tape, self.drop_sites = self.tape, outer_tape, outer_sites
+            for p in y2.parts:                      # the recomputed output itself is not needed
+                if self.refs.get(p.data_ptr(), 0) == 0 and p.data_ptr() in pool.live:
+                    pool.put(p)
+            d = dy
+            for kind, fn in reversed(sub):
+                assert kind == "block"
+                d = fn(d)
+            for q, n in extra.items():              # the first forward's holds (the recomputation took and dropped its own)
+                left = self.refs.get(q, 0) - n
+                if left > 0:
+                    self.refs[q] = left
+                else:
+                    self.refs.pop(q, None)
+                    pool.release_ptr(q)
+            return d
+
+        self.tape.append(("block", bwd))
+        return y
+
     def run_sequential_t(self, seq, h):
         assert isinstance(seq, TimestepEmbedSequential)
         for layer in seq:
             if isinstance(layer, ResBlock):
-                h = self.res_block_t(layer, h)
+                h = self.checkpointed(self.res_block_t, layer, h)
             elif isinstance(layer, SpatialTransformer):
-                h = self.spatial_transformer_t(layer, h)
+                h = self.checkpointed(self.spatial_transformer_t, layer, h)
             elif isinstance(layer, TemporalTransformer):
-                h = self.temporal_transformer_t(layer, h)
+                h = self.checkpointed(self.temporal_transformer_t, layer, h)
             elif isinstance(layer, Downsample):
                 assert layer.use_conv
                 h = self.downsample_t(layer, h)

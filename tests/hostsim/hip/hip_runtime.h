@@ -211,6 +211,21 @@ inline T shfl_xor(T v, int mask) {
     return r;
 }
 
+template <class T>
+inline T shfl_idx(T v, int src) {   // ds_bpermute: every lane reads lane `src`'s value (src may differ per lane)
+    State& s = st();
+    const int me = s.fibers[s.cur].flat, w = me / 64;
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    s.slots[me] = bits;
+    arrive(s.wave_sync[w], alive_in_wave(w));
+    const int partner = w * 64 + (src & 63);
+    T r = v;
+    if (partner < (int)s.fibers.size()) memcpy(&r, &s.slots[partner], sizeof(T));
+    arrive(s.wave_sync[w], alive_in_wave(w));
+    return r;
+}
+
 inline float med3(float a, float b, float c) { return std::max(std::min(a, b), std::min(std::max(a, b), c)); }
 // LDS-DMA (global_load_lds_dwordx{1,4}): every lane copies `size` bytes from ITS global pointer to the wave-uniform LDS base
 // + lane * size (+ offset): the LDS image of one wave instruction is lane-linear.  Synchronous here (the s_waitcnt counters
@@ -373,5 +388,7 @@ inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess
 inline void __syncthreads() { hostsim::arrive(hostsim::st().block_sync, hostsim::alive_in_block()); }
 template <class T>
 inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return hostsim::shfl_xor(v, mask); }
+template <class T>
+inline T __shfl(T v, int src, int width = 64) { (void)width; return hostsim::shfl_idx(v, src); }
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
     hostsim::launch((grid), (block), (size_t)(shmem), [=]() { kern(__VA_ARGS__); })

@@ -345,3 +345,45 @@ def run_trainer_route(dev, emu_factory, loss_tol, cos_min):
     assert abs(float(loss1) - r_loss1) < loss_tol * abs(r_loss1) and abs(float(loss2) - r_loss2) < loss_tol * abs(r_loss2)
     assert c1 > cos_min and c2 > cos_min
     assert c2 - c2_old > 0.03, "step 2 looks like it ran on the parameters of step 1: operand packs not refreshed"
+
+
+# ------------------------------------------------------------------------------------------------------------- a12
+def test_native_checkpointing_on_device_is_the_tape_bit_for_bit():
+    """``checkpoint_blocks`` (the reference's ``use_checkpoint``, lvdm/common.py:96-112 — yaml ``use_checkpoint: true``): each
+    ResBlock / transformer keeps its input only and re-runs its forward inside the backward.  Train mode on the device: the
+    recomputed dropout masks are the forward's, every kernel sees the same operands, so output, d/d(latents), d/d(emb_all) and all
+    LoRA gradients equal the tape's BIT FOR BIT, from a smaller activation pool; replays of the recorded lists stay identical."""
+    from t2v_turbo_amd import lora
+    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+    from t2v_turbo_amd.native import HipOps
+    from tests.golden.make_golden_lora_grad import draw_lora
+    g = load("unet_tiny")
+    x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
+    res = {}
+    for ck in (False, True):
+        m, params = _tiny_student(64, draw_lora)
+        m = m.cuda().train()
+        params = lora.lora_parameters(m)
+        eng = UNetGradEngine(m, HipOps())
+        eng.checkpoint_blocks = ck
+        eng.bind_lora(params)
+        torch.manual_seed(3)                        # the conditioning branch's own dropouts (torch's generator)
+        emb_all = m.conditioning_emb_all(ts.cuda(), 16, tc.cuda()).detach()
+        outs = []
+        for rep in range(3):                        # record, plain replay, replay
+            y = eng.forward_tape(x.cuda(), ts.cuda(), ctx.cuda(), 16, tc.cuda(), None, emb_all=emb_all, seed=4242)
+            flat = torch.zeros(eng.lora_numel, device="cuda")
+            dx = eng.backward(r_out.cuda(), flat_grad=flat, accumulate=False)
+            outs.append((y.clone(), dx.clone(), flat.clone(), eng.d_emb_all.clone()))
+        for o in outs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+        plan = eng._last
+        res[ck] = dict(out=outs[0], pool=eng.pool.bytes, n_fwd=len(plan["rec"]), n_bwd=len(plan["rec_bwd"]))
+    a, b = res[False], res[True]
+    print(f"[checkpoint] activation pool {a['pool'] / 2**20:.1f} MiB (tape) -> {b['pool'] / 2**20:.1f} MiB; launches forward "
+          f"{a['n_fwd']} / {b['n_fwd']}, backward {a['n_bwd']} -> {b['n_bwd']}", flush=True)
+    assert float(a["out"][2].abs().sum()) > 0
+    for ta, tb in zip(a["out"], b["out"]):
+        assert torch.equal(ta, tb)
+    assert b["pool"] < 0.6 * a["pool"] and a["n_fwd"] == b["n_fwd"] and b["n_bwd"] > a["n_bwd"] + 0.8 * a["n_fwd"]

@@ -320,3 +320,41 @@ def test_tn_weight_gradient_variant_of_the_engine():
     assert calls.count("wgrad_tn") > 1000 and calls.count("transpose_pad") < 200   # (what is left: the attention backward's operands)
     assert rel_l2(y, y_ref) < 2e-5 and rel_l2(dx, dx_ref) < 1e-4
     _compare(params, grads, g_ref, m, max_zero=8)
+
+
+def test_native_checkpointing_recomputes_the_same_function():
+    """``checkpoint_blocks`` (the reference's ``use_checkpoint``, lvdm/common.py:96-112): every ResBlock / transformer keeps only
+    its input and re-runs its forward inside the backward.  Train mode (dropout on): the recomputed masks must be the forward's
+    own — output, d/d(latents) and every LoRA gradient are bit-identical to the tape, with a smaller activation pool and exactly
+    one more forward's worth of launches in the backward."""
+    g = load("unet_tiny")
+    x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
+    res = {}
+    for ck in (False, True):
+        m, params = _student("unet_tiny", 64)
+        m.train()
+        eng = UNetGradEngine(m, EmuOps(strict=True))
+        eng.checkpoint_blocks = ck
+        eng.bind_lora(params)
+        torch.manual_seed(3)                        # the conditioning branch's dropouts are torch's: same draw in both runs
+        emb_all = m.conditioning_emb_all(ts, 16, tc, None).detach()
+        y = eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all, seed=77)
+        n_fwd = len(eng.ops.calls)
+        flat = torch.zeros(eng.lora_numel)
+        dx = eng.backward(r_out, flat_grad=flat, accumulate=False)
+        assert not eng.pool.live or all(isinstance(k, int) for k in eng.pool.live)
+        res[ck] = dict(y=y, dx=dx, flat=flat, d_emb=eng.d_emb_all.clone(), pool=eng.pool.bytes, n_fwd=n_fwd,
+                       n_bwd=len(eng.ops.calls) - n_fwd, sites=len(eng.drop_sites), live=len(eng.pool.live))
+        # a second step on the same plan (replayed closures): same numbers again
+        y2 = eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all, seed=77)
+        flat2 = torch.zeros(eng.lora_numel)
+        dx2 = eng.backward(r_out, flat_grad=flat2, accumulate=False)
+        assert torch.equal(y2, y) and torch.equal(dx2, dx) and torch.equal(flat2, flat)
+    a, b = res[False], res[True]
+    assert torch.equal(a["y"], b["y"]) and torch.equal(a["dx"], b["dx"]) and torch.equal(a["flat"], b["flat"])
+    assert torch.equal(a["d_emb"], b["d_emb"])
+    assert float(a["flat"].abs().sum()) > 0 and a["sites"] == b["sites"] > 100
+    assert b["pool"] < 0.6 * a["pool"], (a["pool"], b["pool"])
+    assert a["n_fwd"] == b["n_fwd"] and b["n_bwd"] > a["n_bwd"] + 0.8 * a["n_fwd"]
+    assert a["live"] == b["live"]       # nothing leaks from the discarded first forward of a block

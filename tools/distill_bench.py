@@ -119,7 +119,9 @@ def main():
             eng = UNetGradEngine(student, HipOps())
             flags = set(variant.split("+"))
             eng.flash_attn_bwd, eng.tn_wgrad, eng.use_graph = "flash" in flags, "tn" in flags, "graph" in flags
+            eng.checkpoint_blocks = "ckpt" in flags      # the reference's use_checkpoint: recompute each block in the backward
             eng.bind_lora(params)
+            torch.cuda.reset_peak_memory_stats()
         for _ in range(a.warmup + (2 if variant and "graph" in variant else 0)):  # graphs are captured on the second replay
             loss, _ = step()
             print(f"[rank {rank}] warmup loss {float(loss):.4f} ({time.time() - t0:.1f}s)", file=sys.stderr, flush=True)
@@ -142,7 +144,8 @@ def main():
                               "value": round(world / dt, 4), "unit": "samples/s", "n_gpus": world, "ms_per_step": round(dt * 1e3, 1),
                               "lora_grad_mb": round(sync.numel * 4 / 2 ** 20, 1), "loss": float(loss), "host_ms_last_step": info.get("host_ms"),
                               "teacher_native": teacher._engine_box.engine is not None, "peak_mem_gb":
-                              round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}), flush=True)
+                              round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                              "student_activation_pool_gb": None if eng is None else round(eng.pool.bytes / 2 ** 30, 2)}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
