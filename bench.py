@@ -398,7 +398,11 @@ def distill_step_leg(teacher, dev, world=1, dry=False, parity=True):
            "finite": bool(torch.isfinite(sync.flat).all() and torch.isfinite(opt.flat_param).all()),
            "lora_params_m": round(sync.numel / 1e6, 1), "student": "native gradient engine (flash attention backward, token-contracted "
            "weight gradients), train mode", "teacher": "2 forwards on the inference engine",
-           "grad_exchange": ("one all-reduce(mean) of the flat fp32 LoRA gradient buffer, %.1f MB, backend %s"
+           "grad_exchange": ("gradient arena all-reduced in %d segments from inside the backward (%.1f MB fp32, backend %s) + the "
+                             "conditioning branch's tensors after it; allreduce_ms = ONE blocking all-reduce of the whole flat "
+                             "buffer, timed separately, for scale" % (len(eng._handles), eng.e_used * 4 / 2 ** 20, dist.get_backend())
+                             if getattr(eng, "_handles", None) else
+                             "one all-reduce(mean) of the flat fp32 LoRA gradient buffer, %.1f MB, backend %s"
                              % (sync.numel * 4 / 2 ** 20, dist.get_backend())) if world > 1 else "none (1 rank)",
            "allreduce_ms": None if ar_ms is None else round(ar_ms, 3),
            "launches": {"student_forward": len(plan["rec"]), "student_backward": len(plan["rec_bwd"])} if "rec" in plan else None,

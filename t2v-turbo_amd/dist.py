@@ -52,13 +52,30 @@ class FlatGradSync:
             p._t2v_flat_sync = self   # the native student writes its weight gradients straight into this buffer (unet3d._flat_grad_buffer)
             off += p.numel()
         self.numel = n
+        self.force = False        # True: the native engine exchanges its gradients even in a one-rank group (RCCL smoke tests)
+        self._rest_idx = None
 
     def zero_(self):
         self.flat.zero_()
+        self._rest_idx = None
+
+    def mark_engine_reduced(self, rest_idx):
+        """The native gradient engine has written ALREADY AVERAGED gradients for its tensors (it all-reduces its gradient arena
+        in segments while the backward runs: engine_lora); what is left for ``all_reduce_mean`` are the flat positions
+        ``rest_idx`` (int64) — the conditioning branch's tensors, which torch differentiates after the engine's backward."""
+        self._rest_idx = rest_idx
 
     def all_reduce_mean(self, async_op=False, force=False):
         """``force``: run the collective even in a one-rank group (smoke tests of the RCCL path)."""
-        if not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        rest, self._rest_idx = self._rest_idx, None
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not (force or self.force)):
+            return None
+        if rest is not None:
+            if rest.numel():
+                buf = self.flat.index_select(0, rest)
+                buf.div_(dist.get_world_size())
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                self.flat.index_copy_(0, rest, buf)
             return None
         self.flat.div_(dist.get_world_size())
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)

@@ -168,7 +168,7 @@ def distill_step(unet, teacher_unet, solver, noise_scheduler, latents, prompt_em
         if eng is not None:
             # native student backward: token-row LoRA gradients straight into the flat buffer (added to what the reward /
             # conditioning branch put there), then the B-row conditioning branch through torch
-            eng.backward(noise_pred.grad, flat_grad=grad_sync.flat, accumulate=True)
+            eng.backward(noise_pred.grad, flat_grad=grad_sync.flat, accumulate=True, grad_sync=grad_sync)
             emb_all.backward(eng.d_emb_all.to(emb_all.dtype))
         _mark("backward")
         if grad_sync is not None:

@@ -34,6 +34,8 @@ from . import native as nt
 from .engine import is_lora_leaf
 
 RP = 64  # rank granularity: K of a GEMM is a multiple of 64
+# the gradient arena is all-reduced in this many pieces while the backward is still running (dist.FlatGradSync, N > 1)
+ALLREDUCE_SEGMENTS = max(1, int(os.environ.get("T2V_ALLREDUCE_SEGMENTS", "8")))
 
 
 def _pad(n, m):
@@ -240,6 +242,7 @@ class LoraTrainMixin:
         g.rp = rp = _pad(r0, RP)
         g.cin = cin = mods[0].lora_down.weight.shape[1]
         g.ce = ce = _pad(cin, 64)
+        g.e_lo = self.e_used
         e_d_off, g.ED = self._e_alloc((g.n if taps == 1 else taps) * rp, ce)
         for i, mod in enumerate(mods):
             down, up = mod.lora_down.weight, mod.lora_up.weight
@@ -293,6 +296,7 @@ class LoraTrainMixin:
         else:
             g.Db = self._lp_alloc(torch.cat(db_cols, dim=1))
         g.ntot = sum(g.N)
+        g.e_hi = self.e_used
         self._groups[key] = g
         return g
 
@@ -412,6 +416,7 @@ class LoraTrainMixin:
                 c0 += c
             self.drop(*x.parts)
             grp.saved = None
+            self._group_finished(grp)
             return
         GT = self.tposed(G, m_in, G.shape[1])
         c0 = 0
@@ -424,8 +429,63 @@ class LoraTrainMixin:
         self.pool.put(GT)
         self.drop(*x.parts)
         grp.saved = None
+        self._group_finished(grp)
 
-    def lora_grads_into(self, flat_grad, accumulate=True):
+    def lora_grads_into(self, flat_grad, accumulate=True, alpha=1.0):
         """E arena -> flat gradient buffer in parameter layout (one launch).  Conditioning-branch tensors are not touched
         when accumulating (their gradient comes from torch), and zeroed otherwise."""
-        self.ops.gather(self.E, self.g_idx, flat_grad, accumulate=accumulate)
+        self.ops.gather(self.E, self.g_idx, flat_grad, alpha=alpha, accumulate=accumulate)
+
+    # ---- gradient exchange overlapped with the backward (train_t2v_turbo_v1_lora.py:1190 under DDP: buckets reduced as they fill) ---
+    # The weight gradients land in the arena E in GEMM output layout, groups in forward order, and the backward completes them from
+    # the top of the arena down.  The arena layout is the same on every rank, so it is all-reduced AS IT IS, in ALLREDUCE_SEGMENTS
+    # contiguous pieces, each as soon as every group that touches it has its dU and dD: the recorded backward list carries a marker
+    # entry per piece (a host call between two launches) that issues ``all_reduce(E[lo:hi], async_op=True)`` — the process group
+    # orders it after the launches enqueued so far and runs it on its own stream.  ``backward`` waits for the handles and the ONE
+    # gather launch that re-lays E into parameter order applies the 1 / world factor.  The conditioning branch's few tensors
+    # (torch autograd, after the engine's backward) are reduced by ``FlatGradSync.all_reduce_mean`` as a subset.
+    _overlap = None
+
+    def _seg_bounds(self):
+        k = ALLREDUCE_SEGMENTS
+        return [0 if i == 0 else self.e_used if i == k else (self.e_used * i // k) // 1024 * 1024 for i in range(k + 1)]
+
+    def _seg_reset(self):
+        self._seg_done, self._seg_emitted = set(), 0
+        self._seg_order = sorted(self._groups.values(), key=lambda g: -g.e_lo)
+
+    def _group_finished(self, grp):
+        if getattr(self, "_seg_done", None) is None:
+            return
+        self._seg_done.add(id(grp))
+        tail = self.e_used
+        for g in self._seg_order:       # the arena is complete from `tail` up once every group allocated above it is done
+            if id(g) not in self._seg_done:
+                break
+            tail = g.e_lo
+        self._seg_emit_down_to(tail)
+
+    def _seg_emit_down_to(self, tail):
+        k, b = ALLREDUCE_SEGMENTS, self._seg_bounds()
+        while self._seg_emitted < k and b[k - 1 - self._seg_emitted] >= tail:
+            j = k - 1 - self._seg_emitted
+            self._seg_emitted += 1
+            self._segment_hook(j, b[j], b[j + 1])
+            rec = getattr(self.ops, "record_host_call", None)
+            if rec is not None:         # replayed between the launches on either side of it
+                rec(self._segment_hook, (j, b[j], b[j + 1]), "allreduce_segment")
+
+    def _segment_hook(self, j, lo, hi, stream=None):
+        if self._overlap is not None and hi > lo:
+            import torch.distributed as dist
+            self._handles.append(dist.all_reduce(self.E[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        return 0
+
+    def conditioning_index(self):
+        """int64 positions (flat-buffer order) of the LoRA tensors whose gradients torch computes (the B-row conditioning branch)."""
+        idx = getattr(self, "_cond_idx", None)
+        if idx is None or idx[0] is not self.lora_params:
+            parts = [torch.arange(self.lora_off[id(p)], self.lora_off[id(p)] + p.numel()) for p in self.conditioning_parameters()]
+            t = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64)
+            self._cond_idx = idx = (self.lora_params, t.to(self.E.device))
+        return idx[1]

@@ -134,15 +134,19 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         self._publish_probs(plan)
         return plan["out"].clone()
 
-    def backward(self, dout=None, dprobs=None, flat_grad=None, accumulate=True):
+    def backward(self, dout=None, dprobs=None, flat_grad=None, accumulate=True, grad_sync=None):
         """d(loss)/dx for the most recent ``forward_tape``.  ``dout``: gradient w.r.t. the output (or None = 0);
         ``dprobs``: {attention module: gradient w.r.t. its ``attention_probs``} for any of the recorded layers.
         LoRA training: the weight gradients land in ``flat_grad`` (fp32, ``bind_lora`` order; added to what is there
-        when ``accumulate``) and ``self.d_emb_all`` holds d(loss)/d(emb_all) for the caller's torch branch."""
+        when ``accumulate``) and ``self.d_emb_all`` holds d(loss)/d(emb_all) for the caller's torch branch.
+        ``grad_sync``: the ``dist.FlatGradSync`` that owns ``flat_grad``.  In a multi-rank job the engine then all-reduces its
+        gradient arena in segments WHILE the backward runs (engine_lora: "gradient exchange overlapped with the backward") and
+        hands over already averaged gradients; ``grad_sync.all_reduce_mean()`` afterwards only exchanges the conditioning
+        branch's tensors.  T2V_ASYNC_ALLREDUCE=0 keeps the single blocking all-reduce after the backward."""
         plan = self._last
         if plan["out"].is_cuda and plan["out"].device.index != torch.cuda.current_device():
             with torch.cuda.device(plan["out"].device):
-                return self.backward(dout, dprobs, flat_grad, accumulate)
+                return self.backward(dout, dprobs, flat_grad, accumulate, grad_sync)
         if plan.get("bwd_id") == plan["fwd_id"]:
             raise RuntimeError("UNet gradient: backward was already run for this forward (its saved activations are gone)")
         plan["bwd_id"] = plan["fwd_id"]
@@ -157,13 +161,39 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             buf = plan["dprobs"][id(attn)]
             g = dprobs.get(attn)
             buf.zero_() if g is None else buf.copy_(g)
-        self._replay(plan, "rec_bwd")
+        world = self._overlap_world(grad_sync, flat_grad)
+        self._overlap, self._handles = (grad_sync if world else None), []
+        try:
+            self._replay(plan, "rec_bwd")
+        finally:
+            self._overlap = None
         if self.training_lora:
             self.d_emb_all = plan["d_emb"]
             if flat_grad is not None:
                 assert flat_grad.dtype == torch.float32 and flat_grad.numel() == self.lora_numel and flat_grad.is_contiguous()
-                self.lora_grads_into(flat_grad, accumulate)
+                if world:
+                    assert self._handles, "overlapped gradient exchange: the backward list carries no segment markers"
+                    for h in self._handles:
+                        h.wait()
+                    self.lora_grads_into(flat_grad, accumulate, alpha=1.0 / world)
+                    grad_sync.mark_engine_reduced(self.conditioning_index())
+                else:
+                    self.lora_grads_into(flat_grad, accumulate)
         return plan["dx"].clone()
+
+    def _overlap_world(self, grad_sync, flat_grad):
+        """World size when this backward should exchange its gradient arena itself, else 0."""
+        if grad_sync is None or flat_grad is None or not self.training_lora or os.environ.get("T2V_ASYNC_ALLREDUCE", "1") == "0":
+            return 0
+        import torch.distributed as dist
+        if not dist.is_initialized() or grad_sync.flat.data_ptr() != flat_grad.data_ptr():
+            return 0
+        world = dist.get_world_size()
+        if world == 1 and not getattr(grad_sync, "force", False):
+            return 0
+        if self.use_graph:   # a captured list cannot carry the host-side markers
+            return 0
+        return world
 
     def _replay(self, plan, which):
         """Replay one of the two recorded launch lists; with ``use_graph`` (T2V_HIP_GRAPH=1) each list is captured into its own
@@ -609,6 +639,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         return self._ctx_f
 
     def _backward_tape(self, dout, dx_out):
+        if self.training_lora:
+            self._seg_reset()
         d = self.exit_bwd(dout)
         skip_grads = []  # gradients of the skip tensors, in the order the output blocks produced them
         for kind, fn in reversed(self.tape):
@@ -627,6 +659,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             else:
                 d = fn(d)
         self.entry_bwd(d, dx_out)
+        if self.training_lora:
+            self._seg_emit_down_to(0)   # whatever is left of the arena (and every piece, if some group never finished)
 
     def _free_view(self, t):
         """Release a gradient tensor unless it is a column slice of a concat-gradient buffer (freed with the buffer)."""

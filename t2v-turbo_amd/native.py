@@ -274,6 +274,12 @@ class HipOps:
             if keep is not None:
                 self._keep.append(keep)
 
+    def record_host_call(self, fn, args, name):
+        """A host-side entry of a recorded list: ``fn(*args, stream)`` (returning 0) runs between the launches on either side
+        of it on every replay (the gradient engine's all-reduce markers).  Not capturable into a hipGraph as anything but a no-op."""
+        if self.recording is not None:
+            self.recording.append((fn, args, name))
+
     @staticmethod
     def replay(recording, stream):
         for fn, args, name in recording:

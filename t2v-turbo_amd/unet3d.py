@@ -367,7 +367,7 @@ def _warn_aten_route(why):
 
 
 def _flat_grad_buffer(eng, leaves):
-    """The flat fp32 gradient buffer of a ``dist.FlatGradSync`` whose slots ARE the LoRA tensors' ``.grad`` (same order and
+    """The ``dist.FlatGradSync`` whose flat fp32 buffer's slots ARE the LoRA tensors' ``.grad`` (same order and
     offsets as ``bind_lora``), or None.  Only a buffer that announced itself (``FlatGradSync`` tags its parameters) is taken:
     writing into ``.grad`` bypasses AccumulateGrad, so a look-alike layout owned by somebody else — DDP's
     ``gradient_as_bucket_view`` bucket, accelerate's reducer — or any parameter with gradient hooks gets its gradients
@@ -383,7 +383,7 @@ def _flat_grad_buffer(eng, leaves):
             return None
         if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
             return None
-    return sync.flat
+    return sync
 
 
 class _NativeStudent(torch.autograd.Function):
@@ -408,11 +408,11 @@ class _NativeStudent(torch.autograd.Function):
             raise RuntimeError("native student: another grad-mode forward of the same shape ran before this backward "
                                "(the engine keeps one outstanding tape per input shape)")
         eng._last = ctx.plan
-        flat = _flat_grad_buffer(eng, ctx.leaves)
-        if flat is not None:
+        sync = _flat_grad_buffer(eng, ctx.leaves)
+        if sync is not None:
             # every LoRA tensor's .grad is already its slot of ONE flat fp32 buffer in bind_lora order (dist.FlatGradSync): the engine
             # adds its weight gradients there in one launch — what 1096 AccumulateGrad nodes would do with 1096 small kernels
-            dx = eng.backward(dout, flat_grad=flat, accumulate=True)
+            dx = eng.backward(dout, flat_grad=sync.flat, accumulate=True, grad_sync=sync)
             return (dx.to(ctx.x_dtype), eng.d_emb_all.to(ctx.e_dtype).clone(), None, None, *([None] * len(ctx.leaves)))
         flat = torch.empty(eng.lora_numel, dtype=torch.float32, device=dout.device)  # fresh: .grad may keep views of it
         dx = eng.backward(dout, flat_grad=flat, accumulate=False)

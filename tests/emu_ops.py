@@ -559,6 +559,10 @@ class ReplayOps:
         for fn, a, k in recording:
             fn(*a, **k)
 
+    def record_host_call(self, fn, args, name):
+        if self.recording is not None:
+            self.recording.append((fn, args, {}))
+
     def __getattr__(self, name):
         fn = getattr(self.inner, name)
         if name in self._PURE or not callable(fn):

@@ -49,8 +49,8 @@ def _loss(m, i, l2=False):
     return cd_math.huber_loss(pred, target)
 
 
-def _worker(rank, world, port, out, native=False):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+def _worker(rank, world, port, out, native=False, overlap="1"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), T2V_ASYNC_ALLREDUCE=overlap)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
     m = _student()
@@ -61,16 +61,21 @@ def _worker(rank, world, port, out, native=False):
     sync = FlatGradSync(lora.lora_parameters(m))
     sync.zero_()
     if native:  # the student's forward / backward on the native gradient engine's dataflow (emulated ops), one engine per rank
-        from tests.emu_ops import EmuOps
-        m._native_ops_factory = lambda: EmuOps(strict=True)
+        from tests.emu_ops import ReplayOps   # the record / replay protocol of the native backend: the all-reduce markers are
+        m._native_ops_factory = ReplayOps     # entries of the recorded backward list, re-issued between its launches
         m.native_mode = "train"
     loss = _loss(m, rank, l2=native)
     loss.backward()
+    info = {}
+    if native:   # did the engine exchange its gradient arena itself, in how many pieces, and what did it leave for all_reduce_mean?
+        eng = m.native_train_engine()
+        info = {"segments": len(eng._handles), "rest": None if sync._rest_idx is None else int(sync._rest_idx.numel()),
+                "cond": sum(p.numel() for p in eng.conditioning_parameters()), "arena": int(eng.e_used)}
     sync.all_reduce_mean()
     norm = sync.clip_grad_norm_(1e9)
     losses = gather_scalars(loss, loss * 2, loss * 0)
     if rank == 0:
-        torch.save({"flat": sync.flat.clone(), "norm": norm, "losses": losses}, out)
+        torch.save({"flat": sync.flat.clone(), "norm": norm, "losses": losses, "info": info}, out)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -105,3 +110,13 @@ def test_two_rank_native_student_allreduce_matches_single_process(tmp_path):
     ref = torch.cat([p.grad.reshape(-1) for p in params])
     assert float((got["flat"] - ref).norm() / ref.norm()) < 2e-4
     assert abs(float(got["losses"][0, 0]) - float(l0)) < 1e-5 and abs(float(got["losses"][1, 0]) - float(l1)) < 1e-5
+    # the exchange was the overlapped one: the gradient arena all-reduced in segments from inside the backward, the conditioning
+    # branch's tensors (and only those) left for all_reduce_mean
+    info = got["info"]
+    assert 2 <= info["segments"] <= 8 and info["rest"] == info["cond"] > 0, info
+    # ... and it hands over what the single blocking all-reduce after the backward does
+    out2 = str(tmp_path / "r0_blocking.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out2, True, "0"), nprocs=2, join=True)
+    got2 = torch.load(out2)
+    assert got2["info"]["segments"] == 0 and got2["info"]["rest"] is None
+    assert float((got["flat"] - got2["flat"]).norm() / got2["flat"].norm()) < 1e-6

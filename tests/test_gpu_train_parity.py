@@ -387,3 +387,58 @@ def test_native_checkpointing_on_device_is_the_tape_bit_for_bit():
     for ta, tb in zip(a["out"], b["out"]):
         assert torch.equal(ta, tb)
     assert b["pool"] < 0.6 * a["pool"] and a["n_fwd"] == b["n_fwd"] and b["n_bwd"] > a["n_bwd"] + 0.8 * a["n_fwd"]
+
+
+# ------------------------------------------------------------------------------------------------------------- (e)
+def test_overlapped_gradient_exchange_over_rccl_one_rank():
+    """The multi-rank exchange of the training step as the device runs it (train_t2v_turbo_v1_lora.py:1190 under DDP): the recorded
+    backward list carries marker entries that all-reduce the gradient arena in segments over RCCL while later launches are still
+    being issued; the gather into parameter order applies 1 / world; the conditioning branch's tensors go through
+    ``FlatGradSync.all_reduce_mean`` as a subset.  One GPU per box, so: a one-rank ``nccl`` communicator with ``sync.force`` — the
+    collectives really run on RCCL's stream between the engine's launches, and must hand over exactly the gradients of the plain
+    path (a 1-rank sum is the identity: bit-identical), step after step (replays of the recorded list)."""
+    import torch.distributed as dist
+    from t2v_turbo_amd import dist as tdist, lora
+    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+    from t2v_turbo_amd.native import HipOps
+    from tests.golden.make_golden_lora_grad import draw_lora
+    g = load("unet_tiny")
+    x, ts, ctx, tc = (g[k].cuda() for k in ("x", "ts", "ctx", "tc"))
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5)).cuda()
+    m, _ = _tiny_student(64, draw_lora)
+    m = m.cuda()
+    params = lora.lora_parameters(m)
+    sync = tdist.FlatGradSync(params)
+    eng = UNetGradEngine(m, HipOps())
+    eng.bind_lora(params)
+
+    def step(use_sync):
+        sync.zero_()
+        emb_all = m.conditioning_emb_all(ts, 16, tc)
+        eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all)
+        dx = eng.backward(r_out, flat_grad=sync.flat, accumulate=True, grad_sync=sync if use_sync else None)
+        emb_all.backward(eng.d_emb_all)
+        rest = sync._rest_idx
+        sync.all_reduce_mean()
+        torch.cuda.synchronize()
+        return dx.clone(), sync.flat.clone(), rest
+
+    dx0, flat0, rest0 = step(False)
+    assert rest0 is None and float(flat0.abs().sum()) > 0
+    assert not dist.is_initialized()
+    tdist.init_distributed("nccl", single_process_group=True)
+    try:
+        sync.force = True
+        for rep in range(3):
+            dx1, flat1, rest1 = step(True)
+            assert len(eng._handles) == 8, len(eng._handles)
+            assert rest1 is not None and rest1.numel() == sum(p.numel() for p in eng.conditioning_parameters()) > 0
+            assert torch.equal(dx1, dx0) and torch.equal(flat1, flat0), rep
+        markers = [e for e in eng._last["rec_bwd"] if e[2] == "allreduce_segment"]
+        assert len(markers) == 8
+        pos = [i for i, e in enumerate(eng._last["rec_bwd"]) if e[2] == "allreduce_segment"]
+        print(f"[overlap] 8 segment markers at launch {pos} of {len(eng._last['rec_bwd'])}", flush=True)
+        assert pos[0] < 0.5 * len(eng._last["rec_bwd"])     # the first piece leaves long before the backward ends
+    finally:
+        sync.force = False
+        dist.destroy_process_group()
