@@ -200,6 +200,11 @@ long long t2v_group_norm_cs_ws_floats(int n_units, int rows_per_unit, int groups
 int t2v_group_norm_cs(const float* cs0, const float* cs1, const void* x0, int c0, int ld0, const void* x1, int c1, int ld1,
                       int n_units, int rows_per_unit, int groups, float eps, const float* gamma, const float* beta, int silu,
                       float* ws, void* out, int ldo, const void* prefetch, long long prefetch_bytes, void* stream);
+/* (mean, rstd) per (unit, group) — the `stats` of t2v_gn_stats — from the column statistics alone: the training engine keeps them
+ * for the GroupNorm backward and normalises with t2v_gn_apply (openaimodel3d.py:223-254 under autograd).  cs1 / c1: second part of
+ * a virtual concat (NULL / 0: none).  ws: t2v_group_norm_cs_ws_floats floats. */
+int t2v_gn_stats_cs(const float* cs0, int c0, const float* cs1, int c1, int n_units, int rows_per_unit, int groups, float eps,
+                    float* ws, float* stats, void* stream);
 
 /* LayerNorm over the channel dim, eps, affine; bf16 in/out (attention.py:279-281). */
 int t2v_layernorm(const void* x, int ldx, int M, int C, const float* gamma, const float* beta,

@@ -816,6 +816,31 @@ extern "C" int t2v_group_norm_cs(const float* cs0, const float* cs1, const void*
     return T2V_OK;
 }
 
+// (mean, rstd) per (unit, group) from the column statistics of the producing GEMMs — t2v_gn_stats without reading the tensor
+// (the training engine keeps the statistics for the backward and normalises with t2v_gn_apply).  ws: t2v_group_norm_cs_ws_floats.
+extern "C" int t2v_gn_stats_cs(const float* cs0, int c0, const float* cs1, int c1, int n_units, int rows_per_unit, int groups,
+                               float eps, float* ws, float* stats, void* stream) {
+    T2V_REQUIRE(cs0 && ws && stats && n_units > 0 && rows_per_unit > 0 && groups > 0 && groups <= 128 && c0 > 0, T2V_EINVAL,
+                "t2v_gn_stats_cs: bad argument");
+    if (!cs1) c1 = 0;
+    const int C = c0 + c1;
+    T2V_REQUIRE(rows_per_unit % 32 == 0 && C % groups == 0 && C <= 4096, T2V_ESHAPE,
+                "t2v_gn_stats_cs: rows_per_unit must be a multiple of the 32-row statistics slab, channels a multiple of the groups");
+    T2V_REQUIRE((uintptr_t)cs0 % 8 == 0 && (!cs1 || (uintptr_t)cs1 % 8 == 0), T2V_ESHAPE, "t2v_gn_stats_cs: unaligned statistics");
+    hipStream_t s = (hipStream_t)stream;
+    const int slabs_per_unit = rows_per_unit / 32;
+    const int slabs_per_blk = (slabs_per_unit + GN_CS_BLOCKS - 1) / GN_CS_BLOCKS;
+    const int nblk = (slabs_per_unit + slabs_per_blk - 1) / slabs_per_blk;
+    const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / groups));
+    hipLaunchKernelGGL(gn_partial_cs_kernel, dim3(nblk, n_units), dim3(256), (size_t)2 * C * sizeof(float), s, cs0, c0, cs1, c1,
+                       slabs_per_unit, slabs_per_blk, groups, ws);
+    T2V_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gn_final_kernel, dim3(n_units), dim3(1024), 0, s, (const float*)ws, nblk, groups, C, inv_count, eps,
+                       (const float*)nullptr, (const float*)nullptr, stats, (float*)nullptr);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+
 extern "C" int t2v_layernorm(const void* x, int ldx, int M, int C, const float* gamma, const float* beta, float eps,
                              void* out, int ldo, void* stream) {
     T2V_REQUIRE(x && gamma && beta && out && M > 0, T2V_EINVAL, "t2v_layernorm: bad argument");

@@ -66,6 +66,13 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             self.plans.clear()                      # recorded launch lists are specific to the mode
         self._ckpt_set = bool(on)
 
+    def __init__(self, model, ops):
+        super().__init__(model, ops)
+        # GroupNorm statistics of the forward from the producing GEMMs' epilogues (t2v_gemm colstat_out -> t2v_gn_stats_cs), as on
+        # the inference engine; the tape keeps (mean, rstd) for the backward either way.  T2V_FUSE_GN_TRAIN=0: statistics pass
+        # over the tensor (t2v_gn_stats).
+        self.fuse_gn = os.environ.get("T2V_FUSE_GN_TRAIN", "1") == "1"
+
     # ---- public: forward with tape, then backward ----------------------------------------------------------------
     def _active_dropouts(self):
         """Number of active Dropout(p > 0) modules; in LoRA training they must all be ones the engine (or torch's conditioning
@@ -300,9 +307,14 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         """GroupNorm(+SiLU) of an Act keeping (mean, rstd); the caller keeps x for the backward."""
         ops = self.ops
         G = norm.num_groups
-        ws = self.buf(1, max(ops.gn_ws_floats(units, rows, G), 1), torch.float32)
         stats = self.buf(units, G * 2, torch.float32)
-        ops.gn_stats(x.parts[0], x.p1, units, rows, norm.eps, ws, stats, G)
+        if self.fuse_gn and all(c is not None for c in x.cs) and rows % 32 == 0:
+            ws = self.buf(1, max(ops.group_norm_cs_ws_floats(units, rows, G), 1), torch.float32)
+            ops.gn_stats_cs(x.cs[0], x.cs[1] if len(x.cs) > 1 else None, x.parts[0].shape[1],
+                            x.parts[1].shape[1] if len(x.parts) > 1 else 0, units, rows, norm.eps, ws, stats, G)
+        else:
+            ws = self.buf(1, max(ops.gn_ws_floats(units, rows, G), 1), torch.float32)
+            ops.gn_stats(x.parts[0], x.p1, units, rows, norm.eps, ws, stats, G)
         out = self.buf(x.M, x.C)
         ops.gn_apply(x.parts[0], x.p1, units, rows, stats, self.pk.f32(norm.weight), self.pk.f32(norm.bias), silu, out, G)
         self.pool.put(ws)
@@ -352,7 +364,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
 
     # ---- leaves: forward with the LoRA branch (training), backward with the LoRA weight gradients -----------------------
     def linear(self, a, mod, *, residual=None, act=nt.ACT_NONE, out_dtype=None, w=None, bias="auto", N=None, lora=None, perm=None,
-               conv_geom=None):
+               conv_geom=None, want_cs=False):
         """``a``: tensor or two-part Act.  ``lora``: the injected leaves whose row-concatenated weights ``w`` holds (default:
         [mod]); ``perm``: packed output row j = original row perm[j] (GEGLU packing)."""
         x = a if isinstance(a, Act) else Act(a, 0, 0, 0)
@@ -369,7 +381,11 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         bias = self.pk.bias(mod) if isinstance(bias, str) else bias
         N = w.shape[0] if N is None else N
         out = self.buf(x.M, N // 2 if act == nt.ACT_GEGLU else N, out_dtype)
-        self.ops.gemm(x.parts[0], w, out, M=x.M, N=N, a1=x.p1, bias=bias, residual=residual, act=act)
+        kw = dict(M=x.M, N=N, a1=x.p1, bias=bias, residual=residual, act=act)
+        self.last_cs = self._colstat_for(x.parts[0], w, out, **kw) if want_cs else None   # (for the GroupNorm of the next block)
+        if self.last_cs is not None:
+            kw["colstat"] = self.last_cs
+        self.ops.gemm(x.parts[0], w, out, **kw)
         if zf is not None:
             self.pool.put(zf)
         return out
@@ -385,7 +401,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 ho, wo = x.h, x.w
             zf, residual = self.lora_z(self.lgroup([mod], mode), x, x.n_img * ho * wo, residual, frames, kind_meta=(x.n_img, ho, wo))
         y = super().conv(x, mod, mode, frames=frames, rowvec=rowvec, rowvec_div=rowvec_div, residual=residual,
-                         out_dtype=out_dtype, w=w, bias=bias)
+                         out_dtype=out_dtype, w=w, bias=bias, want_cs=w is None)   # (data-gradient convs pass their own pack: no statistics)
         if zf is not None:
             self.pool.put(zf)
         return y
@@ -506,7 +522,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             skip = hs.pop()
             # (reverse order!) once the block below is walked back, its input gradient [M, c(h) + c(skip)] splits in two
             self.tape.append(("split", h.C))
-            h = self.run_sequential_t(block, Act([h.t, skip.t], h.n_img, h.h, h.w))
+            h = self.run_sequential_t(block, Act([h.t, skip.t], h.n_img, h.h, h.w, cs=[h.cs[0], skip.cs[0]]))
         xin = h
         self.hold(xin.t)
         tt, st_out = self.gn_t(xin, m.out[0], B * F, H * W, True)
@@ -684,6 +700,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         del self.tape[n_tape:]
         # nothing the block kept survives the forward, except its output (the next block's input) ...
         keep = {p.data_ptr() for p in y.parts}
+        for q in list(keep):                        # (with the column statistics its producing GEMM wrote next to it)
+            keep.update(side.data_ptr() for side in pool.links.get(q, ()))
         ctx_f = getattr(self, "_ctx_f", None)
         if ctx_f is not None:
             keep.add(ctx_f.data_ptr())
@@ -879,7 +897,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         for blk in tr.transformer_blocks:
             y, b = self.transformer_block_t(blk, y, (n, hw), temporal)
             blocks.append(b)
-        out = self.linear(y, tr.proj_out, residual=x.t)
+        out = self.linear(y, tr.proj_out, residual=x.t, want_cs=True)
+        out_cs = self.last_cs
         self.rel(y)
         geom = (n, x.h, x.w)
 
@@ -896,7 +915,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             return Act(dx, *geom)
 
         self.tape.append(("block", bwd))
-        return Act(out, *geom)
+        return Act(out, *geom, cs=[out_cs])
 
     def transformer_block_t(self, blk, y, x_geom, temporal):
         """-> (output rows, backward closure: d(output) tensor -> d(input) tensor).  The block's input y stays alive

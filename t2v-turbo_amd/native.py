@@ -74,6 +74,8 @@ _SIGS = {
                                  C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong,
                                  C.c_void_p]),
     "t2v_group_norm_cs_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
+    "t2v_gn_stats_cs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     "t2v_group_norm_cs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                     C.c_longlong, C.c_void_p]),
@@ -405,6 +407,10 @@ class HipOps:
                    0 if x1 is None else x1.shape[1], 0 if x1 is None else _row_stride(x1),
                    n_units, rows_per_unit, groups, eps, _p(gamma), _p(beta), int(silu), _p(ws), _p(out), _row_stride(out),
                    *self._pf(prefetch))
+
+    def gn_stats_cs(self, cs0, cs1, c0, c1, n_units, rows_per_unit, eps, ws, stats, groups=32):
+        """``gn_stats`` from the producers' column statistics (cs [rows / 32, C, 2] per part) instead of the tensor."""
+        self._call("t2v_gn_stats_cs", _p(cs0), c0, _p(cs1), c1 if cs1 is not None else 0, n_units, rows_per_unit, groups, eps, _p(ws), _p(stats))
 
     def layernorm(self, x, gamma, beta, eps, out):
         self._call("t2v_layernorm", _p(x), _row_stride(x), x.shape[0], x.shape[1], _p(gamma), _p(beta), eps, _p(out),

@@ -250,6 +250,21 @@ class EmuOps:
         self.gn_apply(x0, x1, n_units, rows_per_unit, stats, gamma, beta, silu, out, groups)
         self.calls.pop()   # (one logical op)
 
+    def gn_stats_cs(self, cs0, cs1, c0, c1, n_units, rows_per_unit, eps, ws, stats, groups=32):
+        """(mean, rstd) per (unit, group) from the producers' column statistics."""
+        self._log("gn_stats_cs")
+        assert rows_per_unit % 32 == 0
+        cs = cs0.float().view(-1, c0, 2)
+        if cs1 is not None:
+            cs = torch.cat([cs, cs1.float().view(-1, c1, 2)], dim=1)
+        C = cs.shape[1]
+        assert cs.shape[0] == n_units * rows_per_unit // 32
+        sums = cs.view(n_units, rows_per_unit // 32, groups, C // groups, 2).sum(dim=(1, 3))
+        cnt = rows_per_unit * (C // groups)
+        mean = sums[:, :, 0] / cnt
+        var = (sums[:, :, 1] / cnt - mean * mean).clamp_min(0.0)
+        stats.copy_(torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=2).reshape(stats.shape))
+
     # ------------------------------------------------------------------------------------ backward pieces
     def gn_bwd_ws_floats(self, n_units, rows_per_unit, groups=32):
         return 8

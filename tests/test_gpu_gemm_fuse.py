@@ -154,6 +154,14 @@ def test_group_norm_from_column_statistics(hip, c0, c1, units, rows, silu):
                       gamma.cuda(), beta.cuda(), silu, ws, out2)
     torch.cuda.synchronize()
     assert torch.equal(out2, out_h)
+    # t2v_gn_stats_cs: (mean, rstd) per (unit, group) for the training engine's backward, from the same column statistics
+    st_h = torch.full((units, 64), float("nan"), device="cuda")
+    st_t = torch.zeros(units, 64, device="cuda")
+    hip.gn_stats_cs(cs0.cuda(), None if cs1 is None else cs1.cuda(), c0, c1, units, rows, 1e-5, ws, st_h)
+    ws2 = torch.zeros(max(hip.gn_ws_floats(units, rows, 32), 1), device="cuda")
+    hip.gn_stats(x0.cuda(), None if x1 is None else x1.cuda(), units, rows, 1e-5, ws2, st_t)
+    torch.cuda.synchronize()
+    assert torch.isfinite(st_h).all() and rel_l2(st_h.cpu(), st_t.cpu()) < 1e-4
 
 
 @pytest.mark.parametrize("C,M", [(64, 200), (320, 250), (320, 40960)])

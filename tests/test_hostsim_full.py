@@ -230,6 +230,12 @@ def test_group_norm_from_the_producers_column_statistics(full_ops, c0, c1, units
     out_e2 = torch.zeros(M, C)
     emu.group_norm_cs(cs0, cs1, x0.float(), None if x1 is None else x1.float(), units, rows, 1e-5, gamma, beta, silu, None, out_e2)
     assert rel_l2(out_e2, out_e) < 1e-5
+    # t2v_gn_stats_cs: the (mean, rstd) the training engine keeps for the backward, from the same column statistics
+    st_s, st_e, st_t = torch.full((units, 64), float("nan")), torch.zeros(units, 64), torch.zeros(units, 64)
+    sim.gn_stats_cs(cs0, cs1, c0, c1, units, rows, 1e-5, ws, st_s)
+    emu.gn_stats_cs(cs0, cs1, c0, c1, units, rows, 1e-5, None, st_e)
+    emu.gn_stats(x0.float(), None if x1 is None else x1.float(), units, rows, 1e-5, None, st_t)
+    assert torch.isfinite(st_s).all() and rel_l2(st_s, st_e) < 1e-5 and rel_l2(st_e, st_t) < 1e-4
 
 
 @pytest.mark.parametrize("C,M", [(64, 200), (320, 250), (64, 192)])
