@@ -360,6 +360,20 @@ int t2v_attn_spatial_bwd(const void* q, int ldq, const void* k, int ldk, const v
  * caller's workspace ws (>= splits*R*C*4 bytes, the split count shrinks to fit) and are added in a fixed order. */
 int t2v_wgrad_tn(const void* a, int lda, const void* b, int ldb, long long M, int R, int C, float alpha, float* out, int ldo, float* ws,
                  long long ws_bytes, int splits, void* stream);
+/* t2v_wgrad_tn_group: up to T2V_WGRAD_GROUP_MAX such products in one launch pair (main + fixed-order reduce): the weight gradients
+ * of ONE LoRA group — dU of each of its leaves and dD (utils/lora.py:45-50 under autograd) — whose operands all exist once the
+ * rank-r gradient is there.  Same arithmetic and summation structure per product as t2v_wgrad_tn; the token splits are chosen for
+ * the group as a whole.  ws: fp32 workspace for the partial slabs of all products. */
+#define T2V_WGRAD_GROUP_MAX 8
+typedef struct t2v_wgrad_problem {
+    const void* a;      /* bf16 [M][lda], columns [0, R) */
+    const void* b;      /* bf16 [M][ldb], columns [0, C) */
+    float* out;         /* fp32 [R][ldo] = alpha * a^T b */
+    long long M;
+    int lda, ldb, ldo, R, C;
+    float alpha;
+} t2v_wgrad_problem;
+int t2v_wgrad_tn_group(const t2v_wgrad_problem* problems, int n, float* ws, long long ws_bytes, void* stream);
 /* t2v_transpose_pad_bf16: out[b][c][r] = in[b][r][c] for r < rows and 0 for rows <= r < roundup(rows, 64) — the K-contiguous,
  * K-padded operand of the token-contracted weight-gradient GEMMs (dU = dy^T t, dD = G^T x) in one pass; 16-byte accesses on both
  * sides: cols % 8 == 0, ld_in % 8 == 0, ld_out % 8 == 0 and >= roundup(rows, 64), 16-byte aligned bases, batch strides % 8. */

@@ -28,16 +28,13 @@ __device__ __forceinline__ uint4 ragged_chunk(const bf16_t* p, int n) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-__global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb, long long M,
-                                                       int R, int C, long long tok_per_split, float* __restrict__ ws) {
-    __shared__ bf16_t sa[WT_TOK][WT_PITCH];
-    __shared__ bf16_t sb[WT_TOK][WT_PITCH];
+// one 64 x 64 output tile over the token range [m_begin, m_end): partial sums into `slab` ([R][C] fp32)
+__device__ __forceinline__ void wgrad_tile(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb, int R, int C, int r0,
+                                           int c0, long long m_begin, long long m_end, float* __restrict__ slab,
+                                           bf16_t (*sa)[WT_PITCH], bf16_t (*sb)[WT_PITCH]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hi = lane >> 5, l31 = lane & 31;
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;  // this wave's 32 x 32 sub-tile
-    const long long m_begin = (long long)blockIdx.z * tok_per_split;
-    const long long m_end = m_begin + tok_per_split < M ? m_begin + tok_per_split : M;
     f32x16_t acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -83,8 +80,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict_
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&fa, *(bf16x8_t*)&fb, acc, 0, 0, 0);
         }
     }
-    // D[row = (e & 3) + 8 (e >> 2) + 4 hi][col = l31] of the wave's sub-tile -> partial slab [split][R][C]
-    float* slab = ws + (long long)blockIdx.z * R * C;
+    // D[row = (e & 3) + 8 (e >> 2) + 4 hi][col = l31] of the wave's sub-tile -> partial slab [R][C]
     const int c = c0 + wc + l31;
     if (c < C) {
 #pragma unroll
@@ -93,6 +89,46 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict_
             if (r < R) slab[(long long)r * C + c] = acc[e];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb, long long M,
+                                                       int R, int C, long long tok_per_split, float* __restrict__ ws) {
+    __shared__ bf16_t sa[WT_TOK][WT_PITCH];
+    __shared__ bf16_t sb[WT_TOK][WT_PITCH];
+    const long long m_begin = (long long)blockIdx.z * tok_per_split;
+    const long long m_end = m_begin + tok_per_split < M ? m_begin + tok_per_split : M;
+    wgrad_tile(a, lda, b, ldb, R, C, blockIdx.y * 64, blockIdx.x * 64, m_begin, m_end, ws + (long long)blockIdx.z * R * C, sa, sb);
+}
+
+// Up to T2V_WGRAD_GROUP_MAX independent products in ONE launch (the weight gradients of one LoRA group: dU of each of its leaves
+// and dD, whose operands all exist once the rank-r gradient g is there): a workgroup finds its problem by a scan over the block
+// prefix sums in the kernel argument, then works exactly like wgrad_tn_kernel.  One launch fills the chip where three or four
+// small ones each had to split their token range a hundred ways to do so (fewer, longer workgroups: a fifth of the partial slabs).
+struct WgradGroup {
+    const bf16_t* a[T2V_WGRAD_GROUP_MAX];
+    const bf16_t* b[T2V_WGRAD_GROUP_MAX];
+    float* out[T2V_WGRAD_GROUP_MAX];
+    long long M[T2V_WGRAD_GROUP_MAX], tok_per_split[T2V_WGRAD_GROUP_MAX], ws_off[T2V_WGRAD_GROUP_MAX];
+    int lda[T2V_WGRAD_GROUP_MAX], ldb[T2V_WGRAD_GROUP_MAX], ldo[T2V_WGRAD_GROUP_MAX], R[T2V_WGRAD_GROUP_MAX], C[T2V_WGRAD_GROUP_MAX];
+    int splits[T2V_WGRAD_GROUP_MAX], tiles_c[T2V_WGRAD_GROUP_MAX];
+    float alpha[T2V_WGRAD_GROUP_MAX];
+    int first_block[T2V_WGRAD_GROUP_MAX + 1];   // main kernel: tiles * splits per problem
+    int first_rblock[T2V_WGRAD_GROUP_MAX + 1];  // reduce kernel: ceil(R * C / 64) per problem
+    int n;
+};
+
+__global__ __launch_bounds__(256) void wgrad_tn_group_kernel(const WgradGroup g, float* __restrict__ ws) {
+    __shared__ bf16_t sa[WT_TOK][WT_PITCH];
+    __shared__ bf16_t sb[WT_TOK][WT_PITCH];
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.first_block[i + 1]) ++i;   // block-uniform
+    const int local = blockIdx.x - g.first_block[i];
+    const int tiles_c = g.tiles_c[i], tiles = tiles_c * ((g.R[i] + 63) / 64);
+    const int split = local / tiles, tile = local - split * tiles;
+    const long long m_begin = (long long)split * g.tok_per_split[i];
+    const long long m_end = m_begin + g.tok_per_split[i] < g.M[i] ? m_begin + g.tok_per_split[i] : g.M[i];
+    wgrad_tile(g.a[i], g.lda[i], g.b[i], g.ldb[i], g.R[i], g.C[i], (tile / tiles_c) * 64, (tile % tiles_c) * 64, m_begin, m_end,
+               ws + g.ws_off[i] + (long long)split * g.R[i] * g.C[i], sa, sb);
 }
 
 // out = alpha * sum over splits, fixed order: thread (o, g) adds the splits k = g, g + 4, g + 8, ... of output o (four loads in
@@ -117,6 +153,31 @@ __global__ __launch_bounds__(256) void wgrad_tn_reduce_kernel(const float* __res
     if (g == 0 && idx < RC) {
         const float s = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
         out[(idx / C) * ldo + idx % C] = s * alpha;
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_tn_group_reduce_kernel(const WgradGroup g, const float* __restrict__ ws) {
+    __shared__ float part[4][64];
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.first_rblock[i + 1]) ++i;
+    const int o = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int R = g.R[i], C = g.C[i], splits = g.splits[i];
+    const long long RC = (long long)R * C, idx = (long long)(blockIdx.x - g.first_rblock[i]) * 64 + o;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < RC) {   // the same fixed summation order as wgrad_tn_reduce_kernel
+        const float* p = ws + g.ws_off[i] + idx;
+        int k = grp;
+        for (; k + 12 < splits; k += 16) {
+            const float t0 = p[(long long)k * RC], t1 = p[(long long)(k + 4) * RC], t2 = p[(long long)(k + 8) * RC], t3 = p[(long long)(k + 12) * RC];
+            s0 += t0; s1 += t1; s2 += t2; s3 += t3;
+        }
+        for (; k < splits; k += 4) s0 += p[(long long)k * RC];
+    }
+    part[grp][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && idx < RC) {
+        const float s = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+        g.out[i][(idx / C) * g.ldo[i] + idx % C] = s * g.alpha[i];
     }
 }
 
@@ -146,6 +207,52 @@ extern "C" int t2v_wgrad_tn(const void* a, int lda, const void* b, int ldb, long
     T2V_CHECK_LAUNCH();
     hipLaunchKernelGGL(wgrad_tn_reduce_kernel, dim3((unsigned)(((long long)R * C + 63) / 64)), dim3(256), 0, s, (const float*)ws, splits, R, C,
                        alpha, out, ldo);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+
+extern "C" int t2v_wgrad_tn_group(const t2v_wgrad_problem* p, int n, float* ws, long long ws_bytes, void* stream) {
+    T2V_REQUIRE(p && ws && n >= 1 && n <= T2V_WGRAD_GROUP_MAX, T2V_EINVAL, "t2v_wgrad_tn_group: 1..8 problems");
+    WgradGroup g;
+    long long total_tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        T2V_REQUIRE(p[i].a && p[i].b && p[i].out && p[i].M > 0 && p[i].R > 0 && p[i].C > 0 && p[i].ldo >= p[i].C, T2V_EINVAL,
+                    "t2v_wgrad_tn_group: bad problem");
+        T2V_REQUIRE(p[i].lda % 8 == 0 && p[i].ldb % 8 == 0 && (uintptr_t)p[i].a % 16 == 0 && (uintptr_t)p[i].b % 16 == 0, T2V_ESHAPE,
+                    "t2v_wgrad_tn_group: 16-byte aligned operand rows");
+        total_tiles += (long long)((p[i].R + 63) / 64) * ((p[i].C + 63) / 64);
+    }
+    // about two and a half workgroups per CU over the whole group; every problem gets the same number of token splits (their
+    // token counts are equal or close), shrunk until the partial slabs fit the workspace
+    long long want = (640 + total_tiles - 1) / total_tiles;
+    if (want > 256) want = 256;
+    for (;;) {
+        long long off = 0, blocks = 0, rblocks = 0;
+        for (int i = 0; i < n; ++i) {
+            const long long steps = (p[i].M + WT_TOK - 1) / WT_TOK;
+            long long sp = want < steps ? want : steps;
+            const long long tps = ((steps + sp - 1) / sp) * WT_TOK;
+            sp = (p[i].M + tps - 1) / tps;
+            const int tiles_c = (p[i].C + 63) / 64, tiles = tiles_c * ((p[i].R + 63) / 64);
+            g.a[i] = (const bf16_t*)p[i].a; g.b[i] = (const bf16_t*)p[i].b; g.out[i] = p[i].out;
+            g.M[i] = p[i].M; g.tok_per_split[i] = tps; g.ws_off[i] = off;
+            g.lda[i] = p[i].lda; g.ldb[i] = p[i].ldb; g.ldo[i] = p[i].ldo; g.R[i] = p[i].R; g.C[i] = p[i].C;
+            g.splits[i] = (int)sp; g.tiles_c[i] = tiles_c; g.alpha[i] = p[i].alpha;
+            g.first_block[i] = (int)blocks; g.first_rblock[i] = (int)rblocks;
+            blocks += (long long)tiles * sp;
+            rblocks += ((long long)p[i].R * p[i].C + 63) / 64;
+            off += sp * (long long)p[i].R * p[i].C;
+        }
+        g.first_block[n] = (int)blocks; g.first_rblock[n] = (int)rblocks;
+        g.n = n;
+        if (off * 4 <= ws_bytes) break;
+        T2V_REQUIRE(want > 1, T2V_ESHAPE, "t2v_wgrad_tn_group: workspace smaller than the outputs");
+        want = want / 2;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_tn_group_kernel, dim3((unsigned)g.first_block[n]), dim3(256), 0, s, g, ws);
+    T2V_CHECK_LAUNCH();
+    hipLaunchKernelGGL(wgrad_tn_group_reduce_kernel, dim3((unsigned)g.first_rblock[n]), dim3(256), 0, s, g, (const float*)ws);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }

@@ -61,6 +61,9 @@ class LoraTrainMixin:
     tn_wgrad = os.environ.get("T2V_TN_WGRAD", "1") == "1"
     # the LoRA branch's dropout as the epilogue of its up-projection GEMM (T2V_FUSE_DROPOUT=0: separate t2v_dropout_bf16 pass)
     fuse_dropout = os.environ.get("T2V_FUSE_DROPOUT", "1") == "1"
+    # all weight gradients of a LoRA group (dU per leaf, per-clip column sums, dD per input part) as ONE t2v_wgrad_tn_group launch
+    # pair once the rank-r gradient exists, instead of one t2v_wgrad_tn pair each (T2V_GROUP_WGRAD=0)
+    group_wgrad = os.environ.get("T2V_GROUP_WGRAD", "1") == "1"
 
     # ---- binding ------------------------------------------------------------------------------------------------------
     def bind_lora(self, params):
@@ -367,15 +370,28 @@ class LoraTrainMixin:
             dy = dym
         g = self.buf(m, grp.n * grp.rp)
         if self.tn_wgrad:  # token-contracted kernel on the token-major operands themselves: no transposed copies
+            grouped = self.group_wgrad and hasattr(ops, "wgrad_tn_group")
+            pending = []
             c0 = 0
             for i in range(grp.n):
                 n_out, rp = grp.N[i], grp.rp
-                ops.wgrad_tn(dy[:, c0:c0 + n_out], t[:, i * rp:(i + 1) * rp], grp.EU[i], alpha=grp.scale[i])
+                prob = (dy[:, c0:c0 + n_out], t[:, i * rp:(i + 1) * rp], grp.EU[i], grp.scale[i])
+                if grouped:
+                    pending.append(prob)
+                else:
+                    ops.wgrad_tn(prob[0], prob[1], prob[2], alpha=prob[3])
                 ops.gemm(dy[:, c0:c0 + grp.npad[i]], grp.UT[i], g[:, i * rp:(i + 1) * rp], M=m, N=rp, alpha=grp.scale[i])
                 c0 += grp.npad[i]
             if colsum is not None:
                 ind = self.clip_indicator_tok(m)
-                ops.wgrad_tn(ind[:, :self.B], dy_plain[:, :grp.N[0]], colsum)
+                prob = (ind[:, :self.B], dy_plain[:, :grp.N[0]], colsum, 1.0)
+                if grouped:
+                    pending.append(prob)
+                else:
+                    ops.wgrad_tn(prob[0], prob[1], prob[2])
+            if grouped:   # launched together with dD by lora_wgrad_down (every caller goes there next); dy / t stay until then
+                grp.pending = (pending, [dy] if grp.drop else [], t)
+                return g
             if grp.drop:
                 self.pool.put(dy)
             self.pool.put(t)
@@ -409,11 +425,19 @@ class LoraTrainMixin:
         m_in = x.M
         mp = _pad(m_in, 64)
         if self.tn_wgrad:
+            pending, masked, t = getattr(grp, "pending", None) or ([], [], None)
+            grp.pending = None
             c0 = 0
             for part in x.parts:
                 c = part.shape[1]
-                ops.wgrad_tn(G, part, grp.ED[:, c0:c0 + c])
+                if t is not None:
+                    pending.append((G, part, grp.ED[:, c0:c0 + c], 1.0))
+                else:
+                    ops.wgrad_tn(G, part, grp.ED[:, c0:c0 + c])
                 c0 += c
+            if t is not None:
+                ops.wgrad_tn_group(pending)
+                self.pool.put(*masked, t)
             self.drop(*x.parts)
             grp.saved = None
             self._group_finished(grp)

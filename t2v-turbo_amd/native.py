@@ -20,6 +20,15 @@ ACT_NONE, ACT_GEGLU, ACT_SILU = 0, 1, 2
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 
+WGRAD_GROUP_MAX = 8
+
+
+class WgradProblem(C.Structure):
+    """struct t2v_wgrad_problem, field for field."""
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("out", C.c_void_p), ("M", C.c_longlong), ("lda", C.c_int), ("ldb", C.c_int),
+                ("ldo", C.c_int), ("R", C.c_int), ("C", C.c_int), ("alpha", C.c_float)]
+
+
 class GemmDesc(C.Structure):
     """struct t2v_gemm_desc"""
     _fields_ = [
@@ -132,6 +141,7 @@ _SIGS = {
                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "t2v_wgrad_tn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int,
                                C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
+    "t2v_wgrad_tn_group": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]),
     "t2v_transpose_pad_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
                                          C.c_longlong, C.c_void_p]),
     "t2v_dropout_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float,
@@ -537,6 +547,19 @@ class HipOps:
         ws = self.workspace(a.device)
         self._call("t2v_wgrad_tn", _p(a), _row_stride(a), _p(b), _row_stride(b), a.shape[0], a.shape[1], b.shape[1], alpha, _p(out),
                    _row_stride(out), ws.data_ptr(), ws.numel(), splits)
+
+    def wgrad_tn_group(self, problems):
+        """``problems``: [(a, b, out, alpha)] with token-major bf16 a [M, R], b [M, C] and fp32 out [R, C] — the weight gradients
+        of one LoRA group in ONE launch pair (t2v_wgrad_tn_group); more than 8 problems go out in chunks of 8."""
+        for k in range(0, len(problems), WGRAD_GROUP_MAX):
+            chunk = problems[k:k + WGRAD_GROUP_MAX]
+            arr = (WgradProblem * len(chunk))()
+            for d, (a, b, out, alpha) in zip(arr, chunk):
+                assert out.dtype == torch.float32 and a.shape[0] == b.shape[0] and out.shape == (a.shape[1], b.shape[1])
+                d.a, d.b, d.out, d.M = _p(a), _p(b), _p(out), a.shape[0]
+                d.lda, d.ldb, d.ldo, d.R, d.C, d.alpha = _row_stride(a), _row_stride(b), _row_stride(out), a.shape[1], b.shape[1], alpha
+            ws = self.workspace(chunk[0][0].device)
+            self._call("t2v_wgrad_tn_group", C.cast(arr, C.c_void_p), len(chunk), ws.data_ptr(), ws.numel(), keep=arr)
 
     def transpose_pad(self, src, rows, cols, out, batch=1, in_stride=0, out_stride=0):
         """out[b][c][r] = src[b][r][c], zero for rows <= r < roundup(rows, 64) (16-byte accesses; see include/t2v_hip.h)."""

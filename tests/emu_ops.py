@@ -394,6 +394,15 @@ class EmuOps:
             assert a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.storage_offset() % 8 == 0 and b.storage_offset() % 8 == 0
         out.copy_((a.float().t() @ b.float()) * alpha)
 
+    def wgrad_tn_group(self, problems):
+        """[(a, b, out, alpha)]: the weight gradients of one LoRA group as one op (t2v_wgrad_tn_group)."""
+        self._log("wgrad_tn_group")
+        for a, b, out, alpha in problems:
+            if self.strict:
+                assert a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.storage_offset() % 8 == 0 and b.storage_offset() % 8 == 0
+                assert out.dtype == torch.float32 and out.shape == (a.shape[1], b.shape[1])
+            out.copy_((a.float().t() @ b.float()) * alpha)
+
     def transpose_pad(self, src, rows, cols, out, batch=1, in_stride=0, out_stride=0):
         self._log("transpose_pad")
         rp = (rows + 63) // 64 * 64

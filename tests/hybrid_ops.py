@@ -13,7 +13,7 @@ from tests.emu_ops import EmuOps
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim"))
 
 SIMULATED = ("gn_bwd", "gn_bwd_ws_floats", "layernorm_bwd", "geglu_fwd", "geglu_bwd", "scatter2x", "add", "attn_temporal_bwd",
-             "softmax_bwd_rows", "transpose", "transpose_pad", "sumpool2x2", "gather", "dropout", "wgrad_tn")
+             "softmax_bwd_rows", "transpose", "transpose_pad", "sumpool2x2", "gather", "dropout", "wgrad_tn", "wgrad_tn_group")
 
 
 class HybridOps(EmuOps):

@@ -303,6 +303,34 @@ def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
     assert rel_l2(o_h[:, :C].cpu(), o_e) < 2e-4 and float(o_h[:, C:].min()) == 7.0
 
 
+@pytest.mark.parametrize("M,N,n,cin", [(40960, 320, 3, 320), (2560, 1280, 1, 1280), (10240, 640, 2, 640), (308, 64, 3, 72)])
+def test_wgrad_tn_group(ops, M, N, n, cin):
+    """t2v_wgrad_tn_group at the shapes of one LoRA group (n leaves of N outputs, rank padded to 64, a cin-channel input): dU of
+    every leaf + dD in one launch pair against the per-product kernel (t2v_wgrad_tn; same summation structure, different token
+    splits) and the emulation; deterministic."""
+    hip, emu = ops
+    dy, t, x = _rt(M, n * N, seed=1, scale=0.3), _rt(M, n * 64, seed=2, scale=0.3), _rt(M, cin, seed=3, scale=0.3)
+    dyd, td, xd = _dev(dy), _dev(t), _dev(x)
+    probs_e, probs_h, singles = [], [], []
+    for i in range(n):
+        probs_e.append((dy[:, i * N:(i + 1) * N], t[:, i * 64:(i + 1) * 64], torch.zeros(N, 64), 0.5 + i))
+        probs_h.append((dyd[:, i * N:(i + 1) * N], td[:, i * 64:(i + 1) * 64], torch.full((N, 64), 7.0, device="cuda"), 0.5 + i))
+    probs_e.append((t, x, torch.zeros(n * 64, cin), 1.0))
+    probs_h.append((td, xd, torch.full((n * 64, cin), 7.0, device="cuda"), 1.0))
+    emu.wgrad_tn_group(probs_e)
+    hip.wgrad_tn_group(probs_h)
+    torch.cuda.synchronize()
+    first = [p[2].clone() for p in probs_h]
+    for (a, b, o, alpha), pe in zip(probs_h, probs_e):
+        single = torch.zeros_like(o)
+        hip.wgrad_tn(a, b, single, alpha=alpha)
+        torch.cuda.synchronize()
+        assert rel_l2(o.cpu(), pe[2]) < 2e-4 and rel_l2(o.cpu(), single.cpu()) < 1e-5
+    hip.wgrad_tn_group(probs_h)
+    torch.cuda.synchronize()
+    assert all(torch.equal(p[2], f) for p, f in zip(probs_h, first))
+
+
 @pytest.mark.parametrize("M,Ns,p", [(40960, (320,), 0.1), (2560, (1280,), 0.1), (770, (320, 320, 320), 0.1), (100, (4,), 0.5)])
 def test_gemm_dropout_epilogue_is_the_standalone_mask(ops, M, Ns, p):
     """The LoRA up-projection with its dropout as the GEMM's epilogue (t2v_gemm drop_* fields) against the two-kernel form

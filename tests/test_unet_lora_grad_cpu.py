@@ -317,9 +317,18 @@ def test_tn_weight_gradient_variant_of_the_engine():
     eng.bind_lora(params)
     y, dx, grads = _engine_step(eng, m, params, x, ts, ctx, 8, tc, mc, r_out)
     calls = eng.ops.calls
-    assert calls.count("wgrad_tn") > 1000 and calls.count("transpose_pad") < 200   # (what is left: the attention backward's operands)
+    # one launch pair per LoRA group (dU of its leaves + per-clip column sums + dD of its input parts)
+    assert calls.count("wgrad_tn_group") > 400 and calls.count("wgrad_tn") == 0
+    assert calls.count("transpose_pad") < 200   # (what is left: the attention backward's operands)
     assert rel_l2(y, y_ref) < 2e-5 and rel_l2(dx, dx_ref) < 1e-4
     _compare(params, grads, g_ref, m, max_zero=8)
+    # ``group_wgrad = False``: one t2v_wgrad_tn pair per product — the same numbers
+    eng1 = UNetGradEngine(m, EmuOps(strict=True))
+    eng1.tn_wgrad, eng1.flash_attn_bwd, eng1.group_wgrad = True, True, False
+    eng1.bind_lora(params)
+    y1, dx1, grads1 = _engine_step(eng1, m, params, x, ts, ctx, 8, tc, mc, r_out)
+    assert eng1.ops.calls.count("wgrad_tn") > 1000 and eng1.ops.calls.count("wgrad_tn_group") == 0
+    assert torch.equal(y1, y) and torch.equal(dx1, dx) and all(torch.equal(a, b) for a, b in zip(grads1, grads))
 
 
 def test_native_checkpointing_recomputes_the_same_function():

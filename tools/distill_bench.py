@@ -121,6 +121,7 @@ def main():
             eng.flash_attn_bwd, eng.tn_wgrad, eng.use_graph = "flash" in flags, "tn" in flags, "graph" in flags
             eng.checkpoint_blocks = "ckpt" in flags      # the reference's use_checkpoint: recompute each block in the backward
             eng.fuse_gn = "nocs" not in flags            # GroupNorm statistics of the forward from the producing GEMMs' epilogues
+            eng.group_wgrad = "nogroup" not in flags     # one t2v_wgrad_tn_group launch pair per LoRA group
             eng.bind_lora(params)
             torch.cuda.reset_peak_memory_stats()
         for _ in range(a.warmup + (2 if variant and "graph" in variant else 0)):  # graphs are captured on the second replay
