@@ -73,11 +73,11 @@ def test_column_statistics(hip, cfg):
     assert rel_l2(got, cs_e) < 2e-2
 
 
-@pytest.mark.parametrize("cfg", FUSED_TILES)
-@pytest.mark.parametrize("C,N,geglu", [(320, 960, False), (640, 512, True), (1280, 256, False), (512, 1536, False)])
+# (GEGLU needs 64-wide wave tiles in N: tile ids 5, 9, 23, 31 do not carry it)
+@pytest.mark.parametrize("cfg,C,N,geglu", [(cfg, C, N, g) for cfg in FUSED_TILES
+                                           for C, N, g in ((320, 960, False), (640, 512, True), (1280, 256, False), (512, 1536, False))
+                                           if not (g and cfg in (5, 9, 23, 31))])
 def test_layernorm_fold(hip, cfg, C, N, geglu):
-    if geglu and cfg in (5, 9, 23, 31):
-        pytest.skip("GEGLU needs 64-wide wave tiles in N")
     M = 1000
     x, wp, s_vec, t_vec, ref = _ln_fold_operands(M, C, N, seed=10 + C, geglu=geglu)
     nb = C // 32

@@ -110,11 +110,10 @@ def _ln_fold_operands(M, C, N, seed, geglu=False):
     return x, wp, s_vec, t_vec, ref
 
 
-@pytest.mark.parametrize("cfg", FUSED_TILES)
-@pytest.mark.parametrize("C,N,geglu", [(320, 192, False), (128, 256, True), (512, 128, False)])
+# (GEGLU needs 64-wide wave tiles in N: tile ids 5, 9, 23, 31 do not carry it)
+@pytest.mark.parametrize("cfg,C,N,geglu", [(cfg, C, N, g) for cfg in FUSED_TILES for C, N, g in ((320, 192, False), (128, 256, True), (512, 128, False))
+                                           if not (g and cfg in (5, 9, 23, 31))])
 def test_layernorm_folded_into_the_consumer(sim, cfg, C, N, geglu):
-    if geglu and cfg in (5, 9, 23, 31):
-        pytest.skip("GEGLU needs 64-wide wave tiles in N")
     M = 200
     x, wp, s_vec, t_vec, ref = _ln_fold_operands(M, C, N, seed=10 + C, geglu=geglu)
     # the producer's statistics: any launch that writes x with rowstat — here an identity GEMM would do; take the emulation
