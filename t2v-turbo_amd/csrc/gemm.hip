@@ -284,6 +284,11 @@ template <int BM, int BN, int WM, int WN, int STAGES, int BK = 64, int WPE = (WM
 __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void gemm_kernel(const GemmParams p) {
     static_assert(FUSE == 0 || (FAST && !RS && !LNOUT), "fused statistics: fast DMA-staged kernels only");
     constexpr bool F_ROW = (FUSE & 1) != 0, F_COL = (FUSE & 2) != 0, F_LNF = (FUSE & 4) != 0;
+    // F_DRP: the LoRA up-projection's dropout epilogue on the fast kernels: out = residual + dropout(acc + bias).  The residual cannot
+    // start the accumulators here (the mask applies to the product only): each 32-row slab's residual runs are loaded at the top of
+    // its epilogue pass and land under the mask arithmetic (~35 VALU per column pair).  The generic kernels, which carried every
+    // dropout launch before, store 32-byte runs per lane and row.
+    constexpr bool F_DRP = (FUSE & 8) != 0;
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -607,7 +612,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
             for (int j = 0; j < TN; ++j) {
                 const int ch = ch_lane + j * 32;
                 rinit[i][j][0] = rinit[i][j][1] = uint4{0, 0, 0, 0};
-                if (fold_rr && d.residual && gm < d.M && ch < d.N && !ABL(64)) {
+                if (fold_rr && !F_DRP && d.residual && gm < d.M && ch < d.N && !ABL(64)) {
                     const bf16_t* rp = (const bf16_t*)d.residual + o_off + (long long)gm * d.ldr + ch;
                     rinit[i][j][0] = *(const uint4*)rp;
                     rinit[i][j][1] = *(const uint4*)(rp + 8);
@@ -659,7 +664,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
                     init[4 * q] = binit[j][q].x; init[4 * q + 1] = binit[j][q].y;
                     init[4 * q + 2] = binit[j][q].z; init[4 * q + 3] = binit[j][q].w;
                 }
-                if (fold_rr) {
+                if (fold_rr && !F_DRP) {
                     float rf[16];
                     unpack8(rinit[i][j][0], rf);
                     unpack8(rinit[i][j][1], rf + 8);
@@ -859,12 +864,41 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
             const int gm = m0 + wave_m * WTM + i * 32 + frow;
             asm volatile("" ::: "memory");
             float rs1[F_ROW ? TN : 1], rs2[F_ROW ? TN : 1];
+            uint4 rdrp[F_DRP ? TN : 1][2];
+            if constexpr (F_DRP) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    rdrp[j][0] = rdrp[j][1] = uint4{0, 0, 0, 0};
+                    if (d.residual && gm < d.M && ch_lane + j * 32 < d.N) {
+                        const bf16_t* rp = (const bf16_t*)d.residual + o_off + (long long)gm * d.ldr + ch_lane + j * 32;
+                        rdrp[j][0] = *(const uint4*)rp;
+                        rdrp[j][1] = *(const uint4*)(rp + 8);
+                    }
+                }
+            }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float v[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
                 if constexpr (F_LNF) ln_fold(v, j, lnr[i], lnrm[i]);
+                if constexpr (F_DRP) {   // keep(row, col) = the counter-based mask of t2v_dropout_bf16, then the residual tile
+                    if (gm < d.M && ch_lane + j * 32 < d.N) {
+                        const uint64_t seed = *(const uint64_t*)d.drop_seed;
+                        const uint64_t pair0 = ((uint64_t)gm * (uint64_t)d.drop_ncols + (uint64_t)(d.drop_col0 + ch_lane + j * 32)) >> 1;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const uint64_t b = dropout_bits(seed, d.drop_site, pair0 + k);
+                            v[2 * k] = ((uint32_t)b >= d.drop_thr) ? v[2 * k] * d.drop_inv_keep : 0.f;
+                            v[2 * k + 1] = ((uint32_t)(b >> 32) >= d.drop_thr) ? v[2 * k + 1] * d.drop_inv_keep : 0.f;
+                        }
+                        float rf[16];
+                        unpack8(rdrp[j][0], rf);
+                        unpack8(rdrp[j][1], rf + 8);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] += rf[e];
+                    }
+                }
                 if (gm < d.M && ch_lane + j * 32 < d.N) epi.template compute<true>(v, nullptr, gm, ch_lane + j * 32, ch_lane + j * 32);
                 if constexpr (F_ROW) {
                     // (sum, sum of squares) of this row over the 32-column block j of the wave tile: the lane's 16 fp32 epilogue
@@ -1014,10 +1048,10 @@ template <int BM, int BN, int WM, int WN, int STAGES, int BK, int WPE, bool FAST
 int launch_impl(GemmParams& p, hipStream_t s);
 
 // does this launch qualify for the fast kernels (accumulators start at bias + row vector + residual, bf16 slab epilogue)?
-inline bool gemm_is_fast(const GemmParams& p) {
+inline bool gemm_is_fast(const GemmParams& p, bool allow_dropout = false) {
     const int n_out = p.d.act == T2V_ACT_GEGLU ? p.d.N / 2 : p.d.N;
     static const bool no_fast = getenv("T2V_GEMM_NOFAST") != nullptr;  // diagnostics: force the generic epilogue
-    return !no_fast && !p.d.drop_thr && p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1 && p.d.alpha == 1.0f &&
+    return !no_fast && (allow_dropout || !p.d.drop_thr) && p.vec4 && n_out % 16 == 0 && p.d.N % 16 == 0 && p.splits == 1 && p.d.alpha == 1.0f &&
            !p.d.out_f32 && (!p.d.rowvec || ((uintptr_t)p.d.rowvec % 16 == 0 && p.d.ld_rowvec % 4 == 0));
 }
 
@@ -1105,6 +1139,7 @@ int launch_fused(int fuse, GemmParams& p, hipStream_t s) {
         case 1: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 1>(p, s);
         case 2: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 2>(p, s);
         case 4: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 4>(p, s);
+        case 8: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 8>(p, s);
         default: return T2V_EINVAL;
     }
 }
@@ -1330,10 +1365,15 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
     p.debug = g_debug;
     cfg_out = cfg;
     fuse = (d.rowstat_out ? 1 : 0) | (d.colstat_out ? 2 : 0) | (d.lnf_stats ? 4 : 0);
+    // a dropout epilogue (the LoRA up-projections of the training path) rides on the fast kernels' staged epilogue where the launch
+    // qualifies for them otherwise (FUSE bit 8 of gemm_fuse.hip); T2V_GEMM_FAST_DROPOUT=0: the generic kernels, as before round 3
+    static const bool fast_dropout = !(getenv("T2V_GEMM_FAST_DROPOUT") && getenv("T2V_GEMM_FAST_DROPOUT")[0] == '0');
+    const bool auto_drop = !fuse && d.drop_thr && fast_dropout && !d.rowvec && d.act == T2V_ACT_NONE && !d.ln_out && d.batch == 1;
+    if (auto_drop) fuse = 8;
     fuse_cfg = 0;
     fuse_ok = false;
     if (fuse) {
-        T2V_REQUIRE(fuse == 1 || fuse == 2 || fuse == 4, T2V_EINVAL, "t2v_gemm: one of rowstat_out / colstat_out / lnf_stats per launch");
+        T2V_REQUIRE(fuse == 1 || fuse == 2 || fuse == 4 || fuse == 8, T2V_EINVAL, "t2v_gemm: one of rowstat_out / colstat_out / lnf_stats per launch");
         T2V_REQUIRE(!d.ln_out && d.batch == 1, T2V_EINVAL, "t2v_gemm: fused statistics: no batch, no LayerNorm second output");
         if (fuse == 1)
             T2V_REQUIRE(d.N % 32 == 0 && d.ld_rowstat >= d.N / 16 && d.ld_rowstat % 4 == 0 && (uintptr_t)d.rowstat_out % 16 == 0 &&
@@ -1349,8 +1389,9 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
                                     "row vector / dropout");
         fuse_cfg = t2v_gemm_fuse_tile(cfg, d.act, fuse);
         // the fused epilogue rides on the fast kernels of one K split; GEGLU needs a 64-wide wave tile (its value / gate pairs)
-        fuse_ok = fuse_cfg != 0 && p.splits == 1 && gemm_is_fast(p) && !(d.act == T2V_ACT_GEGLU && kCfg[fuse_cfg].wtn < 64);
+        fuse_ok = fuse_cfg != 0 && p.splits == 1 && gemm_is_fast(p, fuse == 8) && !(d.act == T2V_ACT_GEGLU && kCfg[fuse_cfg].wtn < 64);
         if (fuse_ok) { p.nk = p.K / kCfg[fuse_cfg].bk; p.nk_per_split = p.nk; }
+        if (fuse == 8 && !fuse_ok) fuse = 0;   // (not a request: the generic kernel carries the dropout epilogue)
         return T2V_OK;
     }
     return T2V_OK;
@@ -1362,7 +1403,7 @@ extern "C" int t2v_gemm_fuse_supported(const t2v_gemm_desc* dd) {
     bool ok = false;
     const int rc = gemm_prepare(dd, p, cfg, fuse, fuse_cfg, ok);
     if (rc != T2V_OK) return rc;
-    return (fuse && ok) ? 1 : 0;
+    return ((fuse & 7) && ok) ? 1 : 0;   // (bit 8 is the library's own choice for dropout launches, not a request)
 }
 
 extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {

@@ -134,6 +134,39 @@ def test_layernorm_folded_into_the_consumer(sim, cfg, C, N, geglu):
     assert rel_l2(out_e, ref) < 6e-3          # the folded form IS LayerNorm -> Linear (up to the bf16 rounding of W diag(gamma))
 
 
+@pytest.mark.parametrize("cfg", FUSED_TILES)
+def test_dropout_epilogue_on_the_fast_kernels(sim, cfg):
+    """The LoRA up-projection with alpha = 1 (utils/lora.py:45-50, scale 1): its dropout epilogue rides on the fast kernels' staged
+    epilogue (FUSE bit 8: mask on the product, then the residual tile) — zeros exactly where the emulated mask of
+    t2v_dropout_bf16 drops, kept values scaled by 1 / (1 - p), residual behind the mask; two leaves of one group write two column
+    blocks of the same masked matrix; ragged M."""
+    M, K, p, site = 200, 64, 0.25, 5
+    seed = torch.tensor([0x1234_5678_9ABC], dtype=torch.int64)
+    a = _rt(M, K, seed=1)
+    res = (_rt(M, 320 + 128, seed=9).abs() + 1.0).bfloat16().float()   # strictly positive: dropped positions show as res exactly
+    z_s = torch.zeros(M, 320 + 128, dtype=torch.bfloat16)
+    z_e = torch.zeros(M, 320 + 128)
+    c0 = 0
+    for N, sd in ((320, 2), (128, 3)):
+        wt = _rt(N, K, seed=sd, scale=K ** -0.5)
+        drop = (p, seed, site, 320 + 128, c0)
+        sim.gemm(_bf(a), _bf(wt), z_s[:, c0:c0 + N], M=M, N=N, residual=_bf(res[:, c0:c0 + N]), tile_cfg=cfg, split_k=1, dropout=drop)
+        EMU.gemm(a, wt, z_e[:, c0:c0 + N], M=M, N=N, residual=res[:, c0:c0 + N], dropout=drop)
+        c0 += N
+    keep = EMU.dropout_keep(int(seed[0]), site, M, 320 + 128, p)
+    got = z_s.float()
+    assert rel_l2(got, z_e) < BF16_TOL
+    assert torch.equal(got[~keep], res[~keep])            # dropped: the residual alone, bit for bit
+    # without a residual, with a bias inside the mask
+    b = _rt(320, seed=4)
+    o_s, o_e = torch.full((M, 320), float("nan"), dtype=torch.bfloat16), torch.zeros(M, 320)
+    wt = _rt(320, K, seed=2, scale=K ** -0.5)
+    sim.gemm(_bf(a), _bf(wt), o_s, M=M, N=320, bias=b, tile_cfg=cfg, split_k=1, dropout=(p, seed, 7, 320, 0))
+    EMU.gemm(a, wt, o_e, M=M, N=320, bias=b, dropout=(p, seed, 7, 320, 0))
+    k2 = EMU.dropout_keep(int(seed[0]), 7, M, 320, p)
+    assert rel_l2(o_s.float(), o_e) < BF16_TOL and float(o_s.float()[~k2].abs().max()) == 0.0
+
+
 def test_unsupported_requests_are_refused_not_ignored(sim):
     M, N, K = 64, 64, 64
     a, w = _bf(_rt(M, K)), _bf(_rt(N, K))
