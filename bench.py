@@ -361,22 +361,35 @@ def distill_step_leg(teacher, dev, world=1, dry=False, parity=True):
         if cuda:
             torch.cuda.synchronize()
 
+    # Two ways of issuing the same launch lists: plain replay (a Python / ctypes loop over ~8 800 C-ABI calls per step: the step is
+    # then as fast as the HOST can issue, 232-262 ms across the boxes of the pool) and hipGraph replay of the teacher's list and of
+    # the student's forward / backward lists (the host is idle, the step is what the GPU needs).  Both are timed; ms_per_step is the
+    # better one and says which.  At N > 1 the graphs keep the gradient exchange as one all-reduce after the backward (a captured
+    # list cannot carry the host-side markers of the overlapped exchange).
     t_eng = None if dry else teacher.native_engine()
-    if t_eng is not None:
-        t_graph, t_eng.use_graph = t_eng.use_graph, False   # the step is GPU-bound: plain replay of the teacher's list measured 3 % faster
+    modes = [("plain replay", False)] + ([] if dry else [("hipGraph replay", True)])
+    timings = {}
+    t_graph = None if t_eng is None else t_eng.use_graph
     try:
-        for _ in range(1 if dry else 2):
-            loss, info = step()
-        fence()
-        t0 = time.perf_counter()
-        n = 2 if dry else 5
-        for _ in range(n):
-            loss, info = step()
-        fence()
-        dt = time.perf_counter() - t0
+        for label, graph in modes:
+            if t_eng is not None:
+                t_eng.use_graph = graph
+            eng.use_graph = graph
+            for _ in range(1 if dry else (3 if graph else 2)):   # (a list is captured on its second plain replay)
+                loss, info = step()
+            fence()
+            t0 = time.perf_counter()
+            n = 2 if dry else 5
+            for _ in range(n):
+                loss, info = step()
+            fence()
+            timings[label] = (time.perf_counter() - t0, info, len(getattr(eng, "_handles", None) or []))
     finally:
         if t_eng is not None:
             t_eng.use_graph = t_graph
+        eng.use_graph = False
+    best = min(timings, key=lambda k: timings[k][0])
+    dt, info, n_segments = timings[best]
     if world > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -393,15 +406,17 @@ def distill_step_leg(teacher, dev, world=1, dry=False, parity=True):
         ar_ms = (time.perf_counter() - t0) / 3 * 1e3
         sync.zero_()
     plan = eng._last
-    out = {"ms_per_step": round(ms, 1), "samples_per_s": round(world * 1e3 / ms, 3), "n_gpus": world, "per_rank_batch": 1,
+    out = {"ms_per_step": round(ms, 1), "issue": best,
+           "ms_per_step_by_issue": {k: round(v[0] / n * 1e3, 1) for k, v in timings.items()},
+           "samples_per_s": round(world * 1e3 / ms, 3), "n_gpus": world, "per_rank_batch": 1,
            "loss": float(loss.detach()),
            "finite": bool(torch.isfinite(sync.flat).all() and torch.isfinite(opt.flat_param).all()),
            "lora_params_m": round(sync.numel / 1e6, 1), "student": "native gradient engine (flash attention backward, token-contracted "
            "weight gradients), train mode", "teacher": "2 forwards on the inference engine",
            "grad_exchange": ("gradient arena all-reduced in %d segments from inside the backward (%.1f MB fp32, backend %s) + the "
                              "conditioning branch's tensors after it; allreduce_ms = ONE blocking all-reduce of the whole flat "
-                             "buffer, timed separately, for scale" % (len(eng._handles), eng.e_used * 4 / 2 ** 20, dist.get_backend())
-                             if getattr(eng, "_handles", None) else
+                             "buffer, timed separately, for scale" % (n_segments, eng.e_used * 4 / 2 ** 20, dist.get_backend())
+                             if n_segments else
                              "one all-reduce(mean) of the flat fp32 LoRA gradient buffer, %.1f MB, backend %s"
                              % (sync.numel * 4 / 2 ** 20, dist.get_backend())) if world > 1 else "none (1 rank)",
            "allreduce_ms": None if ar_ms is None else round(ar_ms, 3),

@@ -1390,6 +1390,10 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
         fuse_cfg = t2v_gemm_fuse_tile(cfg, d.act, fuse);
         // the fused epilogue rides on the fast kernels of one K split; GEGLU needs a 64-wide wave tile (its value / gate pairs)
         fuse_ok = fuse_cfg != 0 && p.splits == 1 && gemm_is_fast(p, fuse == 8) && !(d.act == T2V_ACT_GEGLU && kCfg[fuse_cfg].wtn < 64);
+        // the dropout epilogue moves to the fast kernels only where that keeps the launch on (a twin of) the tile the table chose
+        // for it: measured per shape on MI355X (profiles/r03_student_gemm_fast_dropout.csv), 160x320 (id 28 -> 23) wins 20-35 %,
+        // ids that map to a different workgroup tile or lose their register-staged prologue (18 -> 4, 29 -> 11) lose 5-45 %
+        if (fuse == 8 && !(fuse_cfg == cfg || cfg == 28 || cfg == 32)) fuse_ok = false;
         if (fuse_ok) { p.nk = p.K / kCfg[fuse_cfg].bk; p.nk_per_split = p.nk; }
         if (fuse == 8 && !fuse_ok) fuse = 0;   // (not a request: the generic kernel carries the dropout epilogue)
         return T2V_OK;

@@ -119,14 +119,22 @@ class T2VTurboScheduler:
             self._ops = HipOps()
         return self._ops
 
+    def _acp_on(self, device, dtype):
+        """alphas_cumprod on the samples' device, copied once (a pageable host -> device copy per call synchronises the stream)."""
+        key = (str(device), dtype)
+        hit = getattr(self, "_acp_cache", None)
+        if hit is None or hit[0] != key or hit[1] is not self.alphas_cumprod:
+            hit = self._acp_cache = (key, self.alphas_cumprod, self.alphas_cumprod.to(device=device, dtype=dtype))
+        return hit[2]
+
     def add_noise(self, original_samples, noise, timesteps):
-        acp = self.alphas_cumprod.to(device=original_samples.device, dtype=original_samples.dtype)
+        acp = self._acp_on(original_samples.device, original_samples.dtype)
         timesteps = timesteps.to(original_samples.device)
         shape = (-1,) + (1,) * (original_samples.dim() - 1)
         return (acp[timesteps] ** 0.5).reshape(shape) * original_samples + ((1 - acp[timesteps]) ** 0.5).reshape(shape) * noise
 
     def get_velocity(self, sample, noise, timesteps):
-        acp = self.alphas_cumprod.to(device=sample.device, dtype=sample.dtype)
+        acp = self._acp_on(sample.device, sample.dtype)
         timesteps = timesteps.to(sample.device)
         shape = (-1,) + (1,) * (sample.dim() - 1)
         return (acp[timesteps] ** 0.5).reshape(shape) * noise - ((1 - acp[timesteps]) ** 0.5).reshape(shape) * sample
