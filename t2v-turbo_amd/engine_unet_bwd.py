@@ -149,7 +149,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         ``grad_sync``: the ``dist.FlatGradSync`` that owns ``flat_grad``.  In a multi-rank job the engine then all-reduces its
         gradient arena in segments WHILE the backward runs (engine_lora: "gradient exchange overlapped with the backward") and
         hands over already averaged gradients; ``grad_sync.all_reduce_mean()`` afterwards only exchanges the conditioning
-        branch's tensors.  T2V_ASYNC_ALLREDUCE=0 keeps the single blocking all-reduce after the backward."""
+        branch's tensors.  T2V_ASYNC_ALLREDUCE=0 keeps the single blocking all-reduce after the backward.  Under ``use_graph``
+        the backward list is captured as one hipGraph per run of launches between two markers."""
         plan = self._last
         if plan["out"].is_cuda and plan["out"].device.index != torch.cuda.current_device():
             with torch.cuda.device(plan["out"].device):
@@ -198,8 +199,6 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         world = dist.get_world_size()
         if world == 1 and not getattr(grad_sync, "force", False):
             return 0
-        if self.use_graph:   # a captured list cannot carry the host-side markers
-            return 0
         return world
 
     def _replay(self, plan, which):
@@ -212,17 +211,39 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             return
         gkey, rkey = "graph_" + which, "runs_" + which
         if plan.get(gkey) is not None:
-            plan[gkey].replay()
+            for g, host in plan[gkey]:      # graphs of the launch runs, host calls (all-reduce markers) between them
+                if g is not None:
+                    g.replay()
+                else:
+                    host[0](*host[1], None)
             return
         if self.use_graph and plan.get(rkey, 0) >= 1 and not plan.get("graph_failed"):
             try:
-                g = torch.cuda.CUDAGraph()
+                # a list is cut at its host-side entries (the gradient exchange's segment markers): one hipGraph per run of
+                # launches, the host calls re-issued between the graph launches
+                runs, cur = [], []
+                for e in plan[which]:
+                    if e[2] == "allreduce_segment":
+                        if cur:
+                            runs.append((cur, None))
+                            cur = []
+                        runs.append((None, (e[0], e[1])))
+                    else:
+                        cur.append(e)
+                if cur:
+                    runs.append((cur, None))
+                built = []
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g):
-                    ops.replay(plan[which], ops.stream())
-                plan[gkey] = g
-                g.replay()
-                return
+                for launches, host in runs:
+                    if launches is None:
+                        built.append((None, host))
+                        continue
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        ops.replay(launches, ops.stream())
+                    built.append((g, None))
+                plan[gkey] = built
+                return self._replay(plan, which)
             except Exception as e:  # capture unsupported -> stay on plain replay, loudly
                 plan["graph_failed"] = str(e)
                 import warnings

@@ -439,6 +439,16 @@ def test_overlapped_gradient_exchange_over_rccl_one_rank():
         pos = [i for i, e in enumerate(eng._last["rec_bwd"]) if e[2] == "allreduce_segment"]
         print(f"[overlap] 8 segment markers at launch {pos} of {len(eng._last['rec_bwd'])}", flush=True)
         assert pos[0] < 0.5 * len(eng._last["rec_bwd"])     # the first piece leaves long before the backward ends
+        # hipGraph replay: the backward list is cut at the markers — one graph per run of launches, the all-reduces between them
+        eng.use_graph = True
+        for rep in range(3):
+            dx2, flat2, rest2 = step(True)
+            assert len(eng._handles) == 8 and rest2 is not None
+            assert torch.equal(dx2, dx0) and torch.equal(flat2, flat0), rep
+        built = eng._last["graph_rec_bwd"]
+        assert sum(1 for g, h in built if g is None) == 8 and sum(1 for g, h in built if g is not None) >= 8
+        assert len(eng._last["graph_rec"]) == 1 and "graph_failed" not in eng._last
+        eng.use_graph = False
     finally:
         sync.force = False
         dist.destroy_process_group()
