@@ -400,7 +400,7 @@ __global__ __launch_bounds__(128) void attn_temporal_bwd_kernel(const bf16_t* q,
 // (layout B) are already B operands, and the A operands are the transposed tiles X^T[c][f].  Those come from the matrix core
 // too: X^T tile m = X-fragment(k step m>>1) x E, E the 0/1 matrix that selects channel 16m + n into column n — the result
 // registers (rows f = 4g + r of column n) ARE the A fragment of X^T (row c = 16m + n, k = f); exact, so the bf16 repack is a
-// truncation.  32 MFMAs, ~150 VALU and no LDS traffic per problem; the VALU form above did ~2 800 LDS reads per lane.
+// truncation.  44 MFMAs (P, dS as hi + lo bf16 parts), ~180 VALU and no LDS traffic per problem; the VALU form above did ~2 800 LDS reads per lane.
 //   dQ^T = K^T dS^T (scale folded into dS), dK^T = Q^T dS, dV^T = dO^T P: lane (row of the output token, g) holds channels
 //   16m + 4g + r — 8-byte stores.
 typedef __attribute__((__vector_size__(4 * sizeof(short)))) short tb_bf16x4_t;
@@ -410,11 +410,17 @@ __device__ __forceinline__ tb_bf16x4_t tb_trunc4(f32x4_t t) {   // exact bf16 va
     u.y = (__float_as_uint(t[3]) & 0xffff0000u) | (__float_as_uint(t[2]) >> 16);
     return *(tb_bf16x4_t*)&u;
 }
-__device__ __forceinline__ tb_bf16x4_t tb_round4(float a, float b, float c, float d) {
-    uint2 u;
-    u.x = pack2bf(a, b);
-    u.y = pack2bf(c, d);
-    return *(tb_bf16x4_t*)&u;
+// four fp32 values as hi + lo bf16 parts (hi = bf16(v), lo = bf16(v - hi)): the second-stage products take both, so P and dS enter
+// them with ~16 bits of mantissa instead of 8 — the VALU kernel this one replaces kept them in fp32, and d/d(latents) of the whole
+// student sits at 5.4-5.9e-2 of a 6e-2 tolerance; twelve more MFMAs on a kernel that waits for HBM
+__device__ __forceinline__ void tb_split4(float a, float b, float c, float d, tb_bf16x4_t& hi, tb_bf16x4_t& lo) {
+    uint2 h, l;
+    h.x = pack2bf(a, b);
+    h.y = pack2bf(c, d);
+    l.x = pack2bf(a - __uint_as_float(h.x << 16), b - __uint_as_float(h.x & 0xffff0000u));
+    l.y = pack2bf(c - __uint_as_float(h.y << 16), d - __uint_as_float(h.y & 0xffff0000u));
+    hi = *(tb_bf16x4_t*)&h;
+    lo = *(tb_bf16x4_t*)&l;
 }
 __global__ __launch_bounds__(256) void attn_temporal_bwd_mfma_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                                      const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ dout, int ldo,
@@ -487,8 +493,9 @@ __global__ __launch_bounds__(256) void attn_temporal_bwd_mfma_kernel(const bf16_
     }
     dot += __shfl_xor(dot, 16, 64);
     dot += __shfl_xor(dot, 32, 64);
-    const tb_bf16x4_t dsT_b = tb_round4(pT[0] * (dpT[0] - dot) * scale, pT[1] * (dpT[1] - dot) * scale,
-                                        pT[2] * (dpT[2] - dot) * scale, pT[3] * (dpT[3] - dot) * scale);
+    tb_bf16x4_t dsT_b, dsT_l;
+    tb_split4(pT[0] * (dpT[0] - dot) * scale, pT[1] * (dpT[1] - dot) * scale, pT[2] * (dpT[2] - dot) * scale,
+              pT[3] * (dpT[3] - dot) * scale, dsT_b, dsT_l);
     // ---- layout B: key j = l15, queries i = 4g + r (their statistics live in lane i)
     float pB[4], dsB[4];
 #pragma unroll
@@ -500,8 +507,9 @@ __global__ __launch_bounds__(256) void attn_temporal_bwd_mfma_kernel(const bf16_
         pB[r] = f_ok ? __builtin_amdgcn_exp2f((sB[r] - mi) * c2) * ri : 0.f;
         dsB[r] = pB[r] * (dp - di) * scale;
     }
-    const tb_bf16x4_t p_b = tb_round4(pB[0], pB[1], pB[2], pB[3]);
-    const tb_bf16x4_t ds_b = tb_round4(dsB[0], dsB[1], dsB[2], dsB[3]);
+    tb_bf16x4_t p_b, p_l, ds_b, ds_l;
+    tb_split4(pB[0], pB[1], pB[2], pB[3], p_b, p_l);
+    tb_split4(dsB[0], dsB[1], dsB[2], dsB[3], ds_b, ds_l);
     // ---- selection operands: E_h[c][n] = (c == 16h + n) within one 32-channel k step
     bf16x8_t sel[2];
 #pragma unroll
@@ -522,9 +530,12 @@ __global__ __launch_bounds__(256) void attn_temporal_bwd_mfma_kernel(const bf16_
         const tb_bf16x4_t kT = tb_trunc4(__builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[m >> 1], sel[m & 1], zero4, 0, 0, 0));
         const tb_bf16x4_t qT = tb_trunc4(__builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[m >> 1], sel[m & 1], zero4, 0, 0, 0));
         const tb_bf16x4_t oT = tb_trunc4(__builtin_amdgcn_mfma_f32_16x16x32_bf16(of[m >> 1], sel[m & 1], zero4, 0, 0, 0));
-        const f32x4_t gq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kT, dsT_b, zero4, 0, 0, 0);  // dQ^T[16m + 4g + r][i = l15]
-        const f32x4_t gk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT, ds_b, zero4, 0, 0, 0);   // dK^T[..][j = l15]
-        const f32x4_t gv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(oT, p_b, zero4, 0, 0, 0);    // dV^T[..][j = l15]
+        f32x4_t gq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kT, dsT_l, zero4, 0, 0, 0);  // dQ^T[16m + 4g + r][i = l15]
+        f32x4_t gk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT, ds_l, zero4, 0, 0, 0);   // dK^T[..][j = l15]
+        f32x4_t gv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(oT, p_l, zero4, 0, 0, 0);    // dV^T[..][j = l15]
+        gq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kT, dsT_b, gq, 0, 0, 0);
+        gk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(qT, ds_b, gk, 0, 0, 0);
+        gv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(oT, p_b, gv, 0, 0, 0);
         if (f_ok) {
             uint2 w;
             w.x = pack2bf(gq[0], gq[1]); w.y = pack2bf(gq[2], gq[3]);

@@ -70,6 +70,8 @@ def test_student_full_width_forward_backward_vs_cpu_autograd():
     from t2v_turbo_amd.unet3d import UNetModel
     t0 = time.time()
     dev = torch.device("cuda", 0)
+    torch.manual_seed(4321)                 # the default initialisers draw from the global generators: without this the weights (and
+    torch.cuda.manual_seed_all(4321)        # with them the measured errors, 1.9-2.4e-2 / 5.6-5.9e-2) depend on which tests ran before
     with torch.device(dev):
         student = UNetModel(**bench.VC2_UNET)
     g = torch.Generator(device=dev).manual_seed(4321)
