@@ -240,6 +240,9 @@ def _new_student(cfg, dev, rank_r, seed=4321):
     """LoRA-injected student (fp32 master weights; zero-init tensors and the zero lora_up factors re-drawn: same on every rank)."""
     from t2v_turbo_amd import lora
     from t2v_turbo_amd.unet3d import UNetModel
+    torch.manual_seed(seed)             # the default initialisers draw from the global generators: the parity figures of the leg must
+    if dev.type == "cuda":              # not depend on what ran before it
+        torch.cuda.manual_seed_all(seed)
     with torch.device(dev):
         student = UNetModel(**cfg)
     g = torch.Generator(device=dev).manual_seed(seed)
