@@ -447,7 +447,7 @@ class _Engine:
         if not getattr(ops, "is_native", False):
             plan["fn"]()
             return
-        if plan.get("graph") is not None:
+        if self.use_graph and plan.get("graph") is not None:   # (use_graph switched off again: back to the plain loop)
             plan["graph"].replay()
             return
         if self.use_graph and plan["runs"] >= 1 and not plan.get("graph_failed"):

@@ -210,14 +210,14 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             plan["fn" if which == "rec" else "fn_bwd"]()
             return
         gkey, rkey = "graph_" + which, "runs_" + which
-        if plan.get(gkey) is not None:
+        if self.use_graph and plan.get(gkey) is not None:
             for g, host in plan[gkey]:      # graphs of the launch runs, host calls (all-reduce markers) between them
                 if g is not None:
                     g.replay()
                 else:
                     host[0](*host[1], None)
             return
-        if self.use_graph and plan.get(rkey, 0) >= 1 and not plan.get("graph_failed"):
+        if self.use_graph and plan.get(rkey, 0) >= 1 and not plan.get("graph_failed") and plan.get(gkey) is None:
             try:
                 # a list is cut at its host-side entries (the gradient exchange's segment markers): one hipGraph per run of
                 # launches, the host calls re-issued between the graph launches
