@@ -135,6 +135,23 @@ typedef struct t2v_gemm_desc {
     int lnf_ld, lnf_nblk;
     float lnf_eps;
     const float* lnf_s;
+    /* ---- LoRA branch in the base leaf's epilogue (NULL = off; fast kernels only: ask t2v_gemm_fuse_supported first) ------------
+     * lora_t [M][ld_lora_t] bf16: the rank-64 down-projections t_l = x (*) D_l of the leaves this launch's N columns belong to,
+     * leaf l (columns [l * lora_n_leaf, (l + 1) * lora_n_leaf)) at columns [64 l, 64 l + 64);  lora_u [N][ld_lora_u] bf16: row n
+     * = the up-projection row of output channel n (rank zero-padded to 64).  The launch then computes
+     *     out = epilogue( acc + bias + rowvec + residual + lora_scale * dropout( t_l u_n^T ) )
+     * i.e. LoraInjected*.forward (utils/lora.py:45-50,124-129,204-209) in ONE launch after the down-projection: the M x N
+     * up-projection z is never written or re-read.  With lora_t set, the drop_* fields mask the LoRA product only (drop_thr = 0:
+     * no dropout); the mask is t2v_dropout_bf16's over the [M][drop_ncols] matrix, so it is bit-identical to the three-launch form.
+     * lora_n_leaf % 32 == 0, no GEGLU / batch / split-K, alpha == 1, bf16 out.
+     * NOT YET RUN ON HARDWARE (written after round 3's GPU budget was spent): validated on the host SIMT simulator against the
+     * emulated backend (tests/test_hostsim_gemm_fuse.py); the engines use it only with T2V_LORA_EPILOGUE=1. */
+    const void* lora_t;
+    int ld_lora_t;
+    const void* lora_u;
+    int ld_lora_u;
+    int lora_n_leaf;
+    float lora_scale;
 } t2v_gemm_desc;
 
 int t2v_gemm(const t2v_gemm_desc* d, void* stream);

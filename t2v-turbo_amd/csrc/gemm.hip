@@ -289,6 +289,8 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
     // its epilogue pass and land under the mask arithmetic (~35 VALU per column pair).  The generic kernels, which carried every
     // dropout launch before, store 32-byte runs per lane and row.
     constexpr bool F_DRP = (FUSE & 8) != 0;
+    // F_LRA: the LoRA up-projection (rank 64) of the leaf as an MFMA phase of the epilogue: see t2v_gemm_desc::lora_t
+    constexpr bool F_LRA = (FUSE & 16) != 0;
     constexpr int NW = WM * WN;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -859,11 +861,45 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
             flush_slab<P, TN * 4>(st, lane, (bf16_t*)d.ln_out, d.ld_ln_out, m0 + wave_m * WTM, d.M, n0 + wave_n * WTN, d.N);
             return;
         }
+        // LoRA epilogue operands: the up-projection rows of a 32-column block as A fragments (rows in the accumulator's channel
+        // order: MFMA row r <-> channel 16 ((r >> 2) & 1) + 4 (r >> 3) + (r & 3) of the block, the permutation the weight tile's
+        // LDS rows carry), 4 K steps of 16 over the rank, straight from global memory (64 B per lane and block; the table is
+        // L2-resident).  Block j + 1 is fetched while block j is worked on (two register sets: the 160x320 tile has no room for five).
+        auto lra_load_u = [&](int j, bf16x8_t* dst) {
+            const int cperm = (((frow >> 2) & 1) << 4) | ((frow >> 3) << 2) | (frow & 3);
+            const int n = n0 + wave_n * WTN + j * 32 + cperm;
+            const bf16_t* up = (const bf16_t*)d.lora_u + (long long)min(n, d.N - 1) * d.ld_lora_u + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                uint4 u = *(const uint4*)(up + ks * 16);
+                if (n >= d.N) u = make_uint4(0, 0, 0, 0);
+                dst[ks] = *(bf16x8_t*)&u;
+            }
+        };
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int gm = m0 + wave_m * WTM + i * 32 + frow;
             asm volatile("" ::: "memory");
             float rs1[F_ROW ? TN : 1], rs2[F_ROW ? TN : 1];
+            // this slab's rank-64 rows t (B fragments: column = token); a wave tile spans at most two leaves of a group
+            bf16x8_t lra_t[F_LRA ? 2 : 1][4];
+            int lra_leaf0 = 0;
+            if constexpr (F_LRA) {
+                lra_leaf0 = (n0 + wave_n * WTN) / d.lora_n_leaf;
+                const int last = min(n0 + wave_n * WTN + WTN - 1, d.N - 1) / d.lora_n_leaf;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const bf16_t* tp = (const bf16_t*)d.lora_t + (long long)min(gm, d.M - 1) * d.ld_lora_t + (lra_leaf0 + q) * 64 + hi * 8;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        uint4 u = make_uint4(0, 0, 0, 0);
+                        if (gm < d.M && lra_leaf0 + q <= last) u = *(const uint4*)(tp + ks * 16);
+                        lra_t[q][ks] = *(bf16x8_t*)&u;
+                    }
+                }
+            }
+            bf16x8_t lra_u[2][4];
+            if constexpr (F_LRA) lra_load_u(0, lra_u[0]);
             uint4 rdrp[F_DRP ? TN : 1][2];
             if constexpr (F_DRP) {
 #pragma unroll
@@ -882,6 +918,32 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e];
                 if constexpr (F_LNF) ln_fold(v, j, lnr[i], lnrm[i]);
+                if constexpr (F_LRA) {   // v += lora_scale * dropout(t u^T): four MFMAs over the rank, mask on the product only
+                    f32x16_t lp;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) lp[e] = 0.f;
+                    const int q = (n0 + wave_n * WTN + j * 32) / d.lora_n_leaf - lra_leaf0;
+                    if (j + 1 < TN) lra_load_u(j + 1, lra_u[(j + 1) & 1]);
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        lp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lra_u[j & 1][ks], q ? lra_t[1][ks] : lra_t[0][ks], lp, 0, 0, 0);
+                    if (gm < d.M && ch_lane + j * 32 < d.N) {
+                        if (d.drop_thr) {
+                            const uint64_t seed = *(const uint64_t*)d.drop_seed;
+                            const uint64_t pair0 = ((uint64_t)gm * (uint64_t)d.drop_ncols + (uint64_t)(d.drop_col0 + ch_lane + j * 32)) >> 1;
+                            const float sk = d.lora_scale * d.drop_inv_keep;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const uint64_t b = dropout_bits(seed, d.drop_site, pair0 + k);
+                                if ((uint32_t)b >= d.drop_thr) v[2 * k] = fmaf(sk, lp[2 * k], v[2 * k]);
+                                if ((uint32_t)(b >> 32) >= d.drop_thr) v[2 * k + 1] = fmaf(sk, lp[2 * k + 1], v[2 * k + 1]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 16; ++e) v[e] = fmaf(d.lora_scale, lp[e], v[e]);
+                        }
+                    }
+                }
                 if constexpr (F_DRP) {   // keep(row, col) = the counter-based mask of t2v_dropout_bf16, then the residual tile
                     if (gm < d.M && ch_lane + j * 32 < d.N) {
                         const uint64_t seed = *(const uint64_t*)d.drop_seed;
@@ -1140,13 +1202,15 @@ int launch_fused(int fuse, GemmParams& p, hipStream_t s) {
         case 2: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 2>(p, s);
         case 4: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 4>(p, s);
         case 8: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 8>(p, s);
+        case 16: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 16>(p, s);
+        case 18: return launch_impl<BM, BN, WM, WN, STAGES, BK, WPE, true, false, false, 18>(p, s);   // + column statistics
         default: return T2V_EINVAL;
     }
 }
 }  // namespace
 // tiles with fused variants: one per workgroup-tile shape the tuned table uses for the UNet's norm producers / consumers
 int t2v_gemm_fuse_tile(int cfg, int act, int fuse) {
-    if (fuse == 4 && cfg == 19) cfg = 7;  // the 4-waves-per-SIMD 256x128 tile has no registers to spare for the fold: its 2-per-SIMD twin
+    if ((fuse == 4 || (fuse & 16)) && cfg == 19) cfg = 7;  // the 4-waves-per-SIMD 256x128 tile has no registers to spare for the fold / the LoRA epilogue: its 2-per-SIMD twin
     switch (cfg) {
         case 1: case 4: case 10: case 18: case 26: case 30: case 33: return 4;     // 128x128
         case 31: case 32: return act == T2V_ACT_GEGLU ? 4 : 31;                   // 128x128, eight waves (32-wide wave tiles: no GEGLU)
@@ -1364,21 +1428,28 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
     p.ws = (float*)d.ws;
     p.debug = g_debug;
     cfg_out = cfg;
-    fuse = (d.rowstat_out ? 1 : 0) | (d.colstat_out ? 2 : 0) | (d.lnf_stats ? 4 : 0);
+    fuse = (d.rowstat_out ? 1 : 0) | (d.colstat_out ? 2 : 0) | (d.lnf_stats ? 4 : 0) | (d.lora_t ? 16 : 0);
     // a dropout epilogue (the LoRA up-projections of the training path) rides on the fast kernels' staged epilogue where the launch
     // qualifies for them otherwise (FUSE bit 8 of gemm_fuse.hip); T2V_GEMM_FAST_DROPOUT=0: the generic kernels, as before round 3
     static const bool fast_dropout = !(getenv("T2V_GEMM_FAST_DROPOUT") && getenv("T2V_GEMM_FAST_DROPOUT")[0] == '0');
-    const bool auto_drop = !fuse && d.drop_thr && fast_dropout && !d.rowvec && d.act == T2V_ACT_NONE && !d.ln_out && d.batch == 1;
+    const bool auto_drop = !fuse && !d.lora_t && d.drop_thr && fast_dropout && !d.rowvec && d.act == T2V_ACT_NONE && !d.ln_out && d.batch == 1;
     if (auto_drop) fuse = 8;
     fuse_cfg = 0;
     fuse_ok = false;
     if (fuse) {
-        T2V_REQUIRE(fuse == 1 || fuse == 2 || fuse == 4 || fuse == 8, T2V_EINVAL, "t2v_gemm: one of rowstat_out / colstat_out / lnf_stats per launch");
+        T2V_REQUIRE(fuse == 1 || fuse == 2 || fuse == 4 || fuse == 8 || fuse == 16 || fuse == 18, T2V_EINVAL,
+                    "t2v_gemm: one of rowstat_out / colstat_out / lnf_stats per launch (lora_t alone or with colstat_out)");
+        if (fuse & 16)
+            T2V_REQUIRE(d.lora_u && d.lora_n_leaf > 0 && d.lora_n_leaf % 32 == 0 && d.N % d.lora_n_leaf == 0 && d.ld_lora_t % 8 == 0 &&
+                            d.ld_lora_u % 8 == 0 && d.ld_lora_u >= 64 && d.ld_lora_t >= 64 * (d.N / d.lora_n_leaf) &&
+                            (uintptr_t)d.lora_t % 16 == 0 && (uintptr_t)d.lora_u % 16 == 0 && d.act == T2V_ACT_NONE &&
+                            (!d.drop_thr || (d.drop_seed && d.drop_ncols % 2 == 0 && d.drop_col0 % 2 == 0)),
+                        T2V_ESHAPE, "t2v_gemm: lora_t: rank-64 rows [M][64 leaves], lora_u [N][64], N a multiple of lora_n_leaf (% 32), no activation");
         T2V_REQUIRE(!d.ln_out && d.batch == 1, T2V_EINVAL, "t2v_gemm: fused statistics: no batch, no LayerNorm second output");
         if (fuse == 1)
             T2V_REQUIRE(d.N % 32 == 0 && d.ld_rowstat >= d.N / 16 && d.ld_rowstat % 4 == 0 && (uintptr_t)d.rowstat_out % 16 == 0 &&
                             d.act == T2V_ACT_NONE, T2V_ESHAPE, "t2v_gemm: rowstat_out needs N % 32 == 0, ld_rowstat >= N / 16 (% 4), no activation");
-        if (fuse == 2)
+        if (fuse & 2)
             T2V_REQUIRE(d.M % 32 == 0 && d.N % 2 == 0 && (uintptr_t)d.colstat_out % 16 == 0 && d.act != T2V_ACT_GEGLU, T2V_ESHAPE,
                         "t2v_gemm: colstat_out needs M % 32 == 0");
         if (fuse == 4)
@@ -1389,7 +1460,7 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
                                     "row vector / dropout");
         fuse_cfg = t2v_gemm_fuse_tile(cfg, d.act, fuse);
         // the fused epilogue rides on the fast kernels of one K split; GEGLU needs a 64-wide wave tile (its value / gate pairs)
-        fuse_ok = fuse_cfg != 0 && p.splits == 1 && gemm_is_fast(p, fuse == 8) && !(d.act == T2V_ACT_GEGLU && kCfg[fuse_cfg].wtn < 64);
+        fuse_ok = fuse_cfg != 0 && p.splits == 1 && gemm_is_fast(p, fuse == 8 || (fuse & 16) != 0) && !(d.act == T2V_ACT_GEGLU && kCfg[fuse_cfg].wtn < 64);
         // the dropout epilogue moves to the fast kernels only where that keeps the launch on (a twin of) the tile the table chose
         // for it: measured per shape on MI355X (profiles/r03_student_gemm_fast_dropout.csv), 160x320 (id 28 -> 23) wins 20-35 %,
         // ids that map to a different workgroup tile or lose their register-staged prologue (18 -> 4, 29 -> 11) lose 5-45 %
@@ -1407,7 +1478,7 @@ extern "C" int t2v_gemm_fuse_supported(const t2v_gemm_desc* dd) {
     bool ok = false;
     const int rc = gemm_prepare(dd, p, cfg, fuse, fuse_cfg, ok);
     if (rc != T2V_OK) return rc;
-    return ((fuse & 7) && ok) ? 1 : 0;   // (bit 8 is the library's own choice for dropout launches, not a request)
+    return ((fuse & ~8) && ok) ? 1 : 0;   // (bit 8 is the library's own choice for dropout launches, not a request)
 }
 
 extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {

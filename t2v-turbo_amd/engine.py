@@ -412,7 +412,7 @@ class _Engine:
         return self.fuse_ln and wide_ok and tuple(norm.normalized_shape) == (C,) and norm.elementwise_affine
 
     def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto",
-             want_cs=True):
+             want_cs=True, extra=None, fallback=None):
         """3x3 / strided / upsampled / temporal conv of an Act (virtual concat allowed); ``w`` / ``bias`` override the
         module's packed forward weights (data-gradient convs pass the flipped / transposed pack and no bias).  With
         ``fuse_gn`` the launch also writes its output's column statistics for the GroupNorm that follows every conv of the UNet."""
@@ -429,10 +429,18 @@ class _Engine:
         out = self.buf(M, N, out_dtype)
         kw = dict(M=M, N=N, a1=x.p1, mode=mode, n_img=x.n_img, h=x.h, wd=x.w, frames=frames, bias=bias, rowvec=rowvec,
                   rowvec_div=rowvec_div, residual=residual)
+        zf = None
+        if extra is not None:   # (the gradient engine: the LoRA branch in this launch's epilogue; ``fallback`` builds it as a residual)
+            if self.ops.gemm_fuse_supported(x.parts[0], w, out, **kw, **extra):
+                kw.update(extra)
+            else:
+                zf, kw["residual"] = fallback()
         cs = self._colstat_for(x.parts[0], w, out, **kw) if want_cs else None
         if cs is not None:
             kw["colstat"] = cs
         self.ops.gemm(x.parts[0], w, out, **kw)
+        if zf is not None:
+            self.pool.put(zf)
         return Act(out, x.n_img, ho, wo, cs=[cs])
 
     # ---- plan management --------------------------------------------------------------------------------

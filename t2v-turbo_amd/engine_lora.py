@@ -64,6 +64,10 @@ class LoraTrainMixin:
     # all weight gradients of a LoRA group (dU per leaf, per-clip column sums, dD per input part) as ONE t2v_wgrad_tn_group launch
     # pair once the rank-r gradient exists, instead of one t2v_wgrad_tn pair each (T2V_GROUP_WGRAD=0)
     group_wgrad = os.environ.get("T2V_GROUP_WGRAD", "1") == "1"
+    # the LoRA branch's up-projection and dropout inside the base leaf's GEMM epilogue (t2v_gemm lora_* fields): two launches per
+    # leaf group instead of 2 + leaves, the M x N up-projection never in memory.  NOT YET RUN ON HARDWARE (built after round 3's GPU
+    # budget was spent; simulator- and emulation-validated): opt-in, T2V_LORA_EPILOGUE=1.
+    fuse_lora = os.environ.get("T2V_LORA_EPILOGUE", "0") == "1"
 
     # ---- binding ------------------------------------------------------------------------------------------------------
     def bind_lora(self, params):
@@ -122,7 +126,7 @@ class LoraTrainMixin:
             r, cin, n_out = down.shape[0], down.shape[1], up.shape[0]
             taps = down.numel() // (r * cin)
             rp, ce, npad = _pad(r, RP), _pad(cin, 64), _pad(n_out, 64)
-            n_lp += 2 * rp * taps * ce + n_out * rp + rp * npad + (taps * rp) ** 2 * (taps > 1)
+            n_lp += 2 * rp * taps * ce + n_out * rp * (2 if self.fuse_lora else 1) + rp * npad + (taps * rp) ** 2 * (taps > 1)
             n_e += n_out * rp + taps * rp * ce
         self.lp = torch.zeros(n_lp, dtype=self.adt, device=dev)
         self.lp_idx = torch.full((n_lp,), -1, dtype=torch.int32, device=dev)
@@ -265,6 +269,7 @@ class LoraTrainMixin:
             if perm is not None:
                 idx_u = idx_u[perm]                                              # packed row j <- original row perm[j]
             uf = _pad_to(idx_u, (n_out, rp))
+            g._uf_idx = getattr(g, "_uf_idx", []) + [uf]
             npad = _pad(n_out, 64)
             g.Uf.append(self._lp_alloc(uf))
             g.UT.append(self._lp_alloc(_pad_to(uf.t(), (rp, npad))))
@@ -288,6 +293,7 @@ class LoraTrainMixin:
             o = self.lora_off[id(down)]
             self.g_idx[o:o + down.numel()] = e.reshape(-1).to(self.device, torch.int32)
         g.Df = self._lp_alloc(torch.cat(df_rows, dim=0))
+        g.Ucat = self._lp_alloc(torch.cat(g._uf_idx, dim=0)) if self.fuse_lora else None   # [sum N][rp]: row n = leaf's up-projection row
         if taps > 1:
             # conv leaves: the data-gradient pack of D and the 0/1 selection pack of the gathered rank-r gradient stacked along N,
             # so ONE launch over g yields both (the selection's ones index the constant 1.0 behind the flat parameters)
@@ -312,8 +318,8 @@ class LoraTrainMixin:
     # ---- forward: z = residual + sum_i s_i (x (*) D_i) U_i^T ----------------------------------------------------------------
     row_kind = "rows"  # how torch orders the rows of the current Linear leaves ("rows" | "temporal" | "ctx"): mask replay in tests
 
-    def lora_z(self, grp, x, m_out, residual=None, frames=0, kind_meta=None, kind=None):
-        """x: Act (1 or 2 parts, channels padded to the group's ce).  Returns (z buffer to release, z view [m_out, sum N])."""
+    def lora_t(self, grp, x, m_out, frames=0, kind_meta=None, kind=None):
+        """The group's rank-r down-projections t = x (*) D [m_out, n * rp]; registers the dropout site, keeps x and t for the backward."""
         ops = self.ops
         nrp = grp.n * grp.rp
         t = self.buf(m_out, nrp)
@@ -321,9 +327,28 @@ class LoraTrainMixin:
             ops.gemm(x.parts[0], grp.Df, t, M=m_out, N=nrp, a1=x.p1)
         else:
             ops.gemm(x.parts[0], grp.Df, t, M=m_out, N=nrp, a1=x.p1, mode=grp.mode, n_img=x.n_img, h=x.h, wd=x.w, frames=frames)
+        grp.drop = self.drop_site([mm.dropout for mm in grp.mods], kind or (self.row_kind if grp.mode == nt.GEMM_LINEAR else "conv"), kind_meta)
+        self.hold(*x.parts)
+        grp.saved = (x, t)
+        return t
+
+    def lora_epilogue_args(self, grp):
+        """kwargs that make the base leaf's ``ops.gemm`` add the group's LoRA branch in its epilogue (t2v_gemm lora_*), or None
+        where the group does not fit that form (then: ``lora_up``)."""
+        if not self.fuse_lora or grp.Ucat is None or grp.rp != 64 or len(set(grp.N)) != 1 or grp.N[0] % 32 or len(set(grp.scale)) != 1:
+            return None
+        _, t = grp.saved
+        kw = {"lora": (t, grp.Ucat, grp.N[0], grp.scale[0])}
+        if grp.drop:
+            kw["dropout"] = (grp.drop[0], self.seed_t, grp.drop[1], grp.ntot, 0)
+        return kw
+
+    def lora_up(self, grp, m_out, residual=None):
+        """z = residual + sum_i s_i dropout(t_i U_i^T) as launches of their own.  Returns (z buffer to release, z view [m_out, sum N])."""
+        ops = self.ops
+        _, t = grp.saved
         zf = self.buf(m_out, _pad(grp.ntot, 8))
         z = zf[:, :grp.ntot]
-        grp.drop = self.drop_site([mm.dropout for mm in grp.mods], kind or (self.row_kind if grp.mode == nt.GEMM_LINEAR else "conv"), kind_meta)
         # train mode: dropout(up(down(x))) * scale (utils/lora.py:45-50), then the leaf's own residual.  The mask is the
         # up-projection's own epilogue (t2v_gemm dropout fields) instead of a separate read-modify-write pass over z
         # (442 launches and 23 GB per student forward); ``fuse_dropout = False`` keeps the two-kernel form (tests compare both).
@@ -337,9 +362,12 @@ class LoraTrainMixin:
             c0 += grp.N[i]
         if grp.drop and not fuse:
             ops.dropout(z, None if residual is None else residual[:, :grp.ntot], z, grp.ntot, grp.drop[0], self.seed_t, grp.drop[1])
-        self.hold(*x.parts)
-        grp.saved = (x, t)
         return zf, z
+
+    def lora_z(self, grp, x, m_out, residual=None, frames=0, kind_meta=None, kind=None):
+        """x: Act (1 or 2 parts, channels padded to the group's ce).  Returns (z buffer to release, z view [m_out, sum N])."""
+        self.lora_t(grp, x, m_out, frames, kind_meta, kind)
+        return self.lora_up(grp, m_out, residual)
 
     # ---- backward ---------------------------------------------------------------------------------------------------------
     def tposed(self, src, rows, cols, batch=1, in_stride=0):

@@ -390,19 +390,27 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         [mod]); ``perm``: packed output row j = original row perm[j] (GEGLU packing)."""
         x = a if isinstance(a, Act) else Act(a, 0, 0, 0)
         mods = lora if lora is not None else ([mod] if mod is not None else None)
-        zf = None
+        zf = grp = None
         if self.training_lora and mods and all(is_lora_leaf(mm) for mm in mods):
             assert act == nt.ACT_NONE
             meta = (self.B, self.F, x.M // (self.B * self.F)) if self.row_kind == "temporal" else (self.B, self.F, self.ctx_len)
             if conv_geom is not None:  # a 1x1 conv run as a linear layer: torch sees (n, C, h, w)
                 meta = conv_geom
-            zf, residual = self.lora_z(self.lgroup(mods, nt.GEMM_LINEAR, perm), x, x.M, residual, kind_meta=meta,
-                                       kind="conv" if conv_geom is not None else None)
+            grp = self.lgroup(mods, nt.GEMM_LINEAR, perm)
+            self.lora_t(grp, x, x.M, kind_meta=meta, kind="conv" if conv_geom is not None else None)
         w = self.pk.mat(mod) if w is None else w
         bias = self.pk.bias(mod) if isinstance(bias, str) else bias
         N = w.shape[0] if N is None else N
         out = self.buf(x.M, N // 2 if act == nt.ACT_GEGLU else N, out_dtype)
         kw = dict(M=x.M, N=N, a1=x.p1, bias=bias, residual=residual, act=act)
+        if grp is not None:
+            # the LoRA branch: inside this launch's epilogue where the launch can carry it, else as up-projection launches whose
+            # sum z becomes this launch's residual operand
+            extra = self.lora_epilogue_args(grp) if N == grp.ntot else None
+            if extra is not None and self.ops.gemm_fuse_supported(x.parts[0], w, out, **kw, **extra):
+                kw.update(extra)
+            else:
+                zf, kw["residual"] = self.lora_up(grp, x.M, residual)
         self.last_cs = self._colstat_for(x.parts[0], w, out, **kw) if want_cs else None   # (for the GroupNorm of the next block)
         if self.last_cs is not None:
             kw["colstat"] = self.last_cs
@@ -412,7 +420,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         return out
 
     def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto"):
-        zf = None
+        zf = extra = None
         if w is None and self.training_lora and is_lora_leaf(mod):
             if mode == nt.GEMM_CONV3X3_S2:
                 ho, wo = (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1
@@ -420,9 +428,14 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 ho, wo = 2 * x.h, 2 * x.w
             else:
                 ho, wo = x.h, x.w
-            zf, residual = self.lora_z(self.lgroup([mod], mode), x, x.n_img * ho * wo, residual, frames, kind_meta=(x.n_img, ho, wo))
+            grp = self.lgroup([mod], mode)
+            self.lora_t(grp, x, x.n_img * ho * wo, frames, kind_meta=(x.n_img, ho, wo))
+            extra = self.lora_epilogue_args(grp) if out_dtype in (None, self.adt) else None
+            if extra is None:
+                zf, residual = self.lora_up(grp, x.n_img * ho * wo, residual)
         y = super().conv(x, mod, mode, frames=frames, rowvec=rowvec, rowvec_div=rowvec_div, residual=residual,
-                         out_dtype=out_dtype, w=w, bias=bias, want_cs=w is None)   # (data-gradient convs pass their own pack: no statistics)
+                         out_dtype=out_dtype, w=w, bias=bias, want_cs=w is None,   # (data-gradient convs pass their own pack: no statistics)
+                         extra=extra, fallback=None if extra is None else (lambda: self.lora_up(grp, x.n_img * ho * wo, residual)))
         if zf is not None:
             self.pool.put(zf)
         return y

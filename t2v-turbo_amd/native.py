@@ -49,6 +49,8 @@ class GemmDesc(C.Structure):
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("ln_out", C.c_void_p), ("ld_ln_out", C.c_int),
         ("rowstat_out", C.c_void_p), ("ld_rowstat", C.c_int), ("colstat_out", C.c_void_p),
         ("lnf_stats", C.c_void_p), ("lnf_ld", C.c_int), ("lnf_nblk", C.c_int), ("lnf_eps", C.c_float), ("lnf_s", C.c_void_p),
+        ("lora_t", C.c_void_p), ("ld_lora_t", C.c_int), ("lora_u", C.c_void_p), ("ld_lora_u", C.c_int), ("lora_n_leaf", C.c_int),
+        ("lora_scale", C.c_float),
     ]
 
 
@@ -305,7 +307,9 @@ class HipOps:
         [M, ncols] matrix whose columns col0 .. col0 + N are this launch's output, applied to alpha*acc + bias before the
         residual (include/t2v_hip.h).  ``rowstat`` / ``colstat``: fp32 tensors that receive the row / column statistics of the
         output for the next LayerNorm / GroupNorm; ``lnf``: (producer's rowstat [M, ld], eps, s [N] fp32) — this launch consumes a
-        LayerNorm folded into its weights (t2v_gemm_desc::lnf_*).  Ask ``gemm_fuse_supported`` (same arguments) first."""
+        LayerNorm folded into its weights (t2v_gemm_desc::lnf_*); ``lora``: (t, u, columns per leaf, scale) — the rank-64 LoRA branch
+        of the leaf(s) added in the epilogue, ``dropout`` then masks that product only (t2v_gemm_desc::lora_*).  Ask
+        ``gemm_fuse_supported`` (same arguments) first."""
         self._call("t2v_gemm", C.byref(self._gemm_desc(a0, w, out, **kw)))  # the byref object holds a reference to d: a recording keeps its descriptors alive
 
     def gemm_fuse_supported(self, a0, w, out, **kw):
@@ -319,7 +323,7 @@ class HipOps:
     def _gemm_desc(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
                    rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
                    a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None, ln=None,
-                   rowstat=None, colstat=None, lnf=None):
+                   rowstat=None, colstat=None, lnf=None, lora=None):
         d = GemmDesc()
         d.a0, d.c0, d.lda0 = _p(a0), a0.shape[1], _row_stride(a0)
         if a1 is not None:
@@ -366,6 +370,11 @@ class HipOps:
             stats, eps, s_vec = lnf
             assert stats.dtype == torch.float32 and s_vec.dtype == torch.float32 and stats.shape[0] == M
             d.lnf_stats, d.lnf_ld, d.lnf_nblk, d.lnf_eps, d.lnf_s = _p(stats), _row_stride(stats), a0.shape[1] // 32, float(eps), _p(s_vec)
+        if lora is not None:   # (t [M, 64 leaves] bf16, u [N, 64] bf16, columns per leaf, scale): the LoRA branch in this launch's epilogue
+            t, u, n_leaf, scale = lora
+            assert t.dtype == torch.bfloat16 and u.dtype == torch.bfloat16 and t.shape[0] == M and u.shape[0] == N and u.shape[1] >= 64
+            d.lora_t, d.ld_lora_t, d.lora_u, d.ld_lora_u = _p(t), _row_stride(t), _p(u), _row_stride(u)
+            d.lora_n_leaf, d.lora_scale = int(n_leaf), float(scale)
         ws = self.workspace(a0.device)
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         return d

@@ -37,11 +37,12 @@ class EmuOps:
     def gemm(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
              rowvec=None, rowvec_div=0, residual=None, act=nt.ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
              a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None, ln=None,
-             rowstat=None, colstat=None, lnf=None):
+             rowstat=None, colstat=None, lnf=None, lora=None):
         self._log("gemm")
-        if rowstat is not None or colstat is not None or lnf is not None:
+        if rowstat is not None or colstat is not None or lnf is not None or lora is not None:
             assert self.gemm_fuse_supported(a0, w, out, M=M, N=N, a1=a1, mode=mode, bias=bias, rowvec=rowvec, residual=residual, act=act,
-                                            alpha=alpha, batch=batch, dropout=dropout, ln=ln, rowstat=rowstat, colstat=colstat, lnf=lnf)
+                                            alpha=alpha, batch=batch, dropout=dropout, ln=ln, rowstat=rowstat, colstat=colstat, lnf=lnf,
+                                            lora=lora)
         if ln is not None:
             assert batch == 1 and act == nt.ACT_NONE and alpha == 1.0, "LN output: no batch / activation / alpha (the device kernel: N == 320)"
         # device-side argument rules (csrc/gemm.hip, t2v_gemm): operand row strides, batch strides and base addresses
@@ -103,7 +104,18 @@ class EmuOps:
                 y = rstd[:, None] * (y - mean[:, None] * s_vec.float()[None, :N])
             if bias is not None:
                 y = y + bias.float()[None, :N]
-            if dropout is not None and dropout[0] > 0:  # the dropout epilogue of t2v_gemm: the mask of dropout() on its column block
+            if lora is not None:  # the LoRA branch of the leaf(s) in the epilogue: + scale * dropout(t_leaf u^T), the mask on that product only
+                t_l, u_l, n_leaf, sc = lora
+                z = torch.cat([t_l.float()[:, 64 * l:64 * l + 64] @ u_l.float()[l * n_leaf:(l + 1) * n_leaf, :64].t()
+                               for l in range(N // n_leaf)], dim=1)
+                if dropout is not None and dropout[0] > 0:
+                    p_drop, seed_t, site, ncols, col0 = dropout
+                    keep = self.dropout_keep(int(seed_t.reshape(-1)[0]), site, M, ncols, p_drop)
+                    if getattr(self, "masks", None) is not None:
+                        self.masks[site] = keep
+                    z = torch.where(keep[:, col0:col0 + N], z / (1.0 - p_drop), torch.zeros(()))
+                y = y + sc * z
+            elif dropout is not None and dropout[0] > 0:  # the dropout epilogue of t2v_gemm: the mask of dropout() on its column block
                 p_drop, seed_t, site, ncols, col0 = dropout
                 assert act == nt.ACT_NONE and batch == 1 and ncols % 2 == 0 and col0 % 2 == 0 and col0 + N <= ncols
                 keep = self.dropout_keep(int(seed_t.reshape(-1)[0]), site, M, ncols, p_drop)
@@ -132,9 +144,16 @@ class EmuOps:
                 out2[:, :N] = F.layer_norm(y, (N,), gamma.float(), beta.float(), eps).to(out2.dtype)
 
     def gemm_fuse_supported(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, bias=None, rowvec=None, residual=None,
-                            act=nt.ACT_NONE, alpha=1.0, batch=1, dropout=None, ln=None, rowstat=None, colstat=None, lnf=None, **_):
+                            act=nt.ACT_NONE, alpha=1.0, batch=1, dropout=None, ln=None, rowstat=None, colstat=None, lnf=None,
+                            lora=None, **_):
         """The argument rules of t2v_gemm_fuse_supported (csrc/gemm.hip) that do not depend on the tile: the emulated backend
         takes the fused form wherever the descriptor allows it, so that the CPU suite covers the dataflow at every width."""
+        if lora is not None:   # LoRA epilogue, alone or with column statistics; its dropout masks the LoRA product
+            t_l, u_l, n_leaf, _sc = lora
+            ok = (rowstat is None and lnf is None and batch == 1 and ln is None and alpha == 1.0 and act == nt.ACT_NONE and
+                  out.dtype == self.act_dtype and N % 16 == 0 and n_leaf % 32 == 0 and N % n_leaf == 0 and
+                  t_l.shape[1] >= 64 * (N // n_leaf) and u_l.shape[0] == N and u_l.shape[1] >= 64)
+            return ok and (colstat is None or M % 32 == 0)
         n_req = sum(x is not None for x in (rowstat, colstat, lnf))
         if n_req != 1 or batch != 1 or ln is not None or alpha != 1.0 or (dropout is not None and dropout[0] > 0):
             return False

@@ -167,6 +167,56 @@ def test_dropout_epilogue_on_the_fast_kernels(sim, cfg):
     assert rel_l2(o_s.float(), o_e) < BF16_TOL and float(o_s.float()[~k2].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cfg", FUSED_TILES)
+def test_lora_branch_in_the_base_leaf_epilogue(sim, cfg):
+    """t2v_gemm lora_* fields (csrc/gemm_fuse.hip, FUSE bit 16): y = x W^T + b + residual + s * dropout(t U^T) in ONE launch after the
+    rank-64 down-projection — LoraInjectedLinear.forward (utils/lora.py:45-50) without the M x N up-projection ever in memory.  A
+    three-leaf group (q | k | v: block-diagonal U, t of leaf l at columns [64 l, 64 l + 64)), the mask that of t2v_dropout_bf16
+    over the group's [M][3 N] matrix (bit-identical to the three-launch form), with and without dropout, with column statistics,
+    a 3x3 conv leaf with the time-embedding row vector; ragged M."""
+    M, K, C, p, site = 200, 128, 96, 0.25, 4
+    seed = torch.tensor([0x5EED_1234_ABCD], dtype=torch.int64)
+    N = 3 * C
+    x, w, b = _rt(M, K, seed=1), _rt(N, K, seed=2, scale=K ** -0.5), _rt(N, seed=3)
+    res = _rt(M, N, seed=4)
+    t = _rt(M, 3 * 64, seed=5, scale=0.5)
+    u = _rt(N, 64, seed=6, scale=0.2)
+    for drop in (None, (p, seed, site, N, 0)):
+        o_s, o_e = torch.full((M, N), float("nan"), dtype=torch.bfloat16), torch.zeros(M, N)
+        kw = dict(M=M, N=N, bias=b, dropout=drop)
+        lo_s, lo_e = (_bf(t), _bf(u), C, 0.5), (t, u, C, 0.5)
+        assert sim.gemm_fuse_supported(_bf(x), _bf(w), o_s, residual=_bf(res), lora=lo_s, tile_cfg=cfg, split_k=1, **kw)
+        sim.gemm(_bf(x), _bf(w), o_s, residual=_bf(res), lora=lo_s, tile_cfg=cfg, split_k=1, **kw)
+        EMU.gemm(x, w, o_e, residual=res, lora=lo_e, **kw)
+        assert torch.isfinite(o_s.float()).all() and rel_l2(o_s.float(), o_e) < BF16_TOL
+        # = the three-launch form of the engine: z = residual + dropout(t_l U_l^T) * s per leaf, then the base leaf with z as residual
+        z = torch.zeros(M, N)
+        for l in range(3):
+            EMU.gemm(t[:, 64 * l:64 * l + 64], u[l * C:(l + 1) * C], z[:, l * C:(l + 1) * C], M=M, N=C, alpha=0.5,
+                     residual=res[:, l * C:(l + 1) * C], dropout=None if drop is None else (p, seed, site, N, l * C))
+        o3 = torch.zeros(M, N)
+        EMU.gemm(x, w, o3, M=M, N=N, bias=b, residual=z)
+        assert rel_l2(o_e, o3) < 1e-5
+    # single leaf + column statistics for the GroupNorm that follows (the ResBlock convs): 3x3 conv, row vector, M = 128
+    n, h, wd, c0, Nc = 2, 8, 8, 64, 192
+    Mc = n * h * wd
+    xc, wc, bc, rv = _rt(Mc, c0, seed=11), _rt(Nc, 9 * c0, seed=12, scale=(9 * c0) ** -0.5), _rt(Nc, seed=13), _rt(n, Nc, seed=14)
+    tc, uc = _rt(Mc, 64, seed=15, scale=0.5), _rt(Nc, 64, seed=16, scale=0.2)
+    o_s, o_e = torch.full((Mc, Nc), float("nan"), dtype=torch.bfloat16), torch.zeros(Mc, Nc)
+    cs_s, cs_e = torch.full((Mc // 32, Nc, 2), float("nan")), torch.zeros(Mc // 32, Nc, 2)
+    kw = dict(M=Mc, N=Nc, mode=nt.GEMM_CONV3X3, n_img=n, h=h, wd=wd, bias=bc, rowvec_div=h * wd, dropout=(p, seed, 9, Nc, 0))
+    assert sim.gemm_fuse_supported(_bf(xc), _bf(wc), o_s, rowvec=rv, colstat=cs_s, lora=(_bf(tc), _bf(uc), Nc, 1.0), tile_cfg=cfg, **kw)
+    sim.gemm(_bf(xc), _bf(wc), o_s, rowvec=rv, colstat=cs_s, lora=(_bf(tc), _bf(uc), Nc, 1.0), tile_cfg=cfg, **kw)
+    EMU.gemm(xc, wc, o_e, rowvec=rv, colstat=cs_e, lora=(tc, uc, Nc, 1.0), **kw)
+    assert rel_l2(o_s.float(), o_e) < BF16_TOL
+    st = o_s.float().reshape(Mc // 32, 32, Nc)
+    assert rel_l2(cs_s, torch.stack([st.sum(1), (st * st).sum(1)], dim=2)) < 1e-5
+    keep = EMU.dropout_keep(int(seed[0]), 9, Mc, Nc, p)
+    o_plain = torch.zeros(Mc, Nc)
+    EMU.gemm(xc, wc, o_plain, rowvec=rv, **{k: v for k, v in kw.items() if k != "dropout"})
+    assert rel_l2(o_s.float()[~keep], o_plain[~keep]) < BF16_TOL      # dropped positions: the base leaf alone
+
+
 def test_unsupported_requests_are_refused_not_ignored(sim):
     M, N, K = 64, 64, 64
     a, w = _bf(_rt(M, K)), _bf(_rt(N, K))

@@ -367,3 +367,31 @@ def test_native_checkpointing_recomputes_the_same_function():
     assert b["pool"] < 0.6 * a["pool"], (a["pool"], b["pool"])
     assert a["n_fwd"] == b["n_fwd"] and b["n_bwd"] > a["n_bwd"] + 0.8 * a["n_fwd"]
     assert a["live"] == b["live"]       # nothing leaks from the discarded first forward of a block
+
+
+def test_lora_branch_in_the_base_leaf_epilogue_variant_of_the_engine():
+    """``fuse_lora`` (T2V_LORA_EPILOGUE=1): the up-projection and the dropout of every LoRA group ride in the base leaf's GEMM
+    epilogue (t2v_gemm lora_* fields) — two launches per group instead of 2 + leaves, no M x N up-projection in memory.  Train
+    mode: the masks are those of the three-launch form bit for bit, so output, d/d(latents) and every LoRA gradient agree with it
+    (fp32 emulation: to rounding), and with autograd through the torch module with the masks replayed."""
+    g = load("unet_tiny")
+    x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
+    r_out = torch.randn(x.shape, generator=torch.Generator().manual_seed(5))
+    res = {}
+    for fused in (False, True):
+        m, params = _student("unet_tiny", 64)
+        m.train()
+        eng = UNetGradEngine(m, EmuOps(strict=True))
+        eng.fuse_lora = fused
+        eng.bind_lora(params)
+        torch.manual_seed(3)
+        emb_all = m.conditioning_emb_all(ts, 16, tc, None).detach()
+        y = eng.forward_tape(x, ts, ctx, 16, tc, None, emb_all=emb_all, seed=77)
+        n_fwd = eng.ops.calls.count("gemm")
+        flat = torch.zeros(eng.lora_numel)
+        dx = eng.backward(r_out, flat_grad=flat, accumulate=False)
+        res[fused] = (y, dx, flat, n_fwd, len(eng.drop_sites))
+    a, b = res[False], res[True]
+    assert rel_l2(b[0], a[0]) < 1e-5 and rel_l2(b[1], a[1]) < 1e-4 and rel_l2(b[2], a[2]) < 1e-4
+    assert a[4] == b[4] > 100
+    assert b[3] < a[3] - 400, (a[3], b[3])          # one up-projection launch per leaf gone from the forward
