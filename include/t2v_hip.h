@@ -144,8 +144,9 @@ typedef struct t2v_gemm_desc {
      * up-projection z is never written or re-read.  With lora_t set, the drop_* fields mask the LoRA product only (drop_thr = 0:
      * no dropout); the mask is t2v_dropout_bf16's over the [M][drop_ncols] matrix, so it is bit-identical to the three-launch form.
      * lora_n_leaf % 32 == 0, no GEGLU / batch / split-K, alpha == 1, bf16 out.
-     * NOT YET RUN ON HARDWARE (written after round 3's GPU budget was spent): validated on the host SIMT simulator against the
-     * emulated backend (tests/test_hostsim_gemm_fuse.py); the engines use it only with T2V_LORA_EPILOGUE=1. */
+     * Validated on the host SIMT simulator (tests/test_hostsim_gemm_fuse.py) and, in the last seconds of round 3's GPU budget, on
+     * MI355X (tests/test_gpu_gemm_fuse.py at the UNet's shapes; the gradient engine at tiny width against the reference's LoRA
+     * gradients and with replayed train-mode masks).  NOT YET TIMED: the engines use it only with T2V_LORA_EPILOGUE=1. */
     const void* lora_t;
     int ld_lora_t;
     const void* lora_u;

@@ -190,3 +190,33 @@ def test_fused_feed_forward(hip, C, M):
     hip.ffn_fused(x.cuda(), *pk, 1e-5, out2)
     torch.cuda.synchronize()
     assert torch.equal(out2, out_h)
+
+
+def _dv(t):
+    return None if t is None else t.bfloat16().cuda().contiguous()
+
+
+@pytest.mark.parametrize("M,K,C,leaves", [(40960, 320, 320, 3), (40960, 320, 320, 1), (10240, 640, 640, 1), (2560, 1280, 1280, 3), (1000, 128, 96, 3)])
+def test_lora_branch_in_the_base_leaf_epilogue(hip, M, K, C, leaves):
+    """t2v_gemm lora_* fields (FUSE bit 16): y = x W^T + b + residual + s * dropout(t U^T) in one launch, one- and three-leaf groups at
+    the UNet's shapes, with and without the dropout mask, against the emulation; deterministic.  First run on MI355X in the last
+    seconds of round 3's GPU budget (tools/r3_gpu_calls/r3_call22.sh): green."""
+    N, p, site = leaves * C, 0.1, 4
+    seed = torch.tensor([0x5EED_1234_ABCD], dtype=torch.int64)
+    x, w, b = _rt(M, K, seed=1), _rt(N, K, seed=2, scale=K ** -0.5), _rt(N, seed=3)
+    res, t, u = _rt(M, N, seed=4), _rt(M, leaves * 64, seed=5, scale=0.5), _rt(N, 64, seed=6, scale=0.2)
+    for drop in (None, (p, seed, site, N, 0)):
+        o_h, o_e = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda"), torch.zeros(M, N)
+        kw = dict(M=M, N=N, bias=b)
+        drop_h = None if drop is None else (p, seed.cuda(), site, N, 0)
+        lo_h = (_dv(t), _dv(u), C, 0.5)
+        assert hip.gemm_fuse_supported(_dv(x), _dv(w), o_h, residual=_dv(res), lora=lo_h, bias=b.cuda(), M=M, N=N, dropout=drop_h)
+        hip.gemm(_dv(x), _dv(w), o_h, residual=_dv(res), lora=lo_h, bias=b.cuda(), M=M, N=N, dropout=drop_h)
+        EMU.gemm(x, w, o_e, residual=res, lora=(t, u, C, 0.5), dropout=drop, **kw)
+        torch.cuda.synchronize()
+        got = o_h.float().cpu()
+        assert torch.isfinite(got).all() and rel_l2(got, o_e) < BF16_TOL, (drop is not None, rel_l2(got, o_e))
+        o2 = torch.zeros_like(o_h)
+        hip.gemm(_dv(x), _dv(w), o2, residual=_dv(res), lora=lo_h, bias=b.cuda(), M=M, N=N, dropout=drop_h)
+        torch.cuda.synchronize()
+        assert torch.equal(o2, o_h)

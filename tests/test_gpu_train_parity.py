@@ -198,6 +198,16 @@ def test_train_mode_student_on_device_with_replayed_masks():
     run_train_mode_with_replayed_masks("cuda", HipOps(), OUT_TOL, DX_TOL, 0.985, 0.12)
 
 
+def test_train_mode_student_with_the_lora_branch_in_the_gemm_epilogue(monkeypatch):
+    """The same gate with ``fuse_lora`` (T2V_LORA_EPILOGUE=1): every LoRA group's up-projection and dropout inside the base leaf's GEMM
+    epilogue (t2v_gemm lora_*).  Ran green on MI355X in this form at the very end of round 3 (tools/r3_gpu_calls/r3_call23.sh: out
+    2.3e-2, d/d(latents) 4.0e-2, LoRA cosine min 0.9977); not yet timed, hence not the default."""
+    from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
+    from t2v_turbo_amd.native import HipOps
+    monkeypatch.setattr(UNetGradEngine, "fuse_lora", True)
+    run_train_mode_with_replayed_masks("cuda", HipOps(), OUT_TOL, DX_TOL, 0.985, 0.12)
+
+
 def run_train_mode_with_replayed_masks(dev, ops, out_tol, dx_tol, cos_min, ratio_tol):
     import copy
     from t2v_turbo_amd import lora
