@@ -160,6 +160,21 @@ int t2v_gemm(const t2v_gemm_desc* d, void* stream);
  * split-K factor exactly as the launch does: fast kernel, one K split, a tile that carries the fused epilogue), 0 if the
  * caller has to use the standalone normalisation kernels, negative on an invalid descriptor.  Launches nothing. */
 int t2v_gemm_fuse_supported(const t2v_gemm_desc* d);
+/* 3x3 convolution (stride 1, pad 1) with the activation tile's halo slab RESIDENT in LDS across all nine filter taps
+ * (csrc/conv_halo.hip): same descriptor as t2v_gemm (mode T2V_GEMM_CONV3X3, virtual concat allowed; no batch / split-K /
+ * dropout / GEGLU / fp32 output; epilogue: bias, rowvec, residual, SiLU, colstat_out), EXCEPT that `w` holds the SLAB-MAJOR pack:
+ * K order (32-channel sub-slab, tap, channel) = [N][C/32][9][32] instead of t2v_gemm's tap-major [N][9][C] — one
+ * (sub-slab, tap) pair is 64 contiguous bytes of a weight row, a stage of pairs one contiguous run — with every row zero-padded
+ * to t2v_conv_halo_pack_cols(C) elements (ldw >= that).  Replaces the same reference call sites as t2v_gemm's 3x3 mode
+ * (openaimodel3d.py:155-159,179-184).  tile_cfg 40 / 41 / 42 / 43 force the 320x160 / 320x80 / 160x80 (16-wide grid) / 160x80
+ * (32-wide grid) workgroup tile (tokens x channels), anything else lets the library choose by grid fill.
+ * t2v_conv_halo_supported: 0 = not taken (use t2v_gemm with the tap-major pack), 1 = taken; negative = invalid descriptor.
+ * Launches nothing. */
+int t2v_conv_halo(const t2v_gemm_desc* d, void* stream);
+int t2v_conv_halo_supported(const t2v_gemm_desc* d);
+int t2v_conv_halo_pack_cols(int channels);
+int t2v_conv_halo_force_config(int cfg);
+int t2v_conv_halo_debug(int bits);   /* ablation bits; honoured by -DT2V_HALO_ABLATE tool builds only */
 /* tuning/test hooks: override tile id / split-K factor for every following call (0 = off) */
 int t2v_gemm_force_config(int cfg);
 int t2v_gemm_force_split(int splits);

@@ -168,6 +168,10 @@ class Packer:
             return w.reshape(w.shape[0], -1).to(self.device, self.wdtype).contiguous()
         return self._memo(("conv", id(mod)), make)
 
+    def conv_slab(self, mod):
+        """Slab-major pack of a 3x3 conv for t2v_conv_halo: [N][C/32][9][32], rows zero-padded to whole weight stages (native.pack_conv_slab)."""
+        return self._memo(("conv_slab", id(mod)), lambda: nt.pack_conv_slab(self.conv(mod)))
+
     def mat_t(self, mod):
         """[K, N]^T pack of a Linear / 1x1 conv: the weight of its data gradient (dx = dy @ W)."""
         def make():
@@ -341,6 +345,7 @@ class _Engine:
     # to the standalone statistics passes / LayerNorm launches.
     fuse_gn = False
     fold_ln = False
+    conv_halo = os.environ.get("T2V_CONV_HALO", "1") == "1"   # 3x3 convs on t2v_conv_halo where it takes them (0: always t2v_gemm)
     # Measured on MI355X (profiles/r03_fuse_ab.csv): the fold pays where the consuming GEMM is as wide as the rows it normalises
     # (the text cross-attention's q: +1.2 / +1.9 / +2.6 us on the launch and +2.3 / +0.7 / +0.4 us on the producer against a
     # 13.8 / 8.7 / 8.3 us LayerNorm at the three levels) and LOSES on the wide consumers — q|k|v (+17 us at the 320-channel
@@ -416,6 +421,7 @@ class _Engine:
         """3x3 / strided / upsampled / temporal conv of an Act (virtual concat allowed); ``w`` / ``bias`` override the
         module's packed forward weights (data-gradient convs pass the flipped / transposed pack and no bias).  With
         ``fuse_gn`` the launch also writes its output's column statistics for the GroupNorm that follows every conv of the UNet."""
+        own_w = w is None
         w = self.pk.conv(mod) if w is None else w
         bias = self.pk.bias(mod) if isinstance(bias, str) else bias
         N = w.shape[0]
@@ -429,6 +435,24 @@ class _Engine:
         out = self.buf(M, N, out_dtype)
         kw = dict(M=M, N=N, a1=x.p1, mode=mode, n_img=x.n_img, h=x.h, wd=x.w, frames=frames, bias=bias, rowvec=rowvec,
                   rowvec_div=rowvec_div, residual=residual)
+        # 3x3 convs whose width fills whole 80-channel tiles go to the halo-slab kernel (csrc/conv_halo.hip: the activation tile and
+        # its halo stay in LDS across the nine taps; 14-32 % faster than the tuned t2v_gemm tiles at the UNet's three upper levels,
+        # profiles/r04_conv_halo_v3_static_schedule.csv) when the launch has the module's own weights and a plain epilogue
+        if (self.conv_halo and own_w and extra is None and mode == nt.GEMM_CONV3X3 and N % 80 == 0 and hasattr(self.ops, "conv_halo_supported")
+                and out.dtype == self.adt):
+            ws = self.pk.conv_slab(mod)
+            cs = None
+            if want_cs and self.fuse_gn and M % 32 == 0:
+                cs = self.buf(M // 32, 2 * N, torch.float32)
+                if not self.ops.conv_halo_supported(x.parts[0], ws, out, colstat=cs, **kw):
+                    self.pool.put(cs)
+                    cs = None
+            if cs is not None or self.ops.conv_halo_supported(x.parts[0], ws, out, **kw):
+                if cs is not None:
+                    self.pool.link(out, cs)
+                    kw["colstat"] = cs
+                self.ops.conv_halo(x.parts[0], ws, out, **kw)
+                return Act(out, x.n_img, ho, wo, cs=[cs])
         zf = None
         if extra is not None:   # (the gradient engine: the LoRA branch in this launch's epilogue; ``fallback`` builds it as a residual)
             if self.ops.gemm_fuse_supported(x.parts[0], w, out, **kw, **extra):

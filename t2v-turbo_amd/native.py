@@ -60,12 +60,44 @@ class NativeError(RuntimeError):
 
 _lib = None
 
+
+def conv_halo_pack_cols(channels):
+    """Columns of a slab-major pack row for ``channels`` input channels: an even number of 4-pair weight stages (t2v_conv_halo_pack_cols)."""
+    return ((channels // 32 * 9 + 7) // 8) * 8 * 32
+
+
+def pack_conv_slab(w_tap_major, taps=9):
+    """[N, 9 * C] tap-major 3x3 conv weights (``Packer.conv``) -> the K order of t2v_conv_halo: (32-channel sub-slab, tap, channel),
+    i.e. [N][C / 32][9][32] flattened — one (sub-slab, tap) pair is 64 contiguous bytes of every row — zero-padded to
+    ``conv_halo_pack_cols`` columns (whole weight stages: the kernel multiplies the padding pairs by finite rows)."""
+    n, k = w_tap_major.shape
+    c = k // taps
+    assert taps == 9 and c * taps == k and c % 32 == 0
+    w = w_tap_major.reshape(n, taps, c // 32, 32).permute(0, 2, 1, 3).reshape(n, k)
+    cols = conv_halo_pack_cols(c)
+    out = w.new_zeros(n, cols)
+    out[:, :k] = w
+    return out
+
+
+def unpack_conv_slab(w_slab_major, channels, taps=9):
+    """Inverse of ``pack_conv_slab`` (drops the padding)."""
+    n = w_slab_major.shape[0]
+    k = taps * channels
+    return w_slab_major[:, :k].reshape(n, channels // 32, taps, 32).permute(0, 2, 1, 3).reshape(n, k).contiguous()
+
+
 _SIGS = {
     "t2v_version": (C.c_int, []),
     "t2v_init": (C.c_int, []),
     "t2v_last_error": (C.c_char_p, []),
     "t2v_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "t2v_gemm_fuse_supported": (C.c_int, [C.POINTER(GemmDesc)]),
+    "t2v_conv_halo": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "t2v_conv_halo_supported": (C.c_int, [C.POINTER(GemmDesc)]),
+    "t2v_conv_halo_force_config": (C.c_int, [C.c_int]),
+    "t2v_conv_halo_debug": (C.c_int, [C.c_int]),
+    "t2v_conv_halo_pack_cols": (C.c_int, [C.c_int]),
     "t2v_gemm_force_config": (C.c_int, [C.c_int]),
     "t2v_gemm_force_split": (C.c_int, [C.c_int]),
     "t2v_gemm_num_configs": (C.c_int, []),
@@ -311,6 +343,18 @@ class HipOps:
         of the leaf(s) added in the epilogue, ``dropout`` then masks that product only (t2v_gemm_desc::lora_*).  Ask
         ``gemm_fuse_supported`` (same arguments) first."""
         self._call("t2v_gemm", C.byref(self._gemm_desc(a0, w, out, **kw)))  # the byref object holds a reference to d: a recording keeps its descriptors alive
+
+    def conv_halo(self, a0, w, out, **kw):
+        """3x3 / (3,1,1) conv on the halo-slab kernel (csrc/conv_halo.hip): same arguments as ``gemm`` except that ``w`` is the
+        SLAB-MAJOR pack ``pack_conv_slab`` makes ([N][C/32][9][32], zero-padded to whole weight stages).  Ask ``conv_halo_supported`` first."""
+        self._call("t2v_conv_halo", C.byref(self._gemm_desc(a0, w, out, **kw)))
+
+    def conv_halo_supported(self, a0, w, out, **kw):
+        """0: not taken by the halo kernel (use ``gemm`` with the tap-major pack); 1: taken."""
+        rc = self.lib.t2v_conv_halo_supported(C.byref(self._gemm_desc(a0, w, out, **kw)))
+        if rc < 0:
+            _check(rc, "t2v_conv_halo_supported")
+        return rc
 
     def gemm_fuse_supported(self, a0, w, out, **kw):
         """Would ``gemm`` with these arguments honour its rowstat / colstat / lnf request?  (Resolves tile and split-K as the

@@ -143,6 +143,65 @@ class EmuOps:
                 gamma, beta, eps, out2 = ln
                 out2[:, :N] = F.layer_norm(y, (N,), gamma.float(), beta.float(), eps).to(out2.dtype)
 
+    # ---- t2v_conv_halo: the same 3x3 convolution on the slab-major weight pack (csrc/conv_halo.hip) ----------------------------
+    HALO_TILES = ((10, 32, 160, 4), (10, 32, 80, 4), (10, 16, 80, 8), (5, 32, 80, 8))   # (rows, columns, channels, pairs per stage pair)
+
+    def conv_halo_supported(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
+                            rowvec=None, rowvec_div=0, residual=None, act=nt.ACT_NONE, alpha=1.0, batch=1, tile_cfg=0, split_k=0,
+                            dropout=None, ln=None, rowstat=None, colstat=None, lnf=None, lora=None, **_):
+        """Mirror of halo_prepare (csrc/conv_halo.hip): 0 not taken, 1 taken."""
+        if mode != nt.GEMM_CONV3X3 or batch > 1 or alpha != 1.0 or out.dtype not in (self.act_dtype, torch.bfloat16) or split_k > 1:
+            return 0
+        if dropout is not None or ln is not None or rowstat is not None or lnf is not None or lora is not None or act not in (nt.ACT_NONE, nt.ACT_SILU):
+            return 0
+        c0, c1 = a0.shape[1], (0 if a1 is None else a1.shape[1])
+        if c0 % 64 or c1 % 64 or N % 16:
+            return 0
+        assert w.shape[1] >= nt.conv_halo_pack_cols(c0 + c1), "slab-major pack narrower than conv_halo_pack_cols"
+        U, V = h, wd
+        pick = tile_cfg - 39 if 40 <= tile_cfg < 44 else 0
+        best, best_id = -1.0, 0
+        for i, (S, fx, bn, _) in enumerate(self.HALO_TILES, start=1):
+            if pick and i != pick:
+                continue
+            if V % fx or (fx == 16 and V >= 32) or S >= 2 * U:
+                continue
+            tiles = n_img * ((U + S - 1) // S) * (V // fx) * ((N + bn - 1) // bn)
+            rounds = (tiles + 255) // 256
+            eff = tiles / (256.0 * rounds) * U / (((U + S - 1) // S) * S) * N / (((N + bn - 1) // bn) * bn)
+            score = 2.0 + S * fx * bn * 1e-6 if eff >= 0.85 else eff
+            if score > best:
+                best, best_id = score, i
+        if not best_id:
+            return 0
+        S, fx, _, _ = self.HALO_TILES[best_id - 1]
+        if colstat is not None:
+            if U % S or M % 32 or N % 2:
+                return 0
+            if fx == 16 and (V != 16 or S % 2 or (U * V) % 32):
+                return 0
+        return 1
+
+    def conv_halo(self, a0, w, out, **kw):
+        self._log("conv_halo")
+        assert self.conv_halo_supported(a0, w, out, **kw), "t2v_conv_halo would refuse this launch"
+        cin = a0.shape[1] + (0 if kw.get("a1") is None else kw["a1"].shape[1])
+        assert not w[:, 9 * cin:].any(), "the padding columns of a slab-major pack must be zero"
+        colstat = kw.pop("colstat", None)
+        kw.pop("tile_cfg", None)
+        residual, act = kw.pop("residual", None), kw.pop("act", nt.ACT_NONE)
+        if residual is None:
+            self.gemm(a0, nt.unpack_conv_slab(w, cin), out, act=act, **kw)
+        else:   # the kernel adds the residual to the tile it has already rounded to the output dtype (as the reference's `skip + h` does)
+            self.gemm(a0, nt.unpack_conv_slab(w, cin), out, **kw)
+            M, N = kw["M"], kw["N"]
+            y = out[:M, :N].float() + residual[:M, :N].float()
+            out[:M, :N] = (F.silu(y) if act == nt.ACT_SILU else y).to(out.dtype)
+        if colstat is not None:
+            M, N = kw["M"], kw["N"]
+            yo = out[:M, :N].float().reshape(M // 32, 32, N)
+            colstat.view(M // 32, N, 2).copy_(torch.stack([yo.sum(dim=1), (yo * yo).sum(dim=1)], dim=2))
+
     def gemm_fuse_supported(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, bias=None, rowvec=None, residual=None,
                             act=nt.ACT_NONE, alpha=1.0, batch=1, dropout=None, ln=None, rowstat=None, colstat=None, lnf=None,
                             lora=None, **_):

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "t2v-turbo_amd", "csrc")
 SOURCES = ["backward.hip", "backward_unet.hip", "train.hip", "wgrad_tn.hip"]
-GEMM_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip"]   # MFMA + LDS-DMA: simulated as wave collectives (separate, slower-to-build library)
+GEMM_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip"]   # MFMA + LDS-DMA: simulated as wave collectives (separate, slower-to-build library)
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libt2v_hostsim.so")
 GEMM_LIB = os.path.join(OUT, "libt2v_hostsim_gemm.so")
@@ -69,7 +69,7 @@ def build_gemm(force=False):
     return GEMM_LIB
 
 
-FULL_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip"]
+FULL_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip"]
 FULL_LIB = os.path.join(OUT, "libt2v_hostsim_full.so")
 
 

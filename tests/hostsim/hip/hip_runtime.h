@@ -235,6 +235,21 @@ inline void glds(const void* gsrc, void* lds_wave_base, int size, int offset) {
     const int lane = s.fibers[s.cur].flat % 64;
     memcpy((char*)lds_wave_base + (size_t)lane * size + offset, gsrc, size);
 }
+// buffer_load_dwordx4 ... offen lds (raw buffer form): lane copies `size` bytes from base + voffset + soffset + offset, or ZEROS when
+// that range leaves [0, num_records) — the hardware's out-of-range rule for raw buffers, which the kernels use instead of a zero page.
+struct BufferRsrc { const char* base; unsigned num_records; };
+inline BufferRsrc make_buffer_rsrc(const void* p, int stride, unsigned num_records, unsigned flags) {
+    (void)stride; (void)flags;
+    return BufferRsrc{(const char*)p, num_records};
+}
+inline void buffer_lds(BufferRsrc r, void* lds_wave_base, int size, unsigned voffset, unsigned soffset, int offset) {
+    State& s = st();
+    const int lane = s.fibers[s.cur].flat % 64;
+    char* dst = (char*)lds_wave_base + (size_t)lane * size;
+    const unsigned long long off = (unsigned long long)voffset + soffset + (unsigned)offset;
+    if (off + (unsigned)size <= r.num_records) memcpy(dst, r.base + off, size);
+    else memset(dst, 0, size);
+}
 inline void wave_rendezvous() {
     State& s = st();
     const int w = s.fibers[s.cur].flat / 64;
@@ -380,6 +395,9 @@ inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess
 #define __builtin_amdgcn_exp2f exp2f
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) hostsim::glds((const void*)(g), (void*)(l), (size), (off))
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hostsim::mfma_32x32x16_bf16((a), (b), (c))
+#define __amdgpu_buffer_rsrc_t hostsim::BufferRsrc
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) hostsim::make_buffer_rsrc((const void*)(p), (stride), (num), (flags))
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds(r, l, size, voff, soff, off, aux) hostsim::buffer_lds((r), (void*)(l), (size), (voff), (soff), (off))
 
 #define threadIdx (hostsim::st().fibers[hostsim::st().cur].tid)
 #define blockIdx (hostsim::st().bid)

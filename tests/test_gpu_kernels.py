@@ -510,3 +510,64 @@ def test_gemm_layernorm_second_output(pair, M, K, res):
     assert torch.isfinite(ln_h.float()).all()
     assert rel_l2(ln_h.float().cpu(), ln_e) < BF16_TOL
     assert rel_l2(ln_h.float().cpu(), ln_p.float().cpu()) < 2e-2   # LN of the bf16-rounded stream: the rounding of x shows when |mean| >> std
+
+
+# ---------------------------------------------------------------------------------- t2v_conv_halo (csrc/conv_halo.hip)
+def _halo_case(pair, *, n_img, h, w, c0, N, c1=0, cfg=0, rowvec=False, residual=False, act=0, colstat=False, seed=0, repeat=1):
+    """3x3 conv on the halo-slab kernel (slab-major pack) against the emulated conv on the same bf16-rounded data; with a residual
+    both add it to the bf16-rounded product (the kernel's row pass; tests/emu_ops.py::conv_halo)."""
+    from t2v_turbo_amd import native as nt
+    M, K = n_img * h * w, 9 * (c0 + c1)
+    a0 = _rt(M, c0, seed=seed)
+    a1 = _rt(M, c1, seed=seed + 1) if c1 else None
+    wt = nt.pack_conv_slab(_rt(N, K, seed=seed + 2, scale=K ** -0.5))
+    b, rv, res = _rt(N, seed=seed + 3), (_rt(n_img, N, seed=seed + 4) if rowvec else None), (_rt(M, N, seed=seed + 5) if residual else None)
+    outs, stats = [], []
+    for side, ops in enumerate((pair.hip, pair.emu)):
+        cvt = (lambda t: None if t is None else t.cuda().bfloat16().contiguous()) if side == 0 else (lambda t: None if t is None else t.clone())
+        f32 = (lambda t: None if t is None else t.cuda().float().contiguous()) if side == 0 else (lambda t: None if t is None else t.clone())
+        dev = "cuda" if side == 0 else "cpu"
+        out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16 if side == 0 else torch.float32)
+        cs = torch.full((M // 32, N, 2), float("nan"), device=dev) if colstat else None
+        kw = dict(M=M, N=N, a1=cvt(a1), mode=nt.GEMM_CONV3X3, n_img=n_img, h=h, wd=w, bias=f32(b), rowvec=f32(rv), rowvec_div=h * w if rowvec else 0,
+                  residual=cvt(res), act=act, tile_cfg=cfg)
+        if colstat:
+            kw["colstat"] = cs
+        x0, ww = cvt(a0), cvt(wt)
+        assert ops.conv_halo_supported(x0, ww, out, **kw) == 1
+        for _ in range(repeat if side == 0 else 1):
+            ops.conv_halo(x0, ww, out, **kw)
+        if side == 0:
+            torch.cuda.synchronize()
+        outs.append(out.float().cpu())
+        stats.append(None if cs is None else cs.cpu())
+    y, r = outs
+    assert torch.isfinite(y).all()
+    assert rel_l2(y, r) < BF16_TOL, rel_l2(y, r)
+    if colstat:   # of the bf16 values the kernel itself stored
+        yo = y.reshape(M // 32, 32, N)
+        want = torch.stack([yo.sum(dim=1), (yo * yo).sum(dim=1)], dim=2)
+        assert torch.allclose(stats[0], want, rtol=1e-4, atol=2e-3), (stats[0] - want).abs().max()
+
+
+@pytest.mark.parametrize("cfg", [40, 41, 43])
+def test_conv_halo_tiles_32_wide(pair, cfg):
+    # 20x32 grid, 320 -> 160 channels: 10 sub-slabs = 45 / 45 / 23 weight stages: the DMA ring wraps many times, the loaders run
+    # ahead past the end; residual row pass, row vector, column statistics
+    _halo_case(pair, n_img=4, h=20, w=32, c0=320, N=160, cfg=cfg, rowvec=True, residual=True, colstat=True, seed=cfg)
+
+
+def test_conv_halo_16_wide_whole_frames(pair):
+    _halo_case(pair, n_img=6, h=10, w=16, c0=640, N=160, cfg=42, rowvec=True, residual=True, colstat=True, seed=7)
+
+
+def test_conv_halo_virtual_concat_ragged_and_silu(pair):
+    _halo_case(pair, n_img=2, h=12, w=64, c0=128, c1=192, N=80, cfg=41, act=2, seed=8)      # ragged rows, two tile columns
+    _halo_case(pair, n_img=2, h=20, w=32, c0=64, c1=256, N=48, cfg=40, residual=True, seed=9)   # ragged channel tile
+
+
+def test_conv_halo_unet_level_shapes_repeatable(pair):
+    # the three levels at full size (one frame pair each), library's own tile choice; 3 back-to-back launches into the same output
+    _halo_case(pair, n_img=2, h=40, w=64, c0=320, N=320, rowvec=True, residual=True, colstat=True, seed=10, repeat=3)
+    _halo_case(pair, n_img=2, h=20, w=32, c0=1280, c1=640, N=640, colstat=True, seed=11, repeat=3)
+    _halo_case(pair, n_img=2, h=10, w=16, c0=1280, N=1280, rowvec=True, residual=True, colstat=True, seed=12, repeat=3)

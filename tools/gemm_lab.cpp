@@ -8,7 +8,7 @@
 //     lib    index into T2V_LAB_LIBS (colon-separated .so paths; default: the product library)
 //     mode   T2V_GEMM_* (0 linear: M = nimg*h*w rows, 1 conv3x3, 4 tconv3)
 //     act    0 none, 1 GEGLU, 2 SiLU;  res / rv: 1 = residual operand / time-embedding row vector present
-//     cfg    tile id (0 = library heuristic), split = split-K factor (0 = heuristic), debug = ablation bits (ablate builds)
+//     cfg    tile id (0 = library heuristic; 39 = t2v_conv_halo with its own choice, 40..42 = t2v_conv_halo tiles), split = split-K factor (0 = heuristic), debug = ablation bits (ablate builds)
 // Output: one CSV row per experiment: name, M, N, K, cfg, split, debug, us (best of 3 runs of `iters` back-to-back launches),
 // TFLOP/s, max |err| / tolerance of 256 sampled outputs against an fp64 host reference (debug == 0 only).
 #include <dlfcn.h>
@@ -51,8 +51,10 @@ static inline float bf2f(uint16_t h) {
 struct Lib {
     void* h = nullptr;
     int (*gemm)(const t2v_gemm_desc*, void*) = nullptr;
+    int (*halo)(const t2v_gemm_desc*, void*) = nullptr;
     int (*init)() = nullptr;
     int (*debug)(int) = nullptr;
+    int (*hdebug)(int) = nullptr;
     const char* (*last_error)() = nullptr;
 };
 
@@ -61,8 +63,10 @@ static Lib load_lib(const std::string& path) {
     l.h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!l.h) { fprintf(stderr, "dlopen %s: %s\n", path.c_str(), dlerror()); exit(1); }
     l.gemm = (int (*)(const t2v_gemm_desc*, void*))dlsym(l.h, "t2v_gemm");
+    l.halo = (int (*)(const t2v_gemm_desc*, void*))dlsym(l.h, "t2v_conv_halo");
     l.init = (int (*)())dlsym(l.h, "t2v_init");
     l.debug = (int (*)(int))dlsym(l.h, "t2v_gemm_debug");
+    l.hdebug = (int (*)(int))dlsym(l.h, "t2v_conv_halo_debug");
     l.last_error = (const char* (*)())dlsym(l.h, "t2v_last_error");
     if (!l.gemm || !l.init) { fprintf(stderr, "%s: missing symbols\n", path.c_str()); exit(1); }
     if (l.init() != 0) { fprintf(stderr, "%s: t2v_init failed\n", path.c_str()); exit(1); }
@@ -97,13 +101,14 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    Buf bx, bw, bo, bres, bbias, brv, bws;
+    Buf bx, bw, bw2, bo, bres, bbias, brv, bws;
     std::vector<uint16_t> hx, hw, hres, hout;
     std::vector<float> hbias, hrv;
     printf("name,lib,mode,M,N,K,act,res,rv,cfg,split,debug,us,tflops,err_over_tol\n");
     char line[1024];
     // the last generated problem is kept when consecutive lines share the geometry (same data for A/B rows)
     long long last_key[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    int K2 = 0;
     while (fgets(line, sizeof line, in)) {
         if (line[0] == '#' || line[0] == '\n') { fputs(line, stdout); continue; }
         int lib = 0, mode, nimg, h, w, frames, cin, n, act, res, rv, cfg, split, debug, iters = 20;
@@ -138,6 +143,16 @@ int main(int argc, char** argv) {
             bo.need((size_t)M * n_out * 2);
             CHECK(hipMemcpy(bx.d, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
             CHECK(hipMemcpy(bw.d, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+            if (mode != 0) {   // slab-major pack of the same weights for t2v_conv_halo: [N][C/32][taps][32]
+                K2 = ((cin / 32 * taps + 7) / 8) * 8 * 32;   // rows zero-padded to an even number of 4-pair weight stages
+                std::vector<uint16_t> hw2((size_t)n * K2, 0);
+                for (int r = 0; r < n; ++r)
+                    for (int t = 0; t < taps; ++t)
+                        for (int c = 0; c < cin; ++c)
+                            hw2[(size_t)r * K2 + ((size_t)(c / 32) * taps + t) * 32 + (c % 32)] = hw[(size_t)r * K + (size_t)t * cin + c];
+                bw2.need(hw2.size() * 2);
+                CHECK(hipMemcpy(bw2.d, hw2.data(), hw2.size() * 2, hipMemcpyHostToDevice));
+            }
             CHECK(hipMemcpy(bres.d, hres.data(), hres.size() * 2, hipMemcpyHostToDevice));
             CHECK(hipMemcpy(bbias.d, hbias.data(), hbias.size() * 4, hipMemcpyHostToDevice));
             CHECK(hipMemcpy(brv.d, hrv.data(), hrv.size() * 4, hipMemcpyHostToDevice));
@@ -152,9 +167,19 @@ int main(int argc, char** argv) {
         d.act = act; d.out = bo.d; d.ldo = n_out; d.tile_cfg = cfg; d.split_k = split; d.ws = bws.d; d.ws_bytes = (long long)bws.bytes;
         Lib& L = libs[lib];
         if (L.debug) L.debug(debug);
+        if (L.hdebug) L.hdebug(debug);
+        const bool halo = cfg >= 39 && cfg < 44;
+        int (*run)(const t2v_gemm_desc*, void*) = L.gemm;
+        if (halo) {
+            if (!L.halo || mode == 0) { fprintf(stderr, "no t2v_conv_halo for this line\n"); continue; }
+            run = L.halo;
+            d.w = bw2.d;
+            d.ldw = K2;
+            d.tile_cfg = cfg == 39 ? 0 : cfg;
+        }
         CHECK(hipMemsetAsync(bo.d, 0, (size_t)M * n_out * 2, stream));
         int rc = 0;
-        for (int i = 0; i < 3 && rc == 0; ++i) rc = L.gemm(&d, stream);
+        for (int i = 0; i < 3 && rc == 0; ++i) rc = run(&d, stream);
         if (rc != 0) {
             printf("%s,%d,%d,%lld,%d,%d,%d,%d,%d,%d,%d,%d,rc=%d %s,,\n", name, lib, mode, M, n, K, act, res, rv, cfg, split, debug, rc,
                    L.last_error ? L.last_error() : "");
@@ -164,7 +189,7 @@ int main(int argc, char** argv) {
         float best = 1e30f;
         for (int rep = 0; rep < 3; ++rep) {
             CHECK(hipEventRecord(e0, stream));
-            for (int i = 0; i < iters; ++i) L.gemm(&d, stream);
+            for (int i = 0; i < iters; ++i) run(&d, stream);
             CHECK(hipEventRecord(e1, stream));
             CHECK(hipEventSynchronize(e1));
             float ms;
