@@ -421,6 +421,17 @@ int t2v_transpose_pad_bf16(const void* in, int ld_in, int rows, int cols, void* 
 int t2v_dropout_bf16(const void* x, int ldx, const void* resid, int ldr, void* out, int ldo, long long rows, int ncols, float p,
                      const void* seed, unsigned site, void* stream);
 
+/* ---------------------------------------------------------------- recorded launch lists
+ * The reference has no counterpart: its hot path is issued op by op from Python (and that is what bounds a small-batch step on
+ * the host).  The engines of this library record a forward / backward once and replay it; t2v_replay walks such a recording —
+ * a flat array of 64-bit words [function id, n, n argument slots] ... — inside the library, one host call per LIST instead of
+ * one per launch.  Function ids come from t2v_replay_lookup(name) (-1: not a replayable entry point).  A slot holds an integer
+ * or pointer value as is, a float as its 32 bits (low half), a double as its 64 bits; the stream parameter (always last in the
+ * entry point's signature) is not stored: every launch goes to the stream given here.  Returns the first non-zero return code
+ * and its launch index in *failed_index (may be NULL). */
+int t2v_replay_lookup(const char* name);
+int t2v_replay(const unsigned long long* prog, long long nwords, void* stream, int* failed_index);
+
 #ifdef __cplusplus
 }
 #endif

@@ -307,27 +307,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int bm = 0; bm < 5; ++bm) acc[bn][bm] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (kgroup == 0) {
-        int tok[5];
-#pragma unroll
-        for (int bm = 0; bm < 5; ++bm) tok[bm] = token_of(rg * 5 + bm, half * 16 + l15);
-        float4 bia[5];
+        // (a tile lies inside one image, and rowvec_div is a whole number of images — host-checked — so the row vector is one
+        // row for the whole tile: five 16-byte loads per lane next to the five of the bias)
+        const long long rv_row = d.rowvec ? (long long)(((long long)img * U * V) / d.rowvec_div) * d.ld_rowvec : 0;
 #pragma unroll
         for (int bn = 0; bn < 5; ++bn) {
             const int ch = ch_lane + bn * 16;
-            bia[bn] = (d.bias && ch < d.N) ? *(const float4*)(d.bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int bn = 0; bn < 5; ++bn)
-#pragma unroll
-            for (int bm = 0; bm < 5; ++bm) {
-                const int ch = ch_lane + bn * 16;
-                float4 v = bia[bn];
-                if (d.rowvec && tok[bm] >= 0 && ch < d.N) {
-                    const float4 r4 = *(const float4*)(d.rowvec + (long long)(tok[bm] / d.rowvec_div) * d.ld_rowvec + ch);
-                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
-                }
-                acc[bn][bm] = (f32x4_t){v.x, v.y, v.z, v.w};
+            float4 v = (d.bias && ch < d.N) ? *(const float4*)(d.bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.rowvec && ch < d.N) {
+                const float4 r4 = *(const float4*)(d.rowvec + rv_row + ch);
+                v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
             }
+#pragma unroll
+            for (int bm = 0; bm < 5; ++bm) acc[bn][bm] = (f32x4_t){v.x, v.y, v.z, v.w};
+        }
     }
     hwait_vmcnt<0>();                       // everything staged so far has landed (mine)
     __builtin_amdgcn_s_barrier();           // ... and everybody's
@@ -342,6 +335,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // slots nobody reads, so the counts never change; everything is drained before the LDS is reused.  One scalar compare per
     // stage leaves the loop after the last stage.
     if (HABL(128)) return;   // (launch + prologue only)
+    // static priority for the second-dispatched half of the workgroup (it loses every arbitration by age otherwise): measured
+    // -1.6 / -8.7 / -3.2 % per launch at the three levels (ablation bit 512 switches it off)
+    if (!HABL(512) && wave >= 4) asm volatile("s_setprio 1");
     int k = 0;          // global stage index
     int sub_base = 0;   // first sub-slab of the super-iteration BEFORE the current one (the schedule constants are taken one period in)
     read_frags(std::integral_constant<int, 0>{}, 0);
@@ -572,7 +568,7 @@ static int halo_prepare(const t2v_gemm_desc* dd, HaloParams& p, int& cfg) {
     if (((uintptr_t)d.a0 | (uintptr_t)d.w | (uintptr_t)d.out | (uintptr_t)d.a1) % 16) return T2V_OK;
     if (d.residual && (d.ldr % 8 || (uintptr_t)d.residual % 16)) return T2V_OK;
     if (d.bias && (uintptr_t)d.bias % 16) return T2V_OK;
-    if (d.rowvec && ((uintptr_t)d.rowvec % 16 || d.ld_rowvec % 4 || d.rowvec_div <= 0)) return T2V_OK;
+    if (d.rowvec && ((uintptr_t)d.rowvec % 16 || d.ld_rowvec % 4 || d.rowvec_div <= 0 || d.rowvec_div % (d.h_in * d.w_in))) return T2V_OK;
     T2V_REQUIRE(d.n_img > 0 && d.h_in > 0 && d.w_in > 0, T2V_EINVAL, "t2v_conv_halo: conv geometry");
     const int C = d.c0 + d.c1;
     p.U = d.h_in; p.V = d.w_in;

@@ -1461,6 +1461,12 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
         fuse_cfg = t2v_gemm_fuse_tile(cfg, d.act, fuse);
         // the fused epilogue rides on the fast kernels of one K split; GEGLU needs a 64-wide wave tile (its value / gate pairs)
         fuse_ok = fuse_cfg != 0 && p.splits == 1 && gemm_is_fast(p, fuse == 8 || (fuse & 16) != 0) && !(d.act == T2V_ACT_GEGLU && kCfg[fuse_cfg].wtn < 64);
+        // LoRA epilogue: a wave tile loads the rank-64 rows of at most TWO leaves (lra_t[2]); a group whose leaves are narrower than
+        // the tile's per-wave width could put a third leaf under one wave tile, which would then be multiplied with leaf 1's rows
+        if ((fuse & 16) && fuse_cfg != 0 && d.N != d.lora_n_leaf) {
+            const int wtn = fuse_cfg == 23 ? 160 : kCfg[fuse_cfg].wtn;   // (the 160x320 tile: 32 in the table keeps GEGLU off it; its wave tile is 160 wide)
+            if (wtn > d.lora_n_leaf) fuse_ok = false;
+        }
         // the dropout epilogue moves to the fast kernels only where that keeps the launch on (a twin of) the tile the table chose
         // for it: measured per shape on MI355X (profiles/r03_student_gemm_fast_dropout.csv), 160x320 (id 28 -> 23) wins 20-35 %,
         // ids that map to a different workgroup tile or lose their register-staged prologue (18 -> 4, 29 -> 11) lose 5-45 %

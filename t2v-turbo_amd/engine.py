@@ -521,17 +521,18 @@ class UNetEngine(_Engine):
                None if timestep_cond is None else (tuple(timestep_cond.shape), timestep_cond.dtype),
                None if motion_cond is None else (tuple(motion_cond.shape), motion_cond.dtype), x.device)
         plan = self.plans.get(key)
-        if plan is None or plan["training"] != m.training:
-            for mod in m.modules():  # train-mode dropout (TemporalConvBlock p=0.1, LoRA p=0.1) has no native kernel
-                if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training:
-                    raise RuntimeError("native UNet path is inference-only but a Dropout(p>0) is in training mode: "
-                                       "call .eval() on the model (after any LoRA injection) first")
+        drops = self._active_tconv_dropouts() if m.training else {}
+        if plan is None or plan["training"] != m.training or plan.get("drop_sig") != tuple(sorted(drops.values())):
+            self.drop_ps = drops   # id(nn.Dropout) -> p of the TemporalConvBlock dropouts that are live (train-mode frozen network)
             plan = self._own(self._record(x, timesteps, context, fps, timestep_cond, motion_cond))
             plan["training"] = m.training
+            plan["drop_sig"] = tuple(sorted(drops.values()))
             self._keep_plan(key, plan)
         else:
             self._keep_plan(key, plan)
             st = plan["static"]
+            if "seed" in st:   # a fresh mask per call (the launch list reads the seed from device memory: replays follow it)
+                st["seed"].fill_(self._next_seed())
             st["x"].copy_(x)
             st["ts"].copy_(timesteps)
             st["ctx"].copy_(context)
@@ -547,6 +548,38 @@ class UNetEngine(_Engine):
             self._run(plan)
         self._publish_probs(plan)
         return plan["out"].clone()
+
+    # ---- train-mode frozen network (the v1 distillation teacher) ----------------------------------------------------------
+    # train_t2v_turbo_v1_lora.py never calls .eval() on its teacher (:621-626; calls at :1105-1134, under no_grad), so the
+    # Dropout(p = 0.1) layers of every TemporalConvBlock (openaimodel3d.py:282-294) are LIVE in the reference's teacher forwards.
+    # The inference dataflow applies them with the counter-based masks of t2v_dropout_bf16 between the GroupNorm + SiLU and the
+    # (3,1,1) conv, exactly where the gradient engine puts them for the student; any other active Dropout still refuses.
+    def _active_tconv_dropouts(self):
+        from .nn_util import walk_modules
+        from .unet3d import TemporalConvBlock
+        mods = walk_modules(self.model)
+        active = [mod for mod in mods if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training]
+        if not active:
+            return {}
+        known = {}
+        for blk in mods:
+            if isinstance(blk, TemporalConvBlock):
+                for stg in (blk.conv1, blk.conv2, blk.conv3, blk.conv4):
+                    for layer in stg:
+                        if isinstance(layer, nn.Dropout) and layer.p > 0 and layer.training:
+                            known[id(layer)] = float(layer.p)
+        other = [mod for mod in active if id(mod) not in known]
+        if other:
+            raise RuntimeError(f"native UNet path: {len(other)} Dropout(p>0) module(s) in training mode that the inference engine does "
+                               "not apply (only the TemporalConvBlock dropouts of a frozen train-mode network are): call .eval() first")
+        return known
+
+    def _next_seed(self):
+        """One mask seed per forward.  ``seed_source`` (tests: a list / iterator of ints) overrides torch's generator."""
+        src = getattr(self, "seed_source", None)
+        if src is not None:
+            return int(next(src))
+        return int(torch.randint(0, 2 ** 62, (1,)).item())
 
     def _publish_probs(self, plan):
         for attn, probs in plan["probs"]:
@@ -566,6 +599,9 @@ class UNetEngine(_Engine):
             st["tc"] = timestep_cond.detach().clone().contiguous()
         if motion_cond is not None:
             st["mc"] = motion_cond.detach().clone().contiguous()
+        if getattr(self, "drop_ps", None):
+            st["seed"] = torch.full((1,), self._next_seed(), dtype=torch.int64, device=x.device)
+        self.seed_t = st.get("seed")
         out = torch.empty_like(st["x"][:, :m.out_channels].contiguous()) if m.out_channels != Cin else torch.empty_like(st["x"])
         plan = {"static": st, "out": out, "probs": [], "runs": 0}
         self.plan = plan
@@ -590,6 +626,7 @@ class UNetEngine(_Engine):
     def _forward(self, st, out):
         m, ops, pk = self.model, self.ops, self.pk
         B, F = self.B, self.F
+        self.drop_sites = []   # ([nn.Dropout], kind, geometry) per applied mask, in launch order (tests replay them inside the torch module)
         x = st["x"]
         _, Cin, _, H, W = x.shape
         mc = m.model_channels
@@ -719,6 +756,12 @@ class UNetEngine(_Engine):
         y = h2
         for i, stage in enumerate((tc.conv1, tc.conv2, tc.conv3, tc.conv4)):
             tt = self.gn(y, stage[0], B, F * hw, True, then=self.pk.conv(stage[-1]))
+            for layer in stage:   # train-mode frozen network: the stage's Dropout between SiLU and the conv (openaimodel3d.py:282-294)
+                p_drop = getattr(self, "drop_ps", {}).get(id(layer)) if isinstance(layer, nn.Dropout) else None
+                if p_drop:
+                    site = len(self.drop_sites)
+                    self.drop_sites.append(([layer], "tconv", (B, F, h2.h, h2.w)))
+                    self.ops.dropout(tt, None, tt, tt.shape[1], p_drop, self.seed_t, site)
             ny = self.conv(Act(tt, h2.n_img, h2.h, h2.w), stage[-1], nt.GEMM_TCONV3, frames=F,
                            residual=h2.t if i == 3 else None)
             self.pool.put(tt)

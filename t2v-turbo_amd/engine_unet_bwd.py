@@ -72,6 +72,11 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         # the inference engine; the tape keeps (mean, rstd) for the backward either way.  T2V_FUSE_GN_TRAIN=0: statistics pass
         # over the tensor (t2v_gn_stats).
         self.fuse_gn = os.environ.get("T2V_FUSE_GN_TRAIN", "1") == "1"
+        # the forward convs stay on t2v_gemm here: t2v_conv_halo adds a residual operand to the tile it has already rounded to bf16
+        # (the reference's own bf16 `skip + h` rounding), and EVERY LoRA-injected conv of the student carries its branch as such a
+        # residual — the training forward would pick up one extra rounding per leaf (full-width parity gate: d/dx 5.7e-2 -> above
+        # the 6e-2 bound).  T2V_CONV_HALO_TRAIN=1 switches it on for measurement.
+        self.conv_halo = os.environ.get("T2V_CONV_HALO_TRAIN", "0") == "1"
 
     # ---- public: forward with tape, then backward ----------------------------------------------------------------
     def _active_dropouts(self):

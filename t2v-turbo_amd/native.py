@@ -98,6 +98,8 @@ _SIGS = {
     "t2v_conv_halo_force_config": (C.c_int, [C.c_int]),
     "t2v_conv_halo_debug": (C.c_int, [C.c_int]),
     "t2v_conv_halo_pack_cols": (C.c_int, [C.c_int]),
+    "t2v_replay_lookup": (C.c_int, [C.c_char_p]),
+    "t2v_replay": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.POINTER(C.c_int)]),
     "t2v_gemm_force_config": (C.c_int, [C.c_int]),
     "t2v_gemm_force_split": (C.c_int, [C.c_int]),
     "t2v_gemm_num_configs": (C.c_int, []),
@@ -326,12 +328,79 @@ class HipOps:
         if self.recording is not None:
             self.recording.append((fn, args, name))
 
-    @staticmethod
-    def replay(recording, stream):
-        for fn, args, name in recording:
-            rc = fn(*args, stream)
-            if rc != 0:
-                _check(rc, name)
+    # One host call per recorded LIST (t2v_replay, csrc/replay.hip) instead of one ctypes call per launch: the distillation step
+    # issues ~8 800 launches, ~230 ms of Python per step, which paced the step on every box in round 3.  T2V_C_REPLAY=0: the loop.
+    c_replay = os.environ.get("T2V_C_REPLAY", "1") == "1"
+
+    def compile_recording(self, recording):
+        """-> list of segments: ("c", uint64 array, n words, first launch index) for runs of C-ABI launches, ("py", fn, args, name)
+        for host-side entries (the gradient exchange's markers).  The recording's argument objects stay referenced by it."""
+        import struct
+        segs, words, first = [], [], 0
+        ids = getattr(self, "_replay_ids", None)
+        if ids is None:
+            ids = self._replay_ids = {}
+
+        def flush(upto):
+            nonlocal words, first
+            if words:
+                arr = (C.c_ulonglong * len(words))(*words)
+                segs.append(("c", arr, len(words), first))
+            words, first = [], upto
+
+        for i, (fn, args, name) in enumerate(recording):
+            if name not in ids:
+                ids[name] = int(self.lib.t2v_replay_lookup(name.encode())) if name in _SIGS else -1
+            fid = ids[name]
+            if fid < 0:
+                flush(i + 1)
+                segs.append(("py", fn, args, name))
+                continue
+            types = _SIGS[name][1][:-1]
+            assert len(types) == len(args), name
+            words.append(fid)
+            words.append(len(args))
+            for t, a in zip(types, args):
+                if t is C.c_float:
+                    words.append(struct.unpack("<I", struct.pack("<f", float(a)))[0])
+                elif t is C.c_double:
+                    words.append(struct.unpack("<Q", struct.pack("<d", float(a)))[0])
+                elif t in (C.c_int, C.c_longlong, C.c_uint, C.c_ulonglong):
+                    words.append(int(a) & 0xFFFFFFFFFFFFFFFF)
+                elif hasattr(a, "_obj"):            # C.byref(struct): the recording keeps the struct alive
+                    words.append(C.addressof(a._obj))
+                else:                               # raw pointer value (int) or None
+                    words.append(int(a or 0) if not hasattr(a, "value") else int(a.value or 0))
+        flush(len(recording))
+        return segs
+
+    def replay(self, recording, stream):
+        if not self.c_replay or not hasattr(self.lib, "t2v_replay"):
+            for fn, args, name in recording:
+                rc = fn(*args, stream)
+                if rc != 0:
+                    _check(rc, name)
+            return
+        cache = getattr(self, "_progs", None)
+        if cache is None:
+            cache = self._progs = {}
+        key = id(recording)
+        hit = cache.get(key)
+        if hit is None or hit[0] is not recording or hit[1] != len(recording):
+            if len(cache) > 64:
+                cache.clear()
+            hit = cache[key] = (recording, len(recording), self.compile_recording(recording))
+        failed = C.c_int(-1)
+        for seg in hit[2]:
+            if seg[0] == "c":
+                rc = self.lib.t2v_replay(seg[1], seg[2], stream, C.byref(failed))
+                if rc != 0:
+                    _check(rc, recording[seg[3] + failed.value][2] if failed.value >= 0 else "t2v_replay")
+            else:
+                _, fn, args, name = seg
+                rc = fn(*args, stream)
+                if rc != 0:
+                    _check(rc, name)
 
     # -- ops ----------------------------------------------------------------------------------------
     def gemm(self, a0, w, out, **kw):

@@ -556,7 +556,9 @@ class UNetModel(nn.Module):
           * LoRA-injected student, only LoRA tensors trainable, with or without grad, train or eval mode
             (the student and target forwards of train_t2v_turbo_v1_lora.py:1022-1028,1161-1168)
                                                              -> "train": gradient engine (un-merged LoRA branch, counter-based dropout);
-          * anything else (full fine-tuning, a train-mode network without LoRA, gradients w.r.t. the context, adapters)
+          * no gradient wanted, no LoRA, train mode with only the TemporalConvBlock dropouts live (the v1 teacher, which the
+            reference never puts in eval mode)               -> "infer": inference engine + counter-based dropout masks;
+          * anything else (full fine-tuning, gradients w.r.t. the context, adapters, other live dropouts)
                                                              -> the torch composite path, with a one-time warning."""
         from .nn_util import walk_modules, walk_parameters
         grad = torch.is_grad_enabled() and self._needs_grad(x, context, timestep_cond)
@@ -569,6 +571,11 @@ class UNetModel(nn.Module):
         if not grad and not dropping:
             return "infer", None
         from .engine import is_lora_leaf
+        if not grad and not any(is_lora_leaf(mod) for mod in mods) and self._only_tconv_dropouts(mods):
+            # a frozen, LoRA-free network left in train mode under no_grad: the v1 distillation teacher as the reference runs it
+            # (train_t2v_turbo_v1_lora.py:621-626 never calls .eval(); forwards at :1105-1134) — inference dataflow + the
+            # TemporalConvBlock dropouts as counter-based masks
+            return "infer", None
         lora_ids = {id(w) for mod in mods if is_lora_leaf(mod) for w in (mod.lora_up.weight, mod.lora_down.weight)}
         if not lora_ids:
             return "composite", ("a train-mode network with active Dropout and no LoRA" if not grad else
@@ -580,6 +587,16 @@ class UNetModel(nn.Module):
         if grad and (context.requires_grad or (timestep_cond is not None and timestep_cond.requires_grad)):
             return "composite", "gradients w.r.t. the context / guidance embedding"
         return "train", None
+
+    @staticmethod
+    def _only_tconv_dropouts(mods):
+        """Every active Dropout(p > 0) sits in a TemporalConvBlock stage (the only ones the inference engine applies)."""
+        known = set()
+        for blk in mods:
+            if isinstance(blk, TemporalConvBlock):
+                for stg in (blk.conv1, blk.conv2, blk.conv3, blk.conv4):
+                    known.update(id(layer) for layer in stg if isinstance(layer, nn.Dropout))
+        return all(id(mod) in known for mod in mods if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training)
 
     def _needs_grad(self, *tensors):
         if any(t is not None and t.requires_grad for t in tensors):

@@ -155,7 +155,7 @@ class EmuOps:
         if dropout is not None or ln is not None or rowstat is not None or lnf is not None or lora is not None or act not in (nt.ACT_NONE, nt.ACT_SILU):
             return 0
         c0, c1 = a0.shape[1], (0 if a1 is None else a1.shape[1])
-        if c0 % 64 or c1 % 64 or N % 16:
+        if c0 % 64 or c1 % 64 or N % 16 or (rowvec is not None and (rowvec_div <= 0 or rowvec_div % (h * wd))):
             return 0
         assert w.shape[1] >= nt.conv_halo_pack_cols(c0 + c1), "slab-major pack narrower than conv_halo_pack_cols"
         U, V = h, wd

@@ -205,3 +205,58 @@ def test_unet_engine_norm_statistics_from_the_producing_gemms():
         # GroupNorm: every statistics unit of >= 32 rows whose input came out of a GEMM takes the producer's statistics
         n_gn = counts[False]["group_norm"]
         assert counts[True]["group_norm"] + counts[True]["group_norm_cs"] == n_gn and counts[True]["group_norm_cs"] > n_gn // 3
+
+
+def test_train_mode_frozen_teacher_runs_natively_with_replayed_masks():
+    """The v1 distillation teacher as the reference runs it: frozen, LoRA-free, NEVER put in eval mode
+    (train_t2v_turbo_v1_lora.py:621-626, forwards under no_grad at :1105-1134), so the Dropout(0.1) of every TemporalConvBlock stage
+    (openaimodel3d.py:282-294) is live.  The inference engine applies them as counter-based masks; replaying those masks inside
+    the torch module reproduces its output; the route does not fall to the composite path (no RuntimeWarning)."""
+    import copy
+    import warnings
+    from tests.mask_replay import patch_engine_masks
+    g = load("unet_tiny")
+    cfg = tiny_unet_params()
+    sd = synth_state_dict(manifest("unet_tiny"))
+    m = UNetModel(**cfg)
+    m.load_state_dict(sd, strict=True)
+    m.requires_grad_(False)
+    m.train()
+    ops = EmuOps()
+    ops.masks = {}
+    eng = UNetEngine(m, ops)
+    eng.seed_source = iter([1234, 99, 99])
+    with torch.no_grad():
+        y = eng(g["x"], g["ts"], g["ctx"])               # teacher-style call: no timestep_cond
+    assert len(eng.drop_sites) > 0 and all(kind == "tconv" for _, kind, _ in eng.drop_sites)
+    assert rel_l2(y, g["y_nocond"]) > 1e-3                # the masks did something
+    ref_m = copy.deepcopy(m)
+    patch_engine_masks(ref_m, eng, ops.masks)
+    ref_m.native_mode = "off"
+    with torch.no_grad():
+        ref = ref_m(g["x"], g["ts"], context=g["ctx"])
+    assert rel_l2(y, ref) < 2e-5
+    # a new seed per call (replayed plan), the same seed -> the same output
+    with torch.no_grad():
+        y2 = eng(g["x"], g["ts"], g["ctx"])
+        y3 = eng(g["x"], g["ts"], g["ctx"])
+    assert rel_l2(y2, y) > 1e-4 and torch.equal(y2, y3)
+    # the module's own routing sends this call pattern to the inference engine, silently
+    route, why = m._auto_route(g["x"], g["ctx"], None, None)
+    assert (route, why) == ("infer", None)
+    m.eval()
+    with torch.no_grad():
+        y_eval = eng(g["x"], g["ts"], g["ctx"])          # back in eval mode: a different plan, no masks
+    assert rel_l2(y_eval, g["y_nocond"]) < 2e-5
+    # any OTHER live dropout still refuses
+    m.train()
+    m.output_blocks[0][0].out_layers[2].p = 0.5
+    try:
+        with torch.no_grad():
+            eng(g["x"], g["ts"], g["ctx"])
+        raise AssertionError("expected a refusal")
+    except RuntimeError as e:
+        assert "Dropout" in str(e)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert m._auto_route(g["x"], g["ctx"], None, None)[0] == "composite"

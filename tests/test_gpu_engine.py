@@ -392,3 +392,58 @@ def test_alternating_input_signatures_keep_their_plans():
     assert len(m._engine_box.engine.plans) == 2
     assert torch.isfinite(a1).all() and torch.equal(a0, a1) and torch.equal(a0, a2) and torch.equal(b0.float(), b1.float())
     assert rel_l2(a1.float().cpu(), g["y"]) < E2E_TOL
+
+
+def test_train_mode_frozen_teacher_on_device_no_warning_and_mask_replay():
+    """The v1 teacher's call pattern, unchanged: a frozen LoRA-free network that was never put in eval mode, called under no_grad
+    (train_t2v_turbo_v1_lora.py:621-626,1105-1134).  It must land on the native engine without the composite-path RuntimeWarning;
+    the TemporalConvBlock dropouts are the counter-based device masks (regenerated on the host from seed / site / geometry: bit-identical,
+    tests/emu_ops.py::dropout_keep) and replaying them inside the torch module reproduces the device output; hipGraph replay follows
+    the per-call seed."""
+    import copy
+    import warnings
+    from tests.emu_ops import EmuOps
+    from tests.mask_replay import patch_engine_masks
+    g = load("unet_tiny")
+    m = _unet(tiny_unet_params(), "unet_tiny")
+    m.requires_grad_(False)
+    m.train()
+    eng = m.native_engine()
+    eng.seed_source = iter([77, 78, 78, 79, 79])
+    x, ts, ctx = g["x"].cuda(), g["ts"].cuda(), g["ctx"].cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")           # the ATen composite route announces itself with a RuntimeWarning
+        with torch.no_grad():
+            y = m(x, ts, context=ctx)
+    assert eng.drop_sites and all(kind == "tconv" for _, kind, _ in eng.drop_sites)
+    assert rel_l2(y.float().cpu(), g["y_nocond"]) > 1e-3    # masks applied
+    # host replay of the masks of seed 77 inside the fp32 torch module
+    masks = {}
+    ref_m = copy.deepcopy(m).float().cpu()
+    widths = {}
+    for blk in ref_m.modules():
+        if type(blk).__name__ == "TemporalConvBlock":
+            for stg in (blk.conv1, blk.conv2, blk.conv3, blk.conv4):
+                for layer in stg:
+                    if isinstance(layer, torch.nn.Dropout):
+                        widths[id(layer)] = stg[0].num_channels
+    twin = {id(a): b for a, b in zip(m.modules(), ref_m.modules())}
+    for sid, (drops, _, (B, F, h, w)) in enumerate(eng.drop_sites):
+        C = widths[id(twin[id(drops[0])])]
+        masks[sid] = EmuOps.dropout_keep(77, sid, B * F * h * w, C, drops[0].p)
+    ref_eng_like = type("E", (), {"model": m, "drop_sites": eng.drop_sites})()
+    patch_engine_masks(ref_m, ref_eng_like, masks)
+    ref_m.native_mode = "off"
+    with torch.no_grad():
+        ref = ref_m(g["x"], g["ts"], context=g["ctx"])
+    assert rel_l2(y.float().cpu(), ref) < E2E_TOL
+    # replayed launch list: a new seed per call, the same seed -> bit-identical; then as one hipGraph
+    with torch.no_grad():
+        y2 = m(x, ts, context=ctx)
+        y3 = m(x, ts, context=ctx)
+    assert torch.equal(y2, y3) and not torch.equal(y2, y)
+    eng.use_graph = True
+    with torch.no_grad():
+        y4 = m(x, ts, context=ctx)      # seed 79: captures
+        y5 = m(x, ts, context=ctx)      # seed 79: graph replay
+    assert torch.equal(y4, y5) and not torch.equal(y4, y2)

@@ -265,3 +265,36 @@ def test_fused_feed_forward_kernel(full_ops, C, M):
     assert torch.isfinite(out_s.float()).all()
     assert rel_l2(out_e, ref) < 5e-3                    # (the packed W1 diag(gamma) is rounded to bf16)
     assert rel_l2(out_s.float(), out_e) < 6e-3          # bf16 normalised rows and hidden activations inside the kernel
+
+
+def test_c_side_replay_equals_the_python_loop(full_ops):
+    """t2v_replay (csrc/replay.hip) walks a recorded launch list inside the library: same launches, same arguments, same order
+    as the per-launch ctypes loop — bit-identical outputs — and a failing launch is reported with its index."""
+    import ctypes as C
+    sim = full_ops()
+    x = torch.randn(37, 64).bfloat16()
+    w = torch.randn(48, 64).bfloat16()
+    b = torch.randn(48)
+    out1, out2 = torch.empty(37, 48).bfloat16(), torch.empty(37, 48).bfloat16()
+    ln1, ln2 = torch.empty(37, 48).bfloat16(), torch.empty(37, 48).bfloat16()
+    g, be = torch.randn(48), torch.randn(48)
+    outs = []
+    for replay_c in (False, True):
+        sim.recording = []
+        o, l = (out2, ln2) if replay_c else (out1, ln1)
+        sim.gemm(x, w, o, M=37, N=48, bias=b)
+        sim.layernorm(o, g, be, 1e-5, l)
+        rec, sim.recording = sim.recording, None
+        o.zero_(); l.zero_()
+        sim.c_replay = replay_c
+        sim.replay(rec, None)
+        outs.append((o.clone(), l.clone()))
+        if replay_c:
+            segs = sim.compile_recording(rec)
+            assert [s[0] for s in segs] == ["c"] and segs[0][2] == sum(2 + len(a) for _, a, _ in rec)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert sim.lib.t2v_replay_lookup(b"t2v_gemm") >= 0 and sim.lib.t2v_replay_lookup(b"t2v_version") == -1
+    # a malformed program is refused, not executed
+    bad = (C.c_ulonglong * 3)(9999, 1, 0)
+    failed = C.c_int(-7)
+    assert sim.lib.t2v_replay(bad, 3, None, C.byref(failed)) < 0
