@@ -65,9 +65,10 @@ class LoraTrainMixin:
     # pair once the rank-r gradient exists, instead of one t2v_wgrad_tn pair each (T2V_GROUP_WGRAD=0)
     group_wgrad = os.environ.get("T2V_GROUP_WGRAD", "1") == "1"
     # the LoRA branch's up-projection and dropout inside the base leaf's GEMM epilogue (t2v_gemm lora_* fields): two launches per
-    # leaf group instead of 2 + leaves, the M x N up-projection never in memory.  Built at the end of round 3: correct on MI355X (kernel
-    # at the UNet's shapes, engine at tiny width in eval and train mode) but NOT YET TIMED, hence opt-in: T2V_LORA_EPILOGUE=1.
-    fuse_lora = os.environ.get("T2V_LORA_EPILOGUE", "0") == "1"
+    # leaf group instead of 2 + leaves, the M x N up-projection never in memory.  Built at the end of round 3, timed in round 4
+    # (same box, same process tree: 222.5 vs 227.0 ms per distillation step, student forward 47.3 vs 51.1 ms, 1 650 vs 2 150
+    # launches; profiles/r04_distill_ab.jsonl) and the default since; T2V_LORA_EPILOGUE=0: one GEMM per leaf, as before.
+    fuse_lora = os.environ.get("T2V_LORA_EPILOGUE", "1") == "1"
 
     # ---- binding ------------------------------------------------------------------------------------------------------
     def bind_lora(self, params):

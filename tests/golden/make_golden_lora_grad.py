@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Golden LoRA gradients from THE REFERENCE ITSELF (CPU, build container only; needs /root/reference):
 
-    python tests/golden/make_golden_lora_grad.py        -> tests/golden/unet_tiny_lora_grad.npz
+    python tests/golden/make_golden_lora_grad.py              -> tests/golden/unet_tiny_lora_grad.npz   (model_channels 64)
+    python tests/golden/make_golden_lora_grad.py --width 128  -> tests/golden/unet_mid_lora_grad.npz    (model_channels 128: a second,
+                                                                 wider anchor for the full-width chain, whose CPU reference is the
+                                                                 repository's own composite module: oracle/lora_grad_oracle.py)
 
 The student's backward of the distillation step (train_t2v_turbo_v1_lora.py:1190) at tiny width: the reference
 ``UNetModel`` with the reference's own ``utils.lora.inject_trainable_lora_extended`` (rank 64), both LoRA factors drawn
@@ -41,6 +44,7 @@ def digests(grads):
 
 
 def main():
+    width = int(sys.argv[sys.argv.index("--width") + 1]) if "--width" in sys.argv else 64
     import make_golden as mg
     mg.install_stubs()
     sys.path.insert(0, mg.REF)
@@ -50,7 +54,7 @@ def main():
 
     z = np.load(os.path.join(HERE, "unet_tiny.npz"))
     x, ts, ctx, tc = (torch.from_numpy(z[k]) for k in ("x", "ts", "ctx", "tc"))
-    m = UNetModel(**mg.tiny_unet_params()).eval()
+    m = UNetModel(**mg.tiny_unet_params(model_channels=width)).eval()
     m.load_state_dict(synth_state_dict(manifest_of(m)), strict=True)
     m.requires_grad_(False)
     its, names = inject_trainable_lora_extended(m, target_replace_module={"UNetModel"}, r=64)  # train_t2v_turbo_v1_lora.py:644-657
@@ -64,8 +68,11 @@ def main():
     grads = [p.grad for p in params]
     shapes = np.asarray([list(p.shape) + [0] * (5 - p.dim()) for p in params], dtype=np.int64)
     small = {f"g{i}": g.numpy() for i, g in enumerate(grads) if g.numel() <= 4 * 64 * 9 and min(g.shape[:2]) == 4}
-    np.savez_compressed(os.path.join(HERE, "unet_tiny_lora_grad.npz"), out=out.detach().numpy(), dx=xg.grad.numpy(),
-                        digests=digests(grads), shapes=shapes, n_leaves=np.int64(len(names)), **small)
+    name = "unet_tiny_lora_grad.npz" if width == 64 else "unet_mid_lora_grad.npz"
+    if width != 64:
+        small = {}          # (the second anchor keeps the digests only)
+    np.savez_compressed(os.path.join(HERE, name), out=out.detach().numpy(), dx=xg.grad.numpy(),
+                        digests=digests(grads), shapes=shapes, n_leaves=np.int64(len(names)), width=np.int64(width), **small)
     print(len(params), "LoRA tensors,", sum(p.numel() for p in params), "elements; full gradients kept for", sorted(small))
 
 

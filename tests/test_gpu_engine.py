@@ -447,3 +447,30 @@ def test_train_mode_frozen_teacher_on_device_no_warning_and_mask_replay():
         y4 = m(x, ts, context=ctx)      # seed 79: captures
         y5 = m(x, ts, context=ctx)      # seed 79: graph replay
     assert torch.equal(y4, y5) and not torch.equal(y4, y2)
+
+
+def test_vae_decode_full_size_vs_oracle():
+    """The KL-VAE decoder at the size the clip legs time it on (ae_modules.py:29-73,602-641; ddpm3d.py:666-679): ch = 128, ch_mult
+    (1,2,4,4), latent 40x64 -> 320x512 incl. the single-head 2 560-token AttnBlock at width 512; two frames, bf16 engine against the
+    fp32 oracle on the same random-init weights.  Tolerance: BASELINE.md 4's end-to-end 3e-2."""
+    from oracle import vae_oracle as vo
+    from t2v_turbo_amd.vae import AutoencoderKL
+    from tests.util import VAE_FULL_DD
+    torch.manual_seed(7)
+    ae = AutoencoderKL(ddconfig=VAE_FULL_DD, embed_dim=4).eval()
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for p in ae.parameters():   # (zero-init tensors re-drawn so that every branch carries signal)
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0.0, 0.02, generator=gen)
+    sd = {k: v.detach().clone() for k, v in ae.state_dict().items()}
+    z = torch.randn(1, 4, 2, 40, 64, generator=gen) * 0.18215 * 4.0
+    ref = vo.decode_first_stage_2dae(sd, VAE_FULL_DD, z)
+    ae_dev = ae.to("cuda", torch.bfloat16)
+    with torch.no_grad():
+        v = ae_dev.decode_video(z.cuda().bfloat16())
+    assert ae_dev._engine_box.engine is not None, "native VAE engine did not run"
+    assert v.shape == ref.shape == (1, 3, 2, 320, 512)
+    err = rel_l2(v.float().cpu(), ref)
+    print(f"[full-size VAE decode] rel-L2 vs fp32 oracle {err:.3e}", flush=True)
+    assert err < E2E_TOL, err

@@ -37,3 +37,31 @@ def test_lora_grad_oracle_reproduces_the_reference_fixture():
     assert float(((d[:, 0] - ref[:, 0]).abs() / ref[:, 0]).max()) < 1e-4
     rows, zeros = per_tensor_agreement(grads, grads)
     assert not zeros and all(abs(c - 1) < 1e-12 and abs(q - 1) < 1e-12 for _, c, q in rows)
+
+
+def test_lora_grad_oracle_reproduces_the_mid_width_reference_fixture():
+    """The same at model_channels = 128 (tests/golden/unet_mid_lora_grad.npz, made by running the REFERENCE at that width:
+    make_golden_lora_grad.py --width 128): the full-width training-parity chain compares the device with
+    oracle/lora_grad_oracle.student_reference, whose module is this repository's own composite UNetModel — pinned to the reference at
+    tiny width above, and here at a second width with 2 / 4 / 8 attention heads and 128-512-channel levels."""
+    from oracle.lora_grad_oracle import student_reference
+    from oracle.synth import manifest_of, synth_state_dict
+    from t2v_turbo_amd import lora
+    from t2v_turbo_amd.unet3d import UNetModel
+    from tests.golden.make_golden_lora_grad import SEED_R, digests, draw_lora
+    from tests.util import load, rel_l2, tiny_unet_params
+    g, gg = load("unet_tiny"), load("unet_mid_lora_grad")
+    cfg = tiny_unet_params(model_channels=int(gg["width"]))
+    m = UNetModel(**cfg).eval()
+    m.load_state_dict(synth_state_dict(manifest_of(m)), strict=True)
+    m.requires_grad_(False)
+    lora.inject_trainable_lora_extended(m, r=64)
+    params = lora.lora_parameters(m)
+    assert len(params) == 2 * int(gg["n_leaves"]) and [list(p.shape) for p in params] == [[int(v) for v in row[:p.dim()]] for row, p in zip(gg["shapes"], params)]
+    draw_lora(params)
+    r_out = torch.randn(g["x"].shape, generator=torch.Generator().manual_seed(SEED_R))
+    y, dx, grads = student_reference(m.state_dict(), cfg, 64, g["x"], g["ts"], g["ctx"], 16, g["tc"], r_out)
+    assert rel_l2(y, gg["out"]) < 2e-5 and rel_l2(dx, gg["dx"]) < 1e-4
+    d, ref = torch.from_numpy(digests(grads)), gg["digests"]
+    assert float(((d[:, 0] - ref[:, 0]).abs() / ref[:, 0]).max()) < 1e-4
+    assert float(((d[:, 1:] - ref[:, 1:]).abs() / ref[:, :1]).max()) < 1e-3
