@@ -177,6 +177,11 @@ int t2v_conv_halo_force_config(int cfg);
 int t2v_conv_halo_debug(int bits);   /* ablation bits; honoured by -DT2V_HALO_ABLATE tool builds only */
 /* tuning/test hooks: override tile id / split-K factor for every following call (0 = off) */
 int t2v_gemm_force_config(int cfg);
+/* t2v_gemm's second kernel family (csrc/gemm2.hip: static-schedule main loop, 80x80 wave tiles; tile ids 50 = 320x160, 51 = 160x160)
+ * for LINEAR / TCONV3 launches with a plain epilogue (bias, residual, SiLU, colstat_out).  Measured slower than the tuned first-family
+ * tiles on the UNet's shapes (operand-delivery bound), so it is OFF by default: t2v_gemm2_enable(1) (or T2V_GEMM2=1) lets the library
+ * route long-K launches to it by its own rule, a forced tile id 50 / 51 puts an eligible launch on it whatever its K. */
+int t2v_gemm2_enable(int on);
 int t2v_gemm_force_split(int splits);
 int t2v_gemm_num_configs(void);
 

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "replay.hip"]
+SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "gemm2.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "replay.hip"]
 # T2V_HIP_LIB_OUT: build a variant (e.g. with ablation switches) next to the product library instead of over it
 LIB = os.path.abspath(os.environ["T2V_HIP_LIB_OUT"]) if os.environ.get("T2V_HIP_LIB_OUT") else os.path.join(PKG, "libt2v_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
@@ -25,7 +25,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "gn_bwd_common.h"),
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "gn_bwd_common.h"), os.path.join(HERE, "tile80.h"), os.path.join(HERE, "gemm2.h"),
                                                         os.path.join(ROOT, "include", "t2v_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -29,7 +29,7 @@
 //    so that the next stage's first fragment reads and the DMA issue hide under them.
 //  * Epilogue: accumulators start at bias + time-embedding row vector + residual; the bf16 tile is parked in LDS (whole
 //    workgroup), written out in full rows, and the per-32-row column statistics of the NEXT GroupNorm are taken from it.
-#include "common.h"
+#include "tile80.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -56,30 +56,10 @@ struct HaloParams {
 
 namespace {
 
-constexpr unsigned kOutOfRange = 0x80000000u;   // a buffer offset no descriptor of ours covers: the DMA delivers zeros
-
+using tile80::kOutOfRange;
+using tile80::static_for_until;
 template <int N>
-__device__ __forceinline__ void hwait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-// wait until at most `younger` groups of PER DMAs (issued after the ones waited for) are outstanding
-template <int PER>
-__device__ __forceinline__ void wait_groups(int younger) {
-    if (younger <= 0) hwait_vmcnt<0>();
-    else if (younger == 1) hwait_vmcnt<PER>();
-    else if (younger == 2) hwait_vmcnt<2 * PER>();
-    else hwait_vmcnt<3 * PER>();
-}
-
-template <int I, int N, class F>
-__device__ __forceinline__ bool static_for_until(F&& f) {   // f(integral_constant<int, I>) -> true: stop
-    if constexpr (I < N) {
-        if (f(std::integral_constant<int, I>{})) return true;
-        return static_for_until<I + 1, N>(f);
-    } else {
-        return false;
-    }
-}
+__device__ __forceinline__ void hwait_vmcnt() { tile80::wait_vmcnt<N>(); }
 
 // NWL of the 8 waves stage weights (W_IT pieces of 1 KiB per stage each), the other 8 - NWL the activation sub-slabs (A_IT pieces
 // per sub-slab each).
@@ -102,8 +82,7 @@ struct HaloCfg {
     static constexpr int A_BYTES = A_IT * NAL * 1024;      // one activation sub-slab buffer
     static constexpr int WS_BYTES = NP * BN * 64;
     static constexpr int RING_BYTES = NA * A_BYTES + NWS * WS_BYTES;
-    static constexpr int OUT_PITCH = BN * 2 + 16;
-    static constexpr int OUT_BYTES = BM * OUT_PITCH + BM * 4;   // staged bf16 tile + the tile's global row table
+    static constexpr int OUT_BYTES = tile80::Epi<BM, BN>::BYTES;   // the epilogue's staging area + the tile's global row table
     static constexpr int RED_BYTES = (KG - 1) * WM * WN * 25 * 1024;
     static constexpr int SMEM = RING_BYTES > OUT_BYTES ? (RING_BYTES > RED_BYTES ? RING_BYTES : RED_BYTES) : (OUT_BYTES > RED_BYTES ? OUT_BYTES : RED_BYTES);
     static_assert(SMEM <= 160 * 1024, "LDS");
@@ -220,14 +199,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     auto issue_w = [&](int stage, int slot_byte_off) {   // weight stage `stage` into the ring slot at this byte offset
         char* dst = w_base + slot_byte_off;
-        const int w_soff = stage * (NP * 64);   // byte offset of the stage within a pack row
+        const int w_soff = min(stage, p.nstage - 1) * (NP * 64);   // byte offset of the stage within a pack row (run-ahead past the end: the last stage again)
 #pragma unroll
         for (int j = 0; j < W_IT; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(dst + (lw + NWL * j) * 1024), 16, ld_off[j], w_soff, 0, 0);
     };
     auto issue_a = [&](int a_sub, int buf_off) {   // activation sub-slab a_sub (global index) into the buffer at byte offset buf_off
         char* dst = a_base + buf_off;
-        const int ch0 = a_sub * 32;
+        const int ch0 = min(a_sub, p.nsub - 1) * 32;   // (run-ahead past the end: the last sub-slab again — nothing is read outside the operands)
         const bool second = ch0 >= d.c0 && d.a1;
         const int ld2 = (second ? d.lda1 : d.lda0) * 2, soff = (second ? ch0 - d.c0 : ch0) * 2;
         const __amdgpu_buffer_rsrc_t rs = second ? rs_a1 : rs_a0;
@@ -392,125 +371,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     hwait_vmcnt<0>();   // the loaders ran ahead: nothing may still be landing when the LDS is reused
     if (HABL(256)) { if (acc[0][0][0] == 12345.678f) ((float*)d.out)[0] = acc[1][1][1]; return; }
 
-    // ---- k-groups: sum the partial accumulators through LDS (fixed order) ---------------------------------------------------
+    // ---- k-groups summed through LDS, then the workgroup-level epilogue (tile80.h) ------------------------------------------------
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the ring is dead
     asm volatile("" ::: "memory");
-    if constexpr (KG > 1) {
-        if (kgroup > 0) {
-            char* dst = smem + ((kgroup - 1) * WM * WN + wv) * (25 * 1024) + lane * 16;
-#pragma unroll
-            for (int bn = 0; bn < 5; ++bn)
-#pragma unroll
-                for (int bm = 0; bm < 5; ++bm) *(f32x4_t*)(dst + (bn * 5 + bm) * 1024) = acc[bn][bm];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kgroup == 0) {
-#pragma unroll
-            for (int g = 1; g < KG; ++g) {
-                const char* src = smem + ((g - 1) * WM * WN + wv) * (25 * 1024) + lane * 16;
-#pragma unroll
-                for (int bn = 0; bn < 5; ++bn)
-#pragma unroll
-                    for (int bm = 0; bm < 5; ++bm) acc[bn][bm] += *(const f32x4_t*)(src + (bn * 5 + bm) * 1024);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-
-    // ---- epilogue: bf16 tile -> LDS (whole workgroup) -> [+ residual, SiLU] -> full rows to memory; the per-32-row column
-    // statistics come from the parked (final) tile.  With a residual the sum is bf16(bf16(conv) + residual): the rounding the
-    // reference's own bf16 `skip + h` has (openaimodel3d.py:260), within the stated tolerance of the fp32 oracle.
-    constexpr int P = C::OUT_PITCH;
-    constexpr int CPR = BN / 8;                       // 16-byte chunks per tile row
-    constexpr int NIT = (BM * CPR + 511) / 512;       // row-pass iterations per thread
-    int* row_tab = (int*)(smem + BM * P);   // global row of every tile row (< 0: outside the image)
-    if (tid < BM) {
-        const int s = tid / Fx;
-        row_tab[tid] = token_of(s, tid - s * Fx);   // tile order: row-major over the S x FX rectangle
-    }
-    // the residual chunks of this thread's row pass, all in flight before the tile is parked (no DMA is outstanding any more)
-    uint4 rres[NIT];
-    if (d.residual) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = it * 512 + tid;
-            const int r = idx / CPR, c = idx - r * CPR;
-            rres[it] = make_uint4(0u, 0u, 0u, 0u);
-            if (idx < BM * CPR) {
-                const int s = r / Fx;
-                const int gm = token_of(s, r - s * Fx), ch = n0 + c * 8;
-                if (gm >= 0 && ch < d.N) rres[it] = *(const uint4*)((const bf16_t*)d.residual + (long long)gm * d.ldr + ch);
-            }
-        }
-    }
-    const bool act_late = d.residual != nullptr;   // the activation follows the residual add
-    if (kgroup == 0) {
-#pragma unroll
-        for (int bm = 0; bm < 5; ++bm) {
-            char* st = smem + ((rg * 5 + bm) * Fx + half * 16 + l15) * P + (wave_n * 80 + lq * 4) * 2;
-#pragma unroll
-            for (int bn = 0; bn < 5; ++bn) {
-                f32x4_t v = acc[bn][bm];
-                if (d.act == T2V_ACT_SILU && !act_late) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
-                *(uint2*)(st + bn * 32) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
-            }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    bf16_t* obase = (bf16_t*)d.out;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int idx = it * 512 + tid;
-        if (idx >= BM * CPR) break;
-        const int r = idx / CPR, c = idx - r * CPR;
-        const int gm = row_tab[r], ch = n0 + c * 8;
-        uint4 val = *(const uint4*)(smem + r * P + c * 16);
-        if (act_late) {
-            float x[8], y[8];
-            unpack8(val, x);
-            unpack8(rres[it], y);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                x[e] += y[e];
-                if (d.act == T2V_ACT_SILU) x[e] = silu_f(x[e]);
-            }
-            val = pack8(x);
-            if (d.colstat_out) *(uint4*)(smem + r * P + c * 16) = val;   // the statistics are of what is stored
-        }
-        if (gm >= 0 && ch < d.N && !HABL(32)) *(uint4*)(obase + (long long)gm * d.ldo + ch) = val;
-    }
-    if (d.colstat_out) {
-        if (act_late) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-        // (sum, sum of squares) per 32-row slab and column of the bf16 values just stored: item = (slab, column pair)
-        constexpr int NSL = BM / 32, NCP = BN / 2;
-        for (int it = tid; it < NSL * NCP; it += 512) {
-            const int sl = it / NCP, cp = it - sl * NCP;
-            const int gm0 = row_tab[sl * 32];
-            const int col = n0 + 2 * cp;
-            if (gm0 < 0 || col >= d.N) continue;
-            float a0 = 0.f, q0 = 0.f, a1 = 0.f, q1 = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < 32; ++r) {
-                const uint32_t w2 = *(const uint32_t*)(smem + (sl * 32 + r) * P + cp * 4);
-                const float x0 = __uint_as_float(w2 << 16), x1 = __uint_as_float(w2 & 0xffff0000u);
-                a0 += x0; q0 = fmaf(x0, x0, q0);
-                a1 += x1; q1 = fmaf(x1, x1, q1);
-            }
-            const long long slab = (long long)(gm0 >> 5);   // (host-checked: a tile-order slab is 32 consecutive global rows)
-            *(float4*)(d.colstat_out + (slab * d.N + col) * 2) = make_float4(a0, q0, a1, q1);
-        }
-    }
+    tile80::reduce_kgroups<KG, WM * WN>(smem, acc, kgroup, wv, lane);
+    tile80::epilogue<BM, BN>(
+        smem, d, acc, kgroup == 0, wave_n * 80 + lq * 4, tid, n0,
+        [&](int bm) { return (rg * 5 + bm) * Fx + half * 16 + l15; },                       // tile order: row-major over the S x FX rectangle
+        [&](int r) { const int s = r / Fx; return token_of(s, r - s * Fx); }, HABL(32));
 #endif
 }
 

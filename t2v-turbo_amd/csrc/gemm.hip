@@ -25,6 +25,7 @@
 //  * workgroup id -> tile mapping is XCD-aware: each of the 8 XCDs (private L2s) gets a contiguous
 //    run of tiles, N-tile fastest, so the tiles that share an A panel hit the same L2.
 #include "common.h"
+#include "gemm2.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -1478,12 +1479,38 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
     return T2V_OK;
 }
 
+// The second kernel family (gemm2.hip: static-schedule main loop, 80x80 wave tiles; tile ids 50 / 51) for LINEAR / TCONV3 launches
+// with a plain epilogue.  MEASURED SLOWER than the tuned first-family tiles on every UNet shape (profiles/r04_gemm2_*.csv: 62 vs
+// 44 us at 40960 x 320 x 1280, 54 vs 43 us at 10240 x 640 x 2560): with both operands restaged per K step a 320x160 tile needs
+// 3.75 LDS-DMA pieces per wave per 25 MFMAs (conv_halo: 1.25) and 64-byte row pieces fetch every cache line twice — the loop is
+// bound by DMA issue and L2 -> LDS bytes, not by its schedule.  Kept as a tested, measured negative result: OFF unless asked for
+// (t2v_gemm2_enable(1) / T2V_GEMM2=1: the library's own routing rule; tile id 50 / 51 forced: that tile).
+static int g_gemm2 = -1;
+extern "C" int t2v_gemm2_enable(int on) { g_gemm2 = on ? 1 : 0; return T2V_OK; }
+// c2 > 0: the second family takes this launch.  It implements the column statistics (fuse == 2) itself; every other fused request
+// (row statistics, LayerNorm fold, LoRA / dropout epilogue) and the LayerNorm second output stay with the first family.
+static int gemm2_route(const t2v_gemm_desc* dd, int fuse, Gemm2Params& p2, int& c2) {
+    c2 = 0;
+    if (g_gemm2 < 0) g_gemm2 = (getenv("T2V_GEMM2") && getenv("T2V_GEMM2")[0] == '1') ? 1 : 0;
+    const int want = g_force_cfg ? g_force_cfg : dd->tile_cfg;
+    const int forced = (want == 50 || want == 51) ? want - 49 : 0;
+    if ((fuse & ~2) || dd->ln_out || !(forced || (g_gemm2 && !g_force_cfg))) return T2V_OK;
+    return t2v_gemm2_prepare(dd, p2, forced, c2);
+}
+
 extern "C" int t2v_gemm_fuse_supported(const t2v_gemm_desc* dd) {
     GemmParams p;
     int cfg = 0, fuse = 0, fuse_cfg = 0;
     bool ok = false;
     const int rc = gemm_prepare(dd, p, cfg, fuse, fuse_cfg, ok);
     if (rc != T2V_OK) return rc;
+    if (fuse == 2) {   // column statistics: the second kernel family carries them on the launches it takes
+        Gemm2Params p2;
+        int c2 = 0;
+        const int rc2 = gemm2_route(dd, fuse, p2, c2);
+        if (rc2 != T2V_OK) return rc2;
+        if (c2) return 1;
+    }
     return ((fuse & ~8) && ok) ? 1 : 0;   // (bit 8 is the library's own choice for dropout launches, not a request)
 }
 
@@ -1495,6 +1522,13 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     if (rc != T2V_OK) return rc;
     t2v_gemm_desc& d = p.d;
     hipStream_t s = (hipStream_t)stream;
+    {
+        Gemm2Params p2;
+        int c2 = 0;
+        const int rc2 = gemm2_route(dd, fuse, p2, c2);
+        if (rc2 != T2V_OK) return rc2;
+        if (c2) return t2v_gemm2_dispatch(c2, p2, s);
+    }
     if (fuse) {
         T2V_REQUIRE(fuse_ok, T2V_ESHAPE, "t2v_gemm: this launch cannot carry fused statistics (ask t2v_gemm_fuse_supported first)");
         return t2v_gemm_launch_fused(fuse_cfg, fuse, p, s);

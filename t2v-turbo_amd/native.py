@@ -100,6 +100,7 @@ _SIGS = {
     "t2v_conv_halo_pack_cols": (C.c_int, [C.c_int]),
     "t2v_replay_lookup": (C.c_int, [C.c_char_p]),
     "t2v_replay": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.POINTER(C.c_int)]),
+    "t2v_gemm2_enable": (C.c_int, [C.c_int]),
     "t2v_gemm_force_config": (C.c_int, [C.c_int]),
     "t2v_gemm_force_split": (C.c_int, [C.c_int]),
     "t2v_gemm_num_configs": (C.c_int, []),

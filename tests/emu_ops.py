@@ -189,14 +189,7 @@ class EmuOps:
         assert not w[:, 9 * cin:].any(), "the padding columns of a slab-major pack must be zero"
         colstat = kw.pop("colstat", None)
         kw.pop("tile_cfg", None)
-        residual, act = kw.pop("residual", None), kw.pop("act", nt.ACT_NONE)
-        if residual is None:
-            self.gemm(a0, nt.unpack_conv_slab(w, cin), out, act=act, **kw)
-        else:   # the kernel adds the residual to the tile it has already rounded to the output dtype (as the reference's `skip + h` does)
-            self.gemm(a0, nt.unpack_conv_slab(w, cin), out, **kw)
-            M, N = kw["M"], kw["N"]
-            y = out[:M, :N].float() + residual[:M, :N].float()
-            out[:M, :N] = (F.silu(y) if act == nt.ACT_SILU else y).to(out.dtype)
+        self.gemm(a0, nt.unpack_conv_slab(w, cin), out, **kw)   # (residual and activation in fp32 before the one rounding, as the kernel)
         if colstat is not None:
             M, N = kw["M"], kw["N"]
             yo = out[:M, :N].float().reshape(M // 32, 32, N)

@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "t2v-turbo_amd", "csrc")
 SOURCES = ["backward.hip", "backward_unet.hip", "train.hip", "wgrad_tn.hip"]
-GEMM_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip"]   # MFMA + LDS-DMA: simulated as wave collectives (separate, slower-to-build library)
+GEMM_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "gemm2.hip"]   # MFMA + LDS-DMA: simulated as wave collectives (separate, slower-to-build library)
+GEMM_HEADERS = ["tile80.h", "gemm2.h"]
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libt2v_hostsim.so")
 GEMM_LIB = os.path.join(OUT, "libt2v_hostsim_gemm.so")
@@ -47,12 +48,14 @@ def patch(text):
 
 def build_gemm(force=False):
     """t2v_gemm (+ the experimental tile ids) on the simulator.  Minutes of g++ time: built on demand by its own test module."""
-    deps = [os.path.join(CSRC, s) for s in GEMM_SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
+    deps = [os.path.join(CSRC, s) for s in GEMM_SOURCES + GEMM_HEADERS] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
                                                            os.path.abspath(__file__), os.path.join(ROOT, "include", "t2v_hip.h")]
     if not force and os.path.exists(GEMM_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(GEMM_LIB) for d in deps):
         return GEMM_LIB
     os.makedirs(OUT, exist_ok=True)
     procs, objs = [], []
+    for hdr in GEMM_HEADERS:   # (device headers the sources include: patched like them)
+        open(os.path.join(OUT, hdr), "w").write(patch(open(os.path.join(CSRC, hdr)).read()))
     for src in GEMM_SOURCES:
         cpp = os.path.join(OUT, src.replace(".hip", ".cpp"))
         open(cpp, "w").write(patch(open(os.path.join(CSRC, src)).read()))
@@ -69,20 +72,20 @@ def build_gemm(force=False):
     return GEMM_LIB
 
 
-FULL_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "replay.hip"]
+FULL_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "gemm2.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "replay.hip"]
 FULL_LIB = os.path.join(OUT, "libt2v_hostsim_full.so")
 
 
 def build_full(force=False):
     """EVERY source of libt2v_hip.so on the simulator: the engines can then run on the real C-ABI end to end, on the CPU."""
-    deps = [os.path.join(CSRC, s) for s in FULL_SOURCES] + [os.path.join(CSRC, "gn_bwd_common.h"), os.path.join(HERE, "common.h"),
+    deps = [os.path.join(CSRC, s) for s in FULL_SOURCES + GEMM_HEADERS] + [os.path.join(CSRC, "gn_bwd_common.h"), os.path.join(HERE, "common.h"),
                                                            os.path.join(HERE, "hip", "hip_runtime.h"), os.path.abspath(__file__),
                                                            os.path.join(ROOT, "include", "t2v_hip.h")]
     if not force and os.path.exists(FULL_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(FULL_LIB) for d in deps):
         return FULL_LIB
     full = os.path.join(OUT, "full")
     os.makedirs(full, exist_ok=True)
-    for src in FULL_SOURCES + ["gn_bwd_common.h"]:
+    for src in FULL_SOURCES + ["gn_bwd_common.h"] + GEMM_HEADERS:
         open(os.path.join(full, src.replace(".hip", ".cpp")), "w").write(patch(open(os.path.join(CSRC, src)).read()))
     procs, objs = [], []
     for src in FULL_SOURCES:

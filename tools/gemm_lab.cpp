@@ -55,6 +55,7 @@ struct Lib {
     int (*init)() = nullptr;
     int (*debug)(int) = nullptr;
     int (*hdebug)(int) = nullptr;
+    int (*g2enable)(int) = nullptr;
     const char* (*last_error)() = nullptr;
 };
 
@@ -67,6 +68,7 @@ static Lib load_lib(const std::string& path) {
     l.init = (int (*)())dlsym(l.h, "t2v_init");
     l.debug = (int (*)(int))dlsym(l.h, "t2v_gemm_debug");
     l.hdebug = (int (*)(int))dlsym(l.h, "t2v_conv_halo_debug");
+    l.g2enable = (int (*)(int))dlsym(l.h, "t2v_gemm2_enable");
     l.last_error = (const char* (*)())dlsym(l.h, "t2v_last_error");
     if (!l.gemm || !l.init) { fprintf(stderr, "%s: missing symbols\n", path.c_str()); exit(1); }
     if (l.init() != 0) { fprintf(stderr, "%s: t2v_init failed\n", path.c_str()); exit(1); }
@@ -164,10 +166,11 @@ int main(int argc, char** argv) {
         d.M = (int)M; d.N = n; d.w = bw.d; d.ldw = K; d.batch = 1; d.batch_inner = 1; d.alpha = 1.0f; d.bias = (const float*)bbias.d;
         if (rv) { d.rowvec = (const float*)brv.d; d.rowvec_div = h * w; d.ld_rowvec = n; }
         if (res && act != 1) { d.residual = bres.d; d.ldr = n_out; }
-        d.act = act; d.out = bo.d; d.ldo = n_out; d.tile_cfg = cfg; d.split_k = split; d.ws = bws.d; d.ws_bytes = (long long)bws.bytes;
+        d.act = act; d.out = bo.d; d.ldo = n_out; d.tile_cfg = cfg == 49 ? 0 : cfg; d.split_k = split; d.ws = bws.d; d.ws_bytes = (long long)bws.bytes;
         Lib& L = libs[lib];
         if (L.debug) L.debug(debug);
         if (L.hdebug) L.hdebug(debug);
+        if (L.g2enable) L.g2enable(cfg == 50 || cfg == 51 || cfg == 49);   // 49: the library's own routing between the two families
         const bool halo = cfg >= 39 && cfg < 44;
         int (*run)(const t2v_gemm_desc*, void*) = L.gemm;
         if (halo) {
