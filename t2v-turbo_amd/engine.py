@@ -417,7 +417,7 @@ class _Engine:
         return self.fuse_ln and wide_ok and tuple(norm.normalized_shape) == (C,) and norm.elementwise_affine
 
     def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto",
-             want_cs=True, extra=None, fallback=None):
+             want_cs=True, extra=None, fallback=None, frozen_pack=False):
         """3x3 / strided / upsampled / temporal conv of an Act (virtual concat allowed); ``w`` / ``bias`` override the
         module's packed forward weights (data-gradient convs pass the flipped / transposed pack and no bias).  With
         ``fuse_gn`` the launch also writes its output's column statistics for the GroupNorm that follows every conv of the UNet."""
@@ -438,9 +438,11 @@ class _Engine:
         # 3x3 convs whose width fills whole 80-channel tiles go to the halo-slab kernel (csrc/conv_halo.hip: the activation tile and
         # its halo stay in LDS across the nine taps; 14-32 % faster than the tuned t2v_gemm tiles at the UNet's three upper levels,
         # profiles/r04_conv_halo_v3_static_schedule.csv) when the launch has the module's own weights and a plain epilogue
-        if (self.conv_halo and own_w and extra is None and mode == nt.GEMM_CONV3X3 and N % 80 == 0 and hasattr(self.ops, "conv_halo_supported")
-                and out.dtype == self.adt):
-            ws = self.pk.conv_slab(mod)
+        if (self.conv_halo and (own_w or frozen_pack) and extra is None and mode == nt.GEMM_CONV3X3 and N % 80 == 0
+                and hasattr(self.ops, "conv_halo_supported") and out.dtype == self.adt and w.dtype == self.adt):
+            # (``frozen_pack``: a caller-given pack of FROZEN weights — the data-gradient convs' flipped base weights, which live in the
+            # Packer's cache — is repacked once; packs that are rewritten every step, like the LoRA groups', must not be cached here)
+            ws = self.pk.conv_slab(mod) if own_w else self.pk._memo(("conv_slab_of", id(w)), lambda: (w, nt.pack_conv_slab(w)))[1]
             cs = None
             if want_cs and self.fuse_gn and M % 32 == 0:
                 cs = self.buf(M // 32, 2 * N, torch.float32)

@@ -72,11 +72,10 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         # the inference engine; the tape keeps (mean, rstd) for the backward either way.  T2V_FUSE_GN_TRAIN=0: statistics pass
         # over the tensor (t2v_gn_stats).
         self.fuse_gn = os.environ.get("T2V_FUSE_GN_TRAIN", "1") == "1"
-        # the forward convs stay on t2v_gemm here: t2v_conv_halo adds a residual operand to the tile it has already rounded to bf16
-        # (the reference's own bf16 `skip + h` rounding), and EVERY LoRA-injected conv of the student carries its branch as such a
-        # residual — the training forward would pick up one extra rounding per leaf (full-width parity gate: d/dx 5.7e-2 -> above
-        # the 6e-2 bound).  T2V_CONV_HALO_TRAIN=1 switches it on for measurement.
-        self.conv_halo = os.environ.get("T2V_CONV_HALO_TRAIN", "0") == "1"
+        # 3x3 convs on t2v_conv_halo where it takes them: the base data-gradient convs of the backward (flipped packs), and the
+        # forward convs when the LoRA branch does not ride in the base leaf's epilogue (T2V_LORA_EPILOGUE=0).  Its residual add is
+        # the fp32 row pass of tile80.h (one rounding), so the training numerics are those of t2v_gemm.  T2V_CONV_HALO_TRAIN=0: off.
+        self.conv_halo = os.environ.get("T2V_CONV_HALO_TRAIN", "1") == "1"
 
     # ---- public: forward with tape, then backward ----------------------------------------------------------------
     def _active_dropouts(self):
@@ -424,7 +423,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             self.pool.put(zf)
         return out
 
-    def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto"):
+    def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto", frozen_pack=False):
         zf = extra = None
         if w is None and self.training_lora and is_lora_leaf(mod):
             if mode == nt.GEMM_CONV3X3_S2:
@@ -440,7 +439,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 zf, residual = self.lora_up(grp, x.n_img * ho * wo, residual)
         y = super().conv(x, mod, mode, frames=frames, rowvec=rowvec, rowvec_div=rowvec_div, residual=residual,
                          out_dtype=out_dtype, w=w, bias=bias, want_cs=w is None,   # (data-gradient convs pass their own pack: no statistics)
-                         extra=extra, fallback=None if extra is None else (lambda: self.lora_up(grp, x.n_img * ho * wo, residual)))
+                         frozen_pack=frozen_pack, extra=extra, fallback=None if extra is None else (lambda: self.lora_up(grp, x.n_img * ho * wo, residual)))
         if zf is not None:
             self.pool.put(zf)
         return y
@@ -477,8 +476,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         base = self.tconv_dgrad_w(mod) if mode == nt.GEMM_TCONV3 else self.pk.conv_dgrad(mod)
         inner_mode = nt.GEMM_TCONV3 if mode == nt.GEMM_TCONV3 else nt.GEMM_CONV3X3
 
-        def run(src, wpack, residual=None, odt=None, pool=True):
-            """adjoint gather of ``src`` (a tensor on the output grid) against an [N, taps*c] pack"""
+        def run(src, wpack, residual=None, odt=None, pool=True, frozen=False):
+            """adjoint gather of ``src`` (a tensor on the output grid) against an [N, taps*c] pack (``frozen``: of frozen weights)"""
             if mode == nt.GEMM_CONV3X3_S2:
                 z = self.buf(m_in, src.shape[1])
                 ops.scatter2x(src, n, dy.h, dy.w, h, w, z)
@@ -494,7 +493,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 self.pool.put(hi.t)
                 return lo
             return self.conv(Act(src, n, h, w), None, inner_mode, frames=frames, w=wpack, bias=None, residual=residual,
-                             out_dtype=odt).t
+                             out_dtype=odt, frozen_pack=frozen).t
 
         grp = self.saved_group([mod], mode)
         dl = None
@@ -512,7 +511,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 self.lora_wgrad_down(grp, dl[:, grp.ce:])
         cin = base.shape[0]
         res = None if dl is None else dl[:, :cin]
-        dx = run(dy.t, base, residual=res, odt=out_dtype)
+        dx = run(dy.t, base, residual=res, odt=out_dtype, frozen=True)
         if dl is not None:
             self.pool.put(dl)
         return Act(dx, n, h, w)
