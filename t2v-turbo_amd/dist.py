@@ -54,29 +54,49 @@ class FlatGradSync:
         self.numel = n
         self.force = False        # True: the native engine exchanges its gradients even in a one-rank group (RCCL smoke tests)
         self._rest_idx = None
+        self._local_dirty = False
 
     def zero_(self):
         self.flat.zero_()
         self._rest_idx = None
+        self._local_dirty = False
 
     def mark_engine_reduced(self, rest_idx):
         """The native gradient engine has written ALREADY AVERAGED gradients for its tensors (it all-reduces its gradient arena
         in segments while the backward runs: engine_lora); what is left for ``all_reduce_mean`` are the flat positions
-        ``rest_idx`` (int64) — the conditioning branch's tensors, which torch differentiates after the engine's backward."""
+        ``rest_idx`` (int64) — the conditioning branch's tensors, which torch differentiates after the engine's backward.
+
+        INVARIANT: between ``zero_()`` and ``all_reduce_mean()`` nothing but that one overlapped backward may have written the
+        engine's positions: an un-averaged local contribution there (a second student call of the same step that went through the
+        torch composite path, say) would never be exchanged and the ranks would drift apart silently.  ``note_local_grads()`` is
+        how such a writer says so; the next ``all_reduce_mean`` then exchanges the whole buffer.  (The averaged engine gradients are
+        divided by the world size once more in that case — a step that mixes the two routes is refused instead: see below.)"""
+        if getattr(self, "_local_dirty", False):
+            raise RuntimeError("FlatGradSync: un-averaged local gradients were accumulated into the flat buffer in the same step as an "
+                               "overlapped (already averaged) engine backward; exchange them first or use T2V_ASYNC_ALLREDUCE=0")
         self._rest_idx = rest_idx
+
+    def note_local_grads(self):
+        """A backward that leaves UN-averaged gradients in the flat buffer (torch autograd through the composite path, the engine's
+        blocking mode) has run: the next exchange must cover the whole buffer."""
+        if self._rest_idx is not None:
+            raise RuntimeError("FlatGradSync: un-averaged local gradients after an overlapped (already averaged) engine backward in the "
+                               "same step; use T2V_ASYNC_ALLREDUCE=0 for steps that mix the two routes")
+        self._local_dirty = True
 
     def all_reduce_mean(self, async_op=False, force=False):
         """``force``: run the collective even in a one-rank group (smoke tests of the RCCL path)."""
         rest, self._rest_idx = self._rest_idx, None
+        self._local_dirty = False
         if not dist.is_initialized() or (dist.get_world_size() == 1 and not (force or self.force)):
-            return None
+            return _DoneWork() if async_op else None
         if rest is not None:
             if rest.numel():
                 buf = self.flat.index_select(0, rest)
                 buf.div_(dist.get_world_size())
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM)
                 self.flat.index_copy_(0, rest, buf)
-            return None
+            return _DoneWork() if async_op else None   # (the subset exchange is blocking: a caller that asked for a handle gets a completed one)
         self.flat.div_(dist.get_world_size())
         return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
@@ -99,6 +119,16 @@ class FlatGradSync:
         scale = torch.clamp(max_norm / (norm + 1e-6), max=1.0)
         self.flat.mul_(scale)
         return norm
+
+
+class _DoneWork:
+    """A completed work handle (``wait()`` / ``is_completed()``) for exchanges that had nothing asynchronous left to do."""
+
+    def wait(self, *_a, **_k):
+        return True
+
+    def is_completed(self):
+        return True
 
 
 def broadcast_parameters(module, src=0):

@@ -362,7 +362,7 @@ class _Engine:
     def _colstat_for(self, a0, w, out, **kw):
         """A column-statistics buffer for this launch's output if the launch can carry it (linked to ``out`` in the pool)."""
         M, N = kw["M"], kw["N"]
-        if not self.fuse_gn or M % 32 or out.dtype != self.adt:
+        if not self.fuse_gn or M % 32 or N % 2 or out.dtype != self.adt:
             return None
         cs = self.buf(M // 32, 2 * N, torch.float32)
         if not self.ops.gemm_fuse_supported(a0, w, out, colstat=cs, **kw):
@@ -395,7 +395,7 @@ class _Engine:
             self.last_cs = self._colstat_for(a, w, out, **kw)
             if self.last_cs is not None:
                 kw["colstat"] = self.last_cs
-        elif want_rs and self.fold_ln and N % 32 == 0 and out.dtype == self.adt:
+        elif want_rs and self.fold_ln and N % 64 == 0 and out.dtype == self.adt:   # (t2v_gemm: ld_rowstat = N / 16 must be a multiple of 4)
             rs = self.buf(a.shape[0], N // 16, torch.float32)
             if self.ops.gemm_fuse_supported(a, w, out, rowstat=rs, **kw):
                 self.pool.link(out, rs)

@@ -167,7 +167,9 @@ class LoraTrainMixin:
         moves a version counter (FlatAdamW.step touches one on purpose), and a re-homed parameter moves its data pointer.
         Contract: a write that moves no version counter (through ``p.data``, or through a flat buffer the tensors are ``.data``
         views of — a restored ``flat_param``, an EMA or a custom optimizer on the flat buffer) must call
-        ``invalidate_lora_packs()``; ``FlatAdamW.step`` and ``update_ema_flat`` do (they also touch one version counter)."""
+        ``invalidate_lora_packs()``.  ``FlatAdamW.step`` and ``update_ema_flat`` do NOT call it: they write through the flat buffer and
+        then TOUCH one tensor's version counter on purpose (``add_(0.0)``), which is what this fingerprint sees — do not remove
+        that touch on the strength of an invalidation hook that nothing registers."""
         fp = 0
         for p in self.lora_params:   # every version counter and every data pointer (re-homing of ANY tensor is seen)
             fp = (fp * 1000003 + p._version * 31 + (p.data_ptr() & 0xFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFF

@@ -191,6 +191,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                     grad_sync.mark_engine_reduced(self.conditioning_index())
                 else:
                     self.lora_grads_into(flat_grad, accumulate)
+                    if grad_sync is not None and hasattr(grad_sync, "note_local_grads"):
+                        grad_sync.note_local_grads()   # un-averaged: the next all_reduce_mean covers the whole buffer
         return plan["dx"].clone()
 
     def _overlap_world(self, grad_sync, flat_grad):

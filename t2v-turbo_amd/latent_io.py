@@ -55,14 +55,19 @@ class LatentRecordDataset(Dataset):
     def __init__(self, path_to_csv, latent_root="latent_root", root_dir="."):
         self.latent_root, self.root_dir = latent_root, root_dir
         with open(path_to_csv, newline="") as f:
-            self.rows = list(csv.DictReader(f))
+            reader = csv.DictReader(f)
+            self.rows = list(reader)
+            fields = reader.fieldnames or []
         self.length = len(self.rows)
         # CSV schema / parse errors are the annotation file's, not a record's: found here, once, for every row — resampling
         # on them would spin forever.  Everything raised later, while a record file is read or checked, is a per-record fault.
+        # A missing COLUMN is the file's fault (raise here); a short ROW (DictReader yields None for its missing cells) is one bad
+        # record: the reference tolerates those (data/mp4_dataset.py: pandas fills NaN, the record is resampled on the assert) and so
+        # does __getitem__'s bounded resampling.
+        for col in ("relpath", "text"):
+            if col not in fields:
+                raise KeyError(f"{path_to_csv}: lacks the column {col!r}")
         for i, row in enumerate(self.rows):
-            for col in ("relpath", "text"):
-                if row.get(col) is None:
-                    raise KeyError(f"{path_to_csv}: row {i} lacks the column {col!r}")
             if row.get("use_motion_guide") not in (None, ""):
                 row["use_motion_guide"] = _parse_bool(row["use_motion_guide"])
 
@@ -72,6 +77,8 @@ class LatentRecordDataset(Dataset):
     def get_latent_text_pair(self, idx):
         row = self.rows[idx]
         relpath, text = row["relpath"], row["text"]
+        if relpath is None or text is None:
+            raise ValueError(f"annotation row {idx} is short (no relpath / text)")   # a per-record fault: resampled by __getitem__
         root = row.get("latent_root") or self.latent_root
         latent_dir = f"{root}/{relpath}"
         use_motion_guide = row["use_motion_guide"] if row.get("use_motion_guide") not in (None, "") else True   # parsed in __init__

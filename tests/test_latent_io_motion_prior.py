@@ -143,3 +143,32 @@ def test_dataset_resamples_on_any_per_record_fault(tmp_path):
     random.seed(0)
     for i in range(5):
         assert ds[i]["txt"] == "a cat"      # every faulty row ends up on the one good record
+
+
+def test_short_csv_row_is_a_record_fault_not_a_constructor_error(tmp_path):
+    """A row with fewer cells than the header (DictReader yields None) is ONE bad record: the constructor accepts the file and the
+    record itself is refused when read (``__getitem__`` resamples on that, as data/mp4_dataset.py:139-154 does on any per-record
+    fault); a missing COLUMN still raises at construction."""
+    import csv as _csv
+
+    import pytest as _pytest
+
+    from t2v_turbo_amd.latent_io import LatentRecordDataset
+
+    p = tmp_path / "ann.csv"
+    with open(p, "w", newline="") as f:
+        w = _csv.writer(f)
+        w.writerow(["relpath", "text"])
+        w.writerow(["a.mp4", "a cat"])
+        w.writerow(["b.mp4"])                       # short row
+    ds = LatentRecordDataset(str(p), latent_root="lat", root_dir=str(tmp_path))
+    assert len(ds) == 2
+    with _pytest.raises(ValueError, match="short"):
+        ds.get_latent_text_pair(1)
+    bad = tmp_path / "bad.csv"
+    with open(bad, "w", newline="") as f:
+        w = _csv.writer(f)
+        w.writerow(["relpath"])
+        w.writerow(["a.mp4"])
+    with _pytest.raises(KeyError):
+        LatentRecordDataset(str(bad), latent_root="lat", root_dir=str(tmp_path))
