@@ -95,9 +95,9 @@ typedef struct t2v_gemm_desc {
     void* ws;
     long long ws_bytes;
     /* dropout between the product and the residual (0 threshold = off): out = keep ? (alpha*acc + bias) / (1 - p) : 0, then
-     * + rowvec + residual.  The mask is t2v_dropout_bf16's: one splitmix64 word per PAIR of adjacent columns of a
-     * [rows][drop_ncols] matrix in which this launch's output starts at column drop_col0 (both even), low / high 32 bits against
-     * drop_thr = p * 2^32; the 64-bit seed is read from device memory.  LoraInjected*.forward's dropout(up(down(x))) * scale
+     * + rowvec + residual.  The mask is t2v_dropout_bf16's: one splitmix64 word per QUAD of adjacent elements of a
+     * row-major [rows][drop_ncols] matrix in which this launch's output starts at column drop_col0 (both multiples of 4), 16 bits per
+     * element against drop_thr >> 16 (drop_thr = p * 2^32); the 64-bit seed is read from device memory.  LoraInjected*.forward's dropout(up(down(x))) * scale
      * (utils/lora.py:45-50) as the epilogue of the up-projection.  Not combined with GEGLU / split-K. */
     const void* drop_seed;
     unsigned drop_thr, drop_site;
@@ -160,6 +160,10 @@ int t2v_gemm(const t2v_gemm_desc* d, void* stream);
  * split-K factor exactly as the launch does: fast kernel, one K split, a tile that carries the fused epilogue), 0 if the
  * caller has to use the standalone normalisation kernels, negative on an invalid descriptor.  Launches nothing. */
 int t2v_gemm_fuse_supported(const t2v_gemm_desc* d);
+/* The tile id and the K-split count t2v_gemm would use for the descriptor (resolved exactly as the launch does; launches nothing).
+ * The gradient engine asks with the PLAIN descriptor before it attaches a LoRA epilogue (lora_*: one K split only): where the plain
+ * launch would split K, the three-launch form (up-projection launches + split base leaf) is faster. */
+int t2v_gemm_plan(const t2v_gemm_desc* d, int* tile_cfg, int* splits);
 /* 3x3 convolution (stride 1, pad 1) with the activation tile's halo slab RESIDENT in LDS across all nine filter taps
  * (csrc/conv_halo.hip): same descriptor as t2v_gemm (mode T2V_GEMM_CONV3X3, virtual concat allowed; no batch / split-K /
  * dropout / GEGLU / fp32 output; epilogue: bias, rowvec, residual, SiLU, colstat_out), EXCEPT that `w` holds the SLAB-MAJOR pack:
@@ -418,8 +422,8 @@ int t2v_wgrad_tn_group(const t2v_wgrad_problem* problems, int n, float* ws, long
 int t2v_transpose_pad_bf16(const void* in, int ld_in, int rows, int cols, void* out, int ld_out, int batch, long long in_stride,
                            long long out_stride, void* stream);
 /* t2v_dropout_bf16: out[r][c] = keep(r, c) ? x[r][c] / (1 - p) : 0  (+ resid[r][c]) over rows x ncols bf16 (ncols even), where
- * keep is a pure function of (*seed, site, r * ncols + c): splitmix64(seed + site * 0x9E3779B97F4A7C15 + pair * 0xD1B54A32D192ED03)
- * per pair of adjacent columns, low / high 32 bits compared with p * 2^32.  The backward calls it again with the same (seed,
+ * keep is a pure function of (*seed, site, i = r * ncols + c): word = splitmix64(seed + site * 0x9E3779B97F4A7C15 + (i >> 2) *
+ * 0xD1B54A32D192ED03), element i keeps iff bits [16 (i & 3), +16) of the word >= (p * 2^32) >> 16 (p resolved to 2^-16).  The backward calls it again with the same (seed,
  * site) on the gradient.  seed: device pointer to one uint64 (a replayed launch list follows the step's seed).  In-place is
  * allowed (out == x).  Replaces nn.Dropout in LoraInjected*.forward (utils/lora.py:45-50,124-129) and TemporalConvBlock
  * (openaimodel3d.py:280-297); the random stream is not torch's (train-mode parity is statistical). */

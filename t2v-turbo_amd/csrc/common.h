@@ -54,16 +54,36 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// counter-based dropout bits: one splitmix64 finaliser per PAIR of adjacent columns (low / high 32 bits); shared by
-// t2v_dropout_bf16 (train.hip) and the dropout epilogue of t2v_gemm
+// counter-based dropout bits: one splitmix64 finaliser per QUAD of adjacent elements of the row-major [rows][ncols] matrix (flat
+// index i = row * ncols + col: word = quad i >> 2, 16 bits per element, element i & 3 = bits [16 (i & 3), +16)), compared with
+// thr16 = (p * 2^32) >> 16.  Shared by t2v_dropout_bf16 (train.hip) and the dropout / LoRA epilogues of t2v_gemm.  (Rounds 1-3 drew
+// 32 bits per element, one word per pair: the mask arithmetic — six quarter-rate 32-bit multiplies per word — was 2/3 of the LoRA
+// epilogue's cost; p is resolved to 2^-16 now, 0.1 -> 6553 / 65536.)
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
     z ^= z >> 27; z *= 0x94D049BB133111EBull;
     z ^= z >> 31;
     return z;
 }
-__device__ __forceinline__ uint64_t dropout_bits(uint64_t seed, uint32_t site, uint64_t pair) {
-    return splitmix64(seed + (uint64_t)site * 0x9E3779B97F4A7C15ull + pair * 0xD1B54A32D192ED03ull);
+constexpr uint64_t kDropQuadMul = 0xD1B54A32D192ED03ull;
+__device__ __forceinline__ uint64_t dropout_key(uint64_t seed, uint32_t site) { return seed + (uint64_t)site * 0x9E3779B97F4A7C15ull; }
+__device__ __forceinline__ uint64_t dropout_quad(uint64_t key, uint64_t quad) { return splitmix64(key + quad * kDropQuadMul); }
+__device__ __forceinline__ bool dropout_keep16(uint64_t word, int e, uint32_t thr16) {   // e in 0..3
+    const uint32_t half = (e & 2) ? (uint32_t)(word >> 32) : (uint32_t)word;
+    return ((e & 1) ? (half >> 16) : (half & 0xffffu)) >= thr16;
+}
+// keep bits of 4 NQ consecutive elements starting at flat index 4 quad0: bit e of the result = element e kept
+template <int NQ>
+__device__ __forceinline__ uint32_t dropout_keep_mask(uint64_t key, uint64_t quad0, uint32_t thr16) {
+    const uint64_t z0 = key + quad0 * kDropQuadMul;   // one 64-bit multiply for the run; the quads after it are constant adds
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const uint64_t w = splitmix64(z0 + (uint64_t)k * kDropQuadMul);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m |= dropout_keep16(w, e, thr16) ? (1u << (4 * k + e)) : 0u;
+    }
+    return m;
 }
 
 // host side

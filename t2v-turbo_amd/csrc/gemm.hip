@@ -158,14 +158,11 @@ struct Epi {
         if constexpr (!FAST) {  // dropout(alpha * acc + bias) / (1 - p): only the generic kernels carry it (the host keeps launches
                                 // with a dropout threshold off the FAST ones, whose epilogue is sized for the inference step)
             if (dd.drop_thr) {
-                const uint64_t seed = *(const uint64_t*)dd.drop_seed;
-                const uint64_t pair0 = ((uint64_t)gm * (uint64_t)dd.drop_ncols + (uint64_t)(dd.drop_col0 + ch_out)) >> 1;
+                const uint64_t key = dropout_key(*(const uint64_t*)dd.drop_seed, dd.drop_site);
+                const uint64_t quad0 = ((uint64_t)gm * (uint64_t)dd.drop_ncols + (uint64_t)(dd.drop_col0 + ch_out)) >> 2;
+                const uint32_t keep = dropout_keep_mask<4>(key, quad0, dd.drop_thr >> 16);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const uint64_t b = dropout_bits(seed, dd.drop_site, pair0 + k);
-                    v[2 * k] = ((uint32_t)b >= dd.drop_thr) ? v[2 * k] * dd.drop_inv_keep : 0.f;
-                    v[2 * k + 1] = ((uint32_t)(b >> 32) >= dd.drop_thr) ? v[2 * k + 1] * dd.drop_inv_keep : 0.f;
-                }
+                for (int e = 0; e < 16; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * dd.drop_inv_keep : 0.f;
             }
         }
         const bool folded_rr = FOLD && !gate;  // rowvec / residual already inside the accumulators
@@ -862,42 +859,69 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
             flush_slab<P, TN * 4>(st, lane, (bf16_t*)d.ln_out, d.ld_ln_out, m0 + wave_m * WTM, d.M, n0 + wave_n * WTN, d.N);
             return;
         }
-        // LoRA epilogue operands: the up-projection rows of a 32-column block as A fragments (rows in the accumulator's channel
-        // order: MFMA row r <-> channel 16 ((r >> 2) & 1) + 4 (r >> 3) + (r & 3) of the block, the permutation the weight tile's
-        // LDS rows carry), 4 K steps of 16 over the rank, straight from global memory (64 B per lane and block; the table is
-        // L2-resident).  Block j + 1 is fetched while block j is worked on (two register sets: the 160x320 tile has no room for five).
+        // LoRA epilogue operands.  U (the up-projection rows of this workgroup tile's BN columns, 128 B each) is staged ONCE per tile
+        // in LDS behind the slabs — round 3 fetched every 32-column block's fragments from global memory again for every 32-row slab
+        // of every wave: 4 bytes of L2 traffic per output element, which is what the epilogue's +0.6-0.9 us per million outputs were
+        // (profiles/r04_student_gemm_shapes.csv).  16-byte chunk c of row r sits at chunk c ^ f(r), f(r) = ((r >> 1) & 3) | 4 ((r >> 4) & 1):
+        // the 16 lanes of a ds_read_b128 pass (rows in the accumulator's channel order, below) fall into 16 different bank groups.
+        // The rank-64 rows t of a 32-row slab (B fragments: column = token) come straight from global memory, slab i + 1's while
+        // slab i is worked on; slab 0's are requested BEFORE the staging so that the two latencies overlap.
+        char* const lra_lds = smem + NW * 32 * P;
+        auto lra_swz = [](int r) { return ((r >> 1) & 3) | (((r >> 4) & 1) << 2); };
+        auto lra_load_t = [&](int i, bf16x8_t (*dst)[4], int& leaf0) {
+            const int gm = m0 + wave_m * WTM + i * 32 + frow;
+            leaf0 = (n0 + wave_n * WTN) / d.lora_n_leaf;
+            const int last = min(n0 + wave_n * WTN + WTN - 1, d.N - 1) / d.lora_n_leaf;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bf16_t* tp = (const bf16_t*)d.lora_t + (long long)min(gm, d.M - 1) * d.ld_lora_t + (leaf0 + q) * 64 + hi * 8;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    uint4 u = make_uint4(0, 0, 0, 0);
+                    if (gm < d.M && leaf0 + q <= last) u = *(const uint4*)(tp + ks * 16);
+                    dst[q][ks] = *(bf16x8_t*)&u;
+                }
+            }
+        };
+        // (wave tiles whose accumulators fill half the register file have no room for a second set of t rows: they fetch per slab)
+        constexpr bool LRA_T2 = F_LRA && TM > 1 && TM * TN * 16 < 128 && WPE < 4;
+        bf16x8_t lra_tb[LRA_T2 ? 2 : 1][2][4];
+        int lra_leaf0 = 0;
+        if constexpr (F_LRA) {
+            lra_load_t(0, lra_tb[0], lra_leaf0);
+            for (int idx = tid; idx < BN * 8; idx += NW * 64) {
+                const int r = idx >> 3, c = idx & 7, n = n0 + r;
+                uint4 u = make_uint4(0, 0, 0, 0);
+                if (n < d.N) u = *(const uint4*)((const bf16_t*)d.lora_u + (long long)n * d.ld_lora_u + c * 8);
+                *(uint4*)(lra_lds + r * 128 + ((c ^ lra_swz(r)) << 4)) = u;
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        // a 32-column block's U rows as A fragments (rows in the accumulator's channel order: MFMA row r <-> channel
+        // 16 ((r >> 2) & 1) + 4 (r >> 3) + (r & 3) of the block, the permutation the weight tile's LDS rows carry), 4 K steps of 16
         auto lra_load_u = [&](int j, bf16x8_t* dst) {
             const int cperm = (((frow >> 2) & 1) << 4) | ((frow >> 3) << 2) | (frow & 3);
-            const int n = n0 + wave_n * WTN + j * 32 + cperm;
-            const bf16_t* up = (const bf16_t*)d.lora_u + (long long)min(n, d.N - 1) * d.ld_lora_u + hi * 8;
+            const int r = wave_n * WTN + j * 32 + cperm;
+            const char* up = lra_lds + r * 128;
+            const int sw = lra_swz(r);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                uint4 u = *(const uint4*)(up + ks * 16);
-                if (n >= d.N) u = make_uint4(0, 0, 0, 0);
-                dst[ks] = *(bf16x8_t*)&u;
-            }
+            for (int ks = 0; ks < 4; ++ks) dst[ks] = *(const bf16x8_t*)(up + (((2 * ks + hi) ^ sw) << 4));
         };
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int gm = m0 + wave_m * WTM + i * 32 + frow;
             asm volatile("" ::: "memory");
             float rs1[F_ROW ? TN : 1], rs2[F_ROW ? TN : 1];
-            // this slab's rank-64 rows t (B fragments: column = token); a wave tile spans at most two leaves of a group
-            bf16x8_t lra_t[F_LRA ? 2 : 1][4];
-            int lra_leaf0 = 0;
-            if constexpr (F_LRA) {
-                lra_leaf0 = (n0 + wave_n * WTN) / d.lora_n_leaf;
-                const int last = min(n0 + wave_n * WTN + WTN - 1, d.N - 1) / d.lora_n_leaf;
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const bf16_t* tp = (const bf16_t*)d.lora_t + (long long)min(gm, d.M - 1) * d.ld_lora_t + (lra_leaf0 + q) * 64 + hi * 8;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        uint4 u = make_uint4(0, 0, 0, 0);
-                        if (gm < d.M && lra_leaf0 + q <= last) u = *(const uint4*)(tp + ks * 16);
-                        lra_t[q][ks] = *(bf16x8_t*)&u;
-                    }
-                }
+            // this slab's rank-64 rows t; a wave tile spans at most two leaves of a group (host-checked)
+            bf16x8_t (*lra_t)[4] = lra_tb[LRA_T2 ? (i & 1) : 0];
+            if constexpr (LRA_T2) {
+                int unused;
+                if (i + 1 < TM) lra_load_t(i + 1, lra_tb[(i + 1) & 1], unused);
+            } else if constexpr (F_LRA && TM > 1) {
+                int unused;
+                if (i > 0) lra_load_t(i, lra_tb[0], unused);
             }
             bf16x8_t lra_u[2][4];
             if constexpr (F_LRA) lra_load_u(0, lra_u[0]);
@@ -930,15 +954,12 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
                         lp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lra_u[j & 1][ks], q ? lra_t[1][ks] : lra_t[0][ks], lp, 0, 0, 0);
                     if (gm < d.M && ch_lane + j * 32 < d.N) {
                         if (d.drop_thr) {
-                            const uint64_t seed = *(const uint64_t*)d.drop_seed;
-                            const uint64_t pair0 = ((uint64_t)gm * (uint64_t)d.drop_ncols + (uint64_t)(d.drop_col0 + ch_lane + j * 32)) >> 1;
+                            const uint64_t key = dropout_key(*(const uint64_t*)d.drop_seed, d.drop_site);
+                            const uint64_t quad0 = ((uint64_t)gm * (uint64_t)d.drop_ncols + (uint64_t)(d.drop_col0 + ch_lane + j * 32)) >> 2;
+                            const uint32_t keep = dropout_keep_mask<4>(key, quad0, d.drop_thr >> 16);
                             const float sk = d.lora_scale * d.drop_inv_keep;
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) {
-                                const uint64_t b = dropout_bits(seed, d.drop_site, pair0 + k);
-                                if ((uint32_t)b >= d.drop_thr) v[2 * k] = fmaf(sk, lp[2 * k], v[2 * k]);
-                                if ((uint32_t)(b >> 32) >= d.drop_thr) v[2 * k + 1] = fmaf(sk, lp[2 * k + 1], v[2 * k + 1]);
-                            }
+                            for (int e = 0; e < 16; ++e) v[e] = ((keep >> e) & 1u) ? fmaf(sk, lp[e], v[e]) : v[e];
                         } else {
 #pragma unroll
                             for (int e = 0; e < 16; ++e) v[e] = fmaf(d.lora_scale, lp[e], v[e]);
@@ -947,14 +968,11 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
                 }
                 if constexpr (F_DRP) {   // keep(row, col) = the counter-based mask of t2v_dropout_bf16, then the residual tile
                     if (gm < d.M && ch_lane + j * 32 < d.N) {
-                        const uint64_t seed = *(const uint64_t*)d.drop_seed;
-                        const uint64_t pair0 = ((uint64_t)gm * (uint64_t)d.drop_ncols + (uint64_t)(d.drop_col0 + ch_lane + j * 32)) >> 1;
+                        const uint64_t key = dropout_key(*(const uint64_t*)d.drop_seed, d.drop_site);
+                        const uint64_t quad0 = ((uint64_t)gm * (uint64_t)d.drop_ncols + (uint64_t)(d.drop_col0 + ch_lane + j * 32)) >> 2;
+                        const uint32_t keep = dropout_keep_mask<4>(key, quad0, d.drop_thr >> 16);
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const uint64_t b = dropout_bits(seed, d.drop_site, pair0 + k);
-                            v[2 * k] = ((uint32_t)b >= d.drop_thr) ? v[2 * k] * d.drop_inv_keep : 0.f;
-                            v[2 * k + 1] = ((uint32_t)(b >> 32) >= d.drop_thr) ? v[2 * k + 1] * d.drop_inv_keep : 0.f;
-                        }
+                        for (int e = 0; e < 16; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * d.drop_inv_keep : 0.f;
                         float rf[16];
                         unpack8(rdrp[j][0], rf);
                         unpack8(rdrp[j][1], rf + 8);
@@ -1164,7 +1182,10 @@ int launch_impl(GemmParams& p, hipStream_t s) {
     // LNOUT: the row-statistics exchange area ([2][waves][32] floats) sits behind the epilogue slabs
     constexpr int slab_end = WM * WN * 32 * ((BN / WN) * 2 + 16);
     constexpr int base_smem = gemm_smem_bytes<BM, BN, WM, WN, STAGES, BK, FAST>();
-    constexpr int smem = LNOUT ? (base_smem > slab_end + 2 * WM * WN * 32 * 4 ? base_smem : slab_end + 2 * WM * WN * 32 * 4) : base_smem;
+    constexpr int lra_end = slab_end + BN * 128;   // FUSE & 16: the workgroup tile's LoRA up-projection rows behind the slabs
+    constexpr int smem = LNOUT ? (base_smem > slab_end + 2 * WM * WN * 32 * 4 ? base_smem : slab_end + 2 * WM * WN * 32 * 4)
+                               : ((FUSE & 16) && lra_end > base_smem ? lra_end : base_smem);
+    static_assert(smem <= 160 * 1024, "t2v_gemm: LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, WM, WN, STAGES, BK, WPE, FAST, RS, LNOUT, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1355,9 +1376,9 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
                 "t2v_gemm: batch strides must be multiples of 8");
     T2V_REQUIRE(d.batch <= 65535, T2V_ESHAPE, "t2v_gemm: batch too large");
     if (d.drop_thr)
-        T2V_REQUIRE(d.drop_seed && d.act == T2V_ACT_NONE && d.drop_ncols > 0 && d.drop_ncols % 2 == 0 && d.drop_col0 % 2 == 0 &&
+        T2V_REQUIRE(d.drop_seed && d.act == T2V_ACT_NONE && d.drop_ncols > 0 && d.drop_ncols % 4 == 0 && d.drop_col0 % 4 == 0 &&
                         d.drop_col0 >= 0 && d.drop_col0 + d.N <= d.drop_ncols && d.batch == 1,
-                    T2V_EINVAL, "t2v_gemm: dropout epilogue (seed pointer, even column geometry, no activation, no batch)");
+                    T2V_EINVAL, "t2v_gemm: dropout epilogue (seed pointer, column geometry in multiples of 4, no activation, no batch)");
     p.nsrc = d.a1 ? 2 : 1;
     p.gh = d.h_in; p.gw = d.w_in;
     p.kh = 3; p.kw = 3; p.stride = 1; p.pad_y = 1; p.pad_x = 1; p.ups = 0;
@@ -1444,7 +1465,7 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
             T2V_REQUIRE(d.lora_u && d.lora_n_leaf > 0 && d.lora_n_leaf % 32 == 0 && d.N % d.lora_n_leaf == 0 && d.ld_lora_t % 8 == 0 &&
                             d.ld_lora_u % 8 == 0 && d.ld_lora_u >= 64 && d.ld_lora_t >= 64 * (d.N / d.lora_n_leaf) &&
                             (uintptr_t)d.lora_t % 16 == 0 && (uintptr_t)d.lora_u % 16 == 0 && d.act == T2V_ACT_NONE &&
-                            (!d.drop_thr || (d.drop_seed && d.drop_ncols % 2 == 0 && d.drop_col0 % 2 == 0)),
+                            (!d.drop_thr || (d.drop_seed && d.drop_ncols % 4 == 0 && d.drop_col0 % 4 == 0)),
                         T2V_ESHAPE, "t2v_gemm: lora_t: rank-64 rows [M][64 leaves], lora_u [N][64], N a multiple of lora_n_leaf (% 32), no activation");
         T2V_REQUIRE(!d.ln_out && d.batch == 1, T2V_EINVAL, "t2v_gemm: fused statistics: no batch, no LayerNorm second output");
         if (fuse == 1)
@@ -1462,11 +1483,13 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
         fuse_cfg = t2v_gemm_fuse_tile(cfg, d.act, fuse);
         // the fused epilogue rides on the fast kernels of one K split; GEGLU needs a 64-wide wave tile (its value / gate pairs)
         fuse_ok = fuse_cfg != 0 && p.splits == 1 && gemm_is_fast(p, fuse == 8 || (fuse & 16) != 0) && !(d.act == T2V_ACT_GEGLU && kCfg[fuse_cfg].wtn < 64);
-        // LoRA epilogue: a wave tile loads the rank-64 rows of at most TWO leaves (lra_t[2]); a group whose leaves are narrower than
-        // the tile's per-wave width could put a third leaf under one wave tile, which would then be multiplied with leaf 1's rows
+        // LoRA epilogue: a wave tile loads the rank-64 rows of at most TWO leaves (lra_t[2]); a group whose leaves are narrow could put
+        // a third leaf under one wave tile, which would then be multiplied with leaf 1's rows.  Wave tiles start at multiples of
+        // their width, so the check is exact: walk them.
         if ((fuse & 16) && fuse_cfg != 0 && d.N != d.lora_n_leaf) {
             const int wtn = fuse_cfg == 23 ? 160 : kCfg[fuse_cfg].wtn;   // (the 160x320 tile: 32 in the table keeps GEGLU off it; its wave tile is 160 wide)
-            if (wtn > d.lora_n_leaf) fuse_ok = false;
+            for (int s = 0; s < d.N && fuse_ok; s += wtn)
+                if ((s + wtn - 1 < d.N ? s + wtn - 1 : d.N - 1) / d.lora_n_leaf - s / d.lora_n_leaf > 1) fuse_ok = false;
         }
         // the dropout epilogue moves to the fast kernels only where that keeps the launch on (a twin of) the tile the table chose
         // for it: measured per shape on MI355X (profiles/r03_student_gemm_fast_dropout.csv), 160x320 (id 28 -> 23) wins 20-35 %,
@@ -1512,6 +1535,20 @@ extern "C" int t2v_gemm_fuse_supported(const t2v_gemm_desc* dd) {
         if (c2) return 1;
     }
     return ((fuse & ~8) && ok) ? 1 : 0;   // (bit 8 is the library's own choice for dropout launches, not a request)
+}
+
+// What the library would launch for this descriptor: tile id (the fused twin's where the fused epilogue is taken) and K splits.
+// The gradient engine asks before it attaches a LoRA epilogue (which rides on ONE split): where the plain launch would split K
+// — the 5x8 / 10x16 levels' long-K convs — the epilogue form loses more in the main loop than it saves after it.
+extern "C" int t2v_gemm_plan(const t2v_gemm_desc* dd, int* tile_cfg, int* splits) {
+    GemmParams p;
+    int cfg = 0, fuse = 0, fuse_cfg = 0;
+    bool ok = false;
+    const int rc = gemm_prepare(dd, p, cfg, fuse, fuse_cfg, ok);
+    if (rc != T2V_OK) return rc;
+    if (tile_cfg) *tile_cfg = (fuse && ok) ? fuse_cfg : cfg;
+    if (splits) *splits = p.splits;
+    return T2V_OK;
 }
 
 extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {

@@ -42,10 +42,10 @@ extern "C" int t2v_gather_f32(const float* src, const int* idx, float alpha, voi
 // ---------------------------------------------------------------------------------------------------------------------
 // Dropout with a counter-based mask: keep(row, col) is a pure function of (seed, site, row * ncols + col), so the backward
 // regenerates the forward's mask instead of storing it (nn.Dropout in LoraInjected*.forward, utils/lora.py:45-50,124-129,
-// and in TemporalConvBlock conv2..4, openaimodel3d.py:280-297).  One splitmix64 finaliser per PAIR of adjacent columns
-// (low / high 32 bits).  out = keep ? x / (1 - p) : 0   (+ resid).  `seed` lives in device memory: a replayed launch list
+// and in TemporalConvBlock conv2..4, openaimodel3d.py:280-297).  One splitmix64 finaliser per QUAD of adjacent elements
+// (16 bits each).  out = keep ? x / (1 - p) : 0   (+ resid).  `seed` lives in device memory: a replayed launch list
 // sees the step's seed without being re-recorded.
-// (splitmix64 / dropout_bits: common.h)
+// (splitmix64 / dropout_quad / dropout_keep_mask: common.h)
 
 template <bool VEC8>
 __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ resid, int ldr,
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long r = i / per_row;
         const int c = (int)(i - r * per_row) * W;
-        const uint64_t pair0 = (uint64_t)(r * ncols + c) >> 1;
+        const uint64_t i0 = (uint64_t)(r * ncols + c);   // flat element index: even (W = 2) / a multiple of 8 (ncols % 8 == 0)
         float v[W], rs[W];
         if constexpr (VEC8) {
             unpack8(*(const uint4*)(x + r * ldx + c), v);
@@ -68,11 +68,16 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
             v[0] = __uint_as_float(u << 16); v[1] = __uint_as_float(u & 0xffff0000u);
             if (resid) { const uint32_t q = *(const uint32_t*)(resid + r * ldr + c); rs[0] = __uint_as_float(q << 16); rs[1] = __uint_as_float(q & 0xffff0000u); }
         }
+        const uint64_t key = dropout_key(seed, site);
+        if constexpr (VEC8) {
+            const uint32_t keep = dropout_keep_mask<2>(key, i0 >> 2, thr);
 #pragma unroll
-        for (int k = 0; k < W / 2; ++k) {
-            const uint64_t b = dropout_bits(seed, site, pair0 + k);
-            v[2 * k] = ((uint32_t)b >= thr) ? v[2 * k] * inv_keep : 0.f;
-            v[2 * k + 1] = ((uint32_t)(b >> 32) >= thr) ? v[2 * k + 1] * inv_keep : 0.f;
+            for (int k = 0; k < 8; ++k) v[k] = ((keep >> k) & 1u) ? v[k] * inv_keep : 0.f;
+        } else {
+            const uint64_t w = dropout_quad(key, i0 >> 2);
+            const int e0 = (int)(i0 & 2);
+            v[0] = dropout_keep16(w, e0, thr) ? v[0] * inv_keep : 0.f;
+            v[1] = dropout_keep16(w, e0 + 1, thr) ? v[1] * inv_keep : 0.f;
         }
         if (resid) {
 #pragma unroll
@@ -92,7 +97,7 @@ extern "C" int t2v_dropout_bf16(const void* x, int ldx, const void* resid, int l
     T2V_REQUIRE((uintptr_t)x % 4 == 0 && (uintptr_t)out % 4 == 0 && (!resid || (uintptr_t)resid % 4 == 0), T2V_ESHAPE,
                 "t2v_dropout_bf16: 4-byte aligned rows");
     const double t = (double)p * 4294967296.0;
-    const uint32_t thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    const uint32_t thr = (t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t) >> 16;   // 16 bits per element
     const float inv_keep = 1.0f / (1.0f - p);
     const bool vec8 = ncols % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && (!resid || ldr % 8 == 0) && (uintptr_t)x % 16 == 0 &&
                       (uintptr_t)out % 16 == 0 && (!resid || (uintptr_t)resid % 16 == 0);

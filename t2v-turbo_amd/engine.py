@@ -435,6 +435,12 @@ class _Engine:
         out = self.buf(M, N, out_dtype)
         kw = dict(M=M, N=N, a1=x.p1, mode=mode, n_img=x.n_img, h=x.h, wd=x.w, frames=frames, bias=bias, rowvec=rowvec,
                   rowvec_div=rowvec_div, residual=residual)
+        zf = None
+        if extra is not None and not self._lora_epilogue_pays(x, w, out, kw, own_w):
+            # (the gradient engine's LoRA branch as up-projection launches whose sum z is this launch's residual: the base leaf keeps
+            # its split-K plan / goes to the halo kernel)
+            zf, kw["residual"] = fallback()
+            extra = None
         # 3x3 convs whose width fills whole 80-channel tiles go to the halo-slab kernel (csrc/conv_halo.hip: the activation tile and
         # its halo stay in LDS across the nine taps; 14-32 % faster than the tuned t2v_gemm tiles at the UNet's three upper levels,
         # profiles/r04_conv_halo_v3_static_schedule.csv) when the launch has the module's own weights and a plain epilogue
@@ -454,8 +460,9 @@ class _Engine:
                     self.pool.link(out, cs)
                     kw["colstat"] = cs
                 self.ops.conv_halo(x.parts[0], ws, out, **kw)
+                if zf is not None:
+                    self.pool.put(zf)
                 return Act(out, x.n_img, ho, wo, cs=[cs])
-        zf = None
         if extra is not None:   # (the gradient engine: the LoRA branch in this launch's epilogue; ``fallback`` builds it as a residual)
             if self.ops.gemm_fuse_supported(x.parts[0], w, out, **kw, **extra):
                 kw.update(extra)
@@ -468,6 +475,23 @@ class _Engine:
         if zf is not None:
             self.pool.put(zf)
         return Act(out, x.n_img, ho, wo, cs=[cs])
+
+    # where a LoRA conv leaf does better WITHOUT the epilogue form (profiles/r04_student_gemm_shapes.csv): (a) the plain launch would
+    # split K (2560 x 1280 x 23040: 453 us in one split vs 162 us in four), (b) a 3x3 conv over >= ``lora_halo_min_c`` input channels
+    # that the halo kernel takes (40960 x 320 x 5760: 157 us fused vs 112 + 20 us as halo conv + up-projection)
+    lora_split_aware = os.environ.get("T2V_LORA_SPLIT_AWARE", "1") == "1"
+    lora_halo_min_c = int(os.environ.get("T2V_LORA_HALO_MIN_C", "640"))
+
+    def _lora_epilogue_pays(self, x, w, out, kw, own_w):
+        ops = self.ops
+        if self.lora_split_aware and hasattr(ops, "gemm_plan") and ops.gemm_plan(x.parts[0], w, out, **kw)[1] > 1:
+            return False
+        mode, N = kw["mode"], kw["N"]
+        cin = sum(p.shape[1] for p in x.parts)
+        if (self.lora_halo_min_c and cin >= self.lora_halo_min_c and self.conv_halo and own_w and mode == nt.GEMM_CONV3X3 and N % 80 == 0
+                and hasattr(ops, "conv_halo_supported") and out.dtype == self.adt and w.dtype == self.adt):
+            return False
+        return True
 
     # ---- plan management --------------------------------------------------------------------------------
     def _check_weights(self, module, skip=()):

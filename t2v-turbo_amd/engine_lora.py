@@ -355,7 +355,7 @@ class LoraTrainMixin:
         # train mode: dropout(up(down(x))) * scale (utils/lora.py:45-50), then the leaf's own residual.  The mask is the
         # up-projection's own epilogue (t2v_gemm dropout fields) instead of a separate read-modify-write pass over z
         # (442 launches and 23 GB per student forward); ``fuse_dropout = False`` keeps the two-kernel form (tests compare both).
-        fuse = bool(grp.drop) and self.fuse_dropout and grp.ntot % 2 == 0 and all(n % 2 == 0 for n in grp.N)
+        fuse = bool(grp.drop) and self.fuse_dropout and grp.ntot % 4 == 0 and all(n % 4 == 0 for n in grp.N)
         c0 = 0
         for i in range(grp.n):
             res = None if (residual is None or (grp.drop and not fuse)) else residual[:, c0:c0 + grp.N[i]]

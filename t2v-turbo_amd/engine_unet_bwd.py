@@ -413,6 +413,9 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             # the LoRA branch: inside this launch's epilogue where the launch can carry it, else as up-projection launches whose
             # sum z becomes this launch's residual operand
             extra = self.lora_epilogue_args(grp) if N == grp.ntot else None
+            if (extra is not None and self.lora_split_aware and hasattr(self.ops, "gemm_plan")
+                    and self.ops.gemm_plan(x.parts[0], w, out, **kw)[1] > 1):
+                extra = None   # (the plain launch splits K: the epilogue form, one split, would lose more than it saves)
             if extra is not None and self.ops.gemm_fuse_supported(x.parts[0], w, out, **kw, **extra):
                 kw.update(extra)
             else:

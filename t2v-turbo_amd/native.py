@@ -93,6 +93,7 @@ _SIGS = {
     "t2v_last_error": (C.c_char_p, []),
     "t2v_gemm": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "t2v_gemm_fuse_supported": (C.c_int, [C.POINTER(GemmDesc)]),
+    "t2v_gemm_plan": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "t2v_conv_halo": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "t2v_conv_halo_supported": (C.c_int, [C.POINTER(GemmDesc)]),
     "t2v_conv_halo_force_config": (C.c_int, [C.c_int]),
@@ -433,6 +434,12 @@ class HipOps:
         if rc < 0:
             _check(rc, "t2v_gemm_fuse_supported")
         return rc == 1
+
+    def gemm_plan(self, a0, w, out, **kw):
+        """(tile id, K splits) ``gemm`` would use for these arguments; launches nothing."""
+        cfg, splits = C.c_int(0), C.c_int(0)
+        _check(self.lib.t2v_gemm_plan(C.byref(self._gemm_desc(a0, w, out, **kw)), C.byref(cfg), C.byref(splits)), "t2v_gemm_plan")
+        return cfg.value, splits.value
 
     def _gemm_desc(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
                    rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,

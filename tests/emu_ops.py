@@ -220,6 +220,9 @@ class EmuOps:
         return (mode == nt.GEMM_LINEAR and a1 is None and bias is not None and residual is None and rowvec is None and cin % 64 == 0
                 and cin <= 1280 and act != nt.ACT_SILU and lnf[0].stride(0) >= cin // 16 and lnf[0].stride(0) % 4 == 0)
 
+    def gemm_plan(self, a0, w, out, **_):
+        return 0, 1   # (the emulation has no tiles and never splits K: the fused forms are taken wherever the arguments allow)
+
     def ffn_fused_supported(self, C):
         return C % 32 == 0   # (the device kernel: C = 320 and 64; the emulation takes any width the layout allows)
 
@@ -591,23 +594,24 @@ class EmuOps:
 
     @staticmethod
     def dropout_keep(seed, site, rows, ncols, p):
-        """The device kernel's mask, bit for bit (csrc/train.hip): splitmix64 per pair of adjacent columns."""
+        """The device kernel's mask, bit for bit (csrc/common.h): one splitmix64 word per quad of adjacent elements of the row-major
+        [rows][ncols] matrix, 16 bits per element against (p * 2^32) >> 16."""
         import numpy as np
         assert ncols % 2 == 0
         m64 = np.uint64
+        n = rows * ncols
         with np.errstate(over="ignore"):
-            pair = np.arange(rows * ncols // 2, dtype=np.uint64)
-            z = m64(seed & 0xFFFFFFFFFFFFFFFF) + m64(site) * m64(0x9E3779B97F4A7C15) + pair * m64(0xD1B54A32D192ED03)
+            quad = np.arange((n + 3) // 4, dtype=np.uint64)
+            z = m64(seed & 0xFFFFFFFFFFFFFFFF) + m64(site) * m64(0x9E3779B97F4A7C15) + quad * m64(0xD1B54A32D192ED03)
             z ^= z >> m64(30)
             z *= m64(0xBF58476D1CE4E5B9)
             z ^= z >> m64(27)
             z *= m64(0x94D049BB133111EB)
             z ^= z >> m64(31)
         t = p * 4294967296.0
-        thr = np.uint64(0xFFFFFFFF if t >= 4294967295.0 else int(t))
-        lo, hi = z & m64(0xFFFFFFFF), z >> m64(32)
-        keep = np.stack([lo >= thr, hi >= thr], axis=1).reshape(rows, ncols)
-        return torch.from_numpy(keep)
+        thr = np.uint64((0xFFFFFFFF if t >= 4294967295.0 else int(t)) >> 16)
+        bits = np.stack([(z >> m64(16 * e)) & m64(0xFFFF) for e in range(4)], axis=1).reshape(-1)[:n]
+        return torch.from_numpy((bits >= thr).reshape(rows, ncols))
 
     def dropout(self, x, resid, out, ncols, p, seed, site):
         self._log("dropout")

@@ -53,8 +53,22 @@ inline uint64_t splitmix64(uint64_t z) {
     z ^= z >> 31;
     return z;
 }
-inline uint64_t dropout_bits(uint64_t seed, uint32_t site, uint64_t pair) {
-    return splitmix64(seed + (uint64_t)site * 0x9E3779B97F4A7C15ull + pair * 0xD1B54A32D192ED03ull);
+constexpr uint64_t kDropQuadMul = 0xD1B54A32D192ED03ull;
+inline uint64_t dropout_key(uint64_t seed, uint32_t site) { return seed + (uint64_t)site * 0x9E3779B97F4A7C15ull; }
+inline uint64_t dropout_quad(uint64_t key, uint64_t quad) { return splitmix64(key + quad * kDropQuadMul); }
+inline bool dropout_keep16(uint64_t word, int e, uint32_t thr16) {
+    const uint32_t half = (e & 2) ? (uint32_t)(word >> 32) : (uint32_t)word;
+    return ((e & 1) ? (half >> 16) : (half & 0xffffu)) >= thr16;
+}
+template <int NQ>
+inline uint32_t dropout_keep_mask(uint64_t key, uint64_t quad0, uint32_t thr16) {
+    const uint64_t z0 = key + quad0 * kDropQuadMul;
+    uint32_t m = 0;
+    for (int k = 0; k < NQ; ++k) {
+        const uint64_t w = splitmix64(z0 + (uint64_t)k * kDropQuadMul);
+        for (int e = 0; e < 4; ++e) m |= dropout_keep16(w, e, thr16) ? (1u << (4 * k + e)) : 0u;
+    }
+    return m;
 }
 
 #ifdef HOSTSIM_FULL  // the whole library: csrc/elementwise.hip brings its own definitions

@@ -217,6 +217,19 @@ def test_lora_branch_in_the_base_leaf_epilogue(sim, cfg):
     assert rel_l2(o_s.float()[~keep], o_plain[~keep]) < BF16_TOL      # dropped positions: the base leaf alone
 
 
+def test_lora_epilogue_refuses_a_wave_tile_over_three_leaves(sim):
+    """The fused epilogue holds the rank-64 rows of at most two leaves per wave tile: three 32-wide leaves under the 160-wide wave
+    tile of id 23 are refused (the engine then runs the three-launch form), the same group on a 32-wide wave tile is taken."""
+    M, K, C = 64, 128, 32
+    N = 3 * C
+    x, w = _bf(_rt(M, K, seed=1)), _bf(_rt(N, K, seed=2))
+    t, u = _bf(_rt(M, 3 * 64, seed=3)), _bf(_rt(N, 64, seed=4))
+    out = torch.zeros(M, N, dtype=torch.bfloat16)
+    assert not sim.gemm_fuse_supported(x, w, out, M=M, N=N, lora=(t, u, C, 1.0), tile_cfg=23, split_k=1)
+    narrow = [c for c in FUSED_TILES if c != 23 and sim.gemm_fuse_supported(x, w, out, M=M, N=N, lora=(t, u, C, 1.0), tile_cfg=c, split_k=1)]
+    assert narrow, "no fused tile takes 32-wide leaves"
+
+
 def test_unsupported_requests_are_refused_not_ignored(sim):
     M, N, K = 64, 64, 64
     a, w = _bf(_rt(M, K)), _bf(_rt(N, K))

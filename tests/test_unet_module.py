@@ -91,7 +91,9 @@ def test_auto_route_decisions():
     assert m._auto_route(x.clone().requires_grad_(True), ctx, tc, None)[0] == "composite"   # input gradient without LoRA
     m.train()
     with torch.no_grad():
-        assert m._auto_route(x, ctx, tc, None)[0] == "composite"      # train-mode dropout (temporal convs), no LoRA: e.g. the v1 teacher
+        # train mode, no LoRA, the only live dropouts those of the temporal conv blocks: the v1 teacher, which the reference never
+        # puts in eval mode (train_t2v_turbo_v1_lora.py:621-626) — the inference engine runs it with counter-based masks (round 4)
+        assert m._auto_route(x, ctx, tc, None) == ("infer", None)
     m.eval()
     lora.inject_trainable_lora_extended(m, r=4)
     m.train()

@@ -62,7 +62,7 @@ def main():
                 continue
             d = args[0]._obj
             K = (d.c0 + d.c1) * {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(d.mode, 9)
-            key = (which, d.mode, d.M, d.N, K, d.batch, int(bool(d.residual)), int(bool(d.drop_seed)), int(bool(d.rowvec)), d.act, d.split_k)
+            key = (which, d.mode, d.M, d.N, K, d.batch, int(bool(d.residual)), int(bool(d.drop_seed)), int(bool(d.rowvec)), d.act, d.split_k, int(bool(getattr(d, "lora_t", None))))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             fn(*args, stream)
             e0.record()
@@ -74,14 +74,14 @@ def main():
             r = rows.setdefault(key, [0, 0.0])
             r[0] += 1
             r[1] += us
-    print("list,mode,M,N,K,batch,res,drop,rowvec,act,split,count,us,total_ms,tflops,us_hbm_floor")
+    print("list,mode,M,N,K,batch,res,drop,rowvec,act,split,lora_epi,count,us,total_ms,tflops,us_hbm_floor")
     out = []
-    for (which, mode, M, N, K, batch, res, drop, rv, act, split), (cnt, us_sum) in rows.items():
+    for (which, mode, M, N, K, batch, res, drop, rv, act, split, lra), (cnt, us_sum) in rows.items():
         us = us_sum / cnt
         flop = 2.0 * M * N * K * batch
         n_out = N // 2 if act == nt.ACT_GEGLU else N
         byts = 2.0 * batch * (M * K / ({nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(mode, 9)) + N * K + M * n_out * (1 + res))
-        out.append((us_sum, f"{which},{mode},{M},{N},{K},{batch},{res},{drop},{rv},{act},{split},{cnt},{us:.2f},{us_sum / 1e3:.3f},"
+        out.append((us_sum, f"{which},{mode},{M},{N},{K},{batch},{res},{drop},{rv},{act},{split},{lra},{cnt},{us:.2f},{us_sum / 1e3:.3f},"
                             f"{flop / us / 1e6:.1f},{byts / 8e12 * 1e6:.2f}"))
     for _, line in sorted(out, key=lambda t: -t[0]):
         print(line)
