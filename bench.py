@@ -131,6 +131,13 @@ def kernel_breakdown(engine, plan, rec=None):
             # algorithmic HBM bytes (bf16): statistics read x once, apply reads x and writes y; t2v_group_norm is both
             rows, ch = args[6] * args[7], args[1] + args[4]
             a["gbyte"] += {"t2v_gn_stats": 1, "t2v_gn_apply": 2, "t2v_group_norm": 3}[name] * 2.0 * rows * ch / 1e9
+        elif name == "t2v_group_norm_cs":
+            # the apply pass reads x and writes y (bf16); the statistics come from the producers' column statistics (fp32 (sum, sumsq)
+            # per 32-row slab and channel = 1/8 of the tensor's bytes) instead of a second read of x
+            rows, ch = args[8] * args[9], args[3] + args[6]
+            a["gbyte"] += (2 * 2.0 + 8.0 / 32) * rows * ch / 1e9
+        elif name == "t2v_gn_stats_cs":
+            a["gbyte"] += (8.0 / 32) * args[4] * args[5] * (args[1] + args[3]) / 1e9
         elif name == "t2v_layernorm":
             a["gbyte"] += 2 * 2.0 * args[2] * args[3] / 1e9
     report = os.environ.get("T2V_SHAPE_REPORT")

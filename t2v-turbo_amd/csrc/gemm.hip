@@ -49,7 +49,8 @@ struct GemmParams {
 // Ablation switches (tools only): a -DT2V_GEMM_ABLATE build honours GemmParams::debug bits inside the main loop
 // (1 = no DMA, 2 = no MFMA, 8 = no LDS fragment reads, 16 = no barrier, 4 = no epilogue, 32 = epilogue arithmetic and LDS
 // slabs but no global stores, 64 = accumulators start at zero: no bias / row-vector / residual loads, 128 = leave after the
-// prologue: launch + descriptor + first DMA latency only).  The product build
+// prologue: launch + descriptor + first DMA latency only; LoRA epilogue: 256 = keep everything (no mask arithmetic), 512 = no LoRA
+// MFMAs, 1024 = no t rows, 2048 = no U staging).  The product build
 // compiles them out: runtime branches inside the K loop split its basic block and cost ~20 % (exact s_waitcnt
 // counts and the MFMA / ds_read interleave both need straight-line code).
 #ifdef T2V_GEMM_ABLATE
@@ -878,7 +879,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     uint4 u = make_uint4(0, 0, 0, 0);
-                    if (gm < d.M && leaf0 + q <= last) u = *(const uint4*)(tp + ks * 16);
+                    if (gm < d.M && leaf0 + q <= last && !ABL(1024)) u = *(const uint4*)(tp + ks * 16);
                     dst[q][ks] = *(bf16x8_t*)&u;
                 }
             }
@@ -889,7 +890,7 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
         int lra_leaf0 = 0;
         if constexpr (F_LRA) {
             lra_load_t(0, lra_tb[0], lra_leaf0);
-            for (int idx = tid; idx < BN * 8; idx += NW * 64) {
+            for (int idx = tid; idx < BN * 8 && !ABL(2048); idx += NW * 64) {
                 const int r = idx >> 3, c = idx & 7, n = n0 + r;
                 uint4 u = make_uint4(0, 0, 0, 0);
                 if (n < d.N) u = *(const uint4*)((const bf16_t*)d.lora_u + (long long)n * d.ld_lora_u + c * 8);
@@ -949,14 +950,18 @@ __global__ __launch_bounds__(WM* WN * 64) __attribute__((amdgpu_waves_per_eu(WPE
                     for (int e = 0; e < 16; ++e) lp[e] = 0.f;
                     const int q = (n0 + wave_n * WTN + j * 32) / d.lora_n_leaf - lra_leaf0;
                     if (j + 1 < TN) lra_load_u(j + 1, lra_u[(j + 1) & 1]);
+                    if (!ABL(512)) {
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks)
-                        lp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lra_u[j & 1][ks], q ? lra_t[1][ks] : lra_t[0][ks], lp, 0, 0, 0);
+                        for (int ks = 0; ks < 4; ++ks)
+                            lp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lra_u[j & 1][ks], q ? lra_t[1][ks] : lra_t[0][ks], lp, 0, 0, 0);
+                    }
                     if (gm < d.M && ch_lane + j * 32 < d.N) {
                         if (d.drop_thr) {
+                            // (drawing the keep bits in the prologue instead — under the DMA flight, parked in LDS — was tried and is
+                            // slower: 32.2 vs 30.7 us at 40960 x 320 x 320; the workgroup's waves reach the first barrier later)
                             const uint64_t key = dropout_key(*(const uint64_t*)d.drop_seed, d.drop_site);
                             const uint64_t quad0 = ((uint64_t)gm * (uint64_t)d.drop_ncols + (uint64_t)(d.drop_col0 + ch_lane + j * 32)) >> 2;
-                            const uint32_t keep = dropout_keep_mask<4>(key, quad0, d.drop_thr >> 16);
+                            const uint32_t keep = ABL(256) ? 0xffffu : dropout_keep_mask<4>(key, quad0, d.drop_thr >> 16);
                             const float sk = d.lora_scale * d.drop_inv_keep;
 #pragma unroll
                             for (int e = 0; e < 16; ++e) v[e] = ((keep >> e) & 1u) ? fmaf(sk, lp[e], v[e]) : v[e];

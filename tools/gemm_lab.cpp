@@ -7,7 +7,8 @@
 //   lib name mode nimg h w frames cin n act res rv cfg split debug [iters]
 //     lib    index into T2V_LAB_LIBS (colon-separated .so paths; default: the product library)
 //     mode   T2V_GEMM_* (0 linear: M = nimg*h*w rows, 1 conv3x3, 4 tconv3)
-//     act    0 none, 1 GEGLU, 2 SiLU;  res / rv: 1 = residual operand / time-embedding row vector present
+//     act    0 none, 1 GEGLU, 2 SiLU;  res / rv: 1 = residual operand / time-embedding row vector present;
+//            res 2 / 3 = residual + the LoRA branch in the epilogue (rank 64, one leaf) without / with dropout 0.1 (no reference check)
 //     cfg    tile id (0 = library heuristic; 39 = t2v_conv_halo with its own choice, 40..42 = t2v_conv_halo tiles), split = split-K factor (0 = heuristic), debug = ablation bits (ablate builds)
 // Output: one CSV row per experiment: name, M, N, K, cfg, split, debug, us (best of 3 runs of `iters` back-to-back launches),
 // TFLOP/s, max |err| / tolerance of 256 sampled outputs against an fp64 host reference (debug == 0 only).
@@ -103,7 +104,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    Buf bx, bw, bw2, bo, bres, bbias, brv, bws;
+    Buf bx, bw, bw2, bo, bres, bbias, brv, bws, blt, blu, bseed;
     std::vector<uint16_t> hx, hw, hres, hout;
     std::vector<float> hbias, hrv;
     printf("name,lib,mode,M,N,K,act,res,rv,cfg,split,debug,us,tflops,err_over_tol\n");
@@ -166,6 +167,23 @@ int main(int argc, char** argv) {
         d.M = (int)M; d.N = n; d.w = bw.d; d.ldw = K; d.batch = 1; d.batch_inner = 1; d.alpha = 1.0f; d.bias = (const float*)bbias.d;
         if (rv) { d.rowvec = (const float*)brv.d; d.rowvec_div = h * w; d.ld_rowvec = n; }
         if (res && act != 1) { d.residual = bres.d; d.ldr = n_out; }
+        if (res >= 2) {   // LoRA epilogue operands: t [M][64], U [N][64] (values do not matter for the timing: small random)
+            std::vector<uint16_t> ht((size_t)M * 64), hu((size_t)n * 64);
+            std::mt19937 r2(7);
+            std::uniform_real_distribution<float> U2(-0.1f, 0.1f);
+            for (auto& v : ht) v = f2bf(U2(r2));
+            for (auto& v : hu) v = f2bf(U2(r2));
+            blt.need(ht.size() * 2); blu.need(hu.size() * 2); bseed.need(8);
+            CHECK(hipMemcpy(blt.d, ht.data(), ht.size() * 2, hipMemcpyHostToDevice));
+            CHECK(hipMemcpy(blu.d, hu.data(), hu.size() * 2, hipMemcpyHostToDevice));
+            const uint64_t seed = 0x1234567ull;
+            CHECK(hipMemcpy(bseed.d, &seed, 8, hipMemcpyHostToDevice));
+            d.lora_t = blt.d; d.ld_lora_t = 64; d.lora_u = blu.d; d.ld_lora_u = 64; d.lora_n_leaf = n; d.lora_scale = 1.0f;
+            if (res == 3) {
+                d.drop_seed = bseed.d; d.drop_thr = (unsigned)(0.1 * 4294967296.0); d.drop_site = 3; d.drop_inv_keep = 1.0f / 0.9f;
+                d.drop_ncols = n; d.drop_col0 = 0;
+            }
+        }
         d.act = act; d.out = bo.d; d.ldo = n_out; d.tile_cfg = cfg == 49 ? 0 : cfg; d.split_k = split; d.ws = bws.d; d.ws_bytes = (long long)bws.bytes;
         Lib& L = libs[lib];
         if (L.debug) L.debug(debug);
@@ -201,7 +219,7 @@ int main(int argc, char** argv) {
         }
         const double us = best * 1e3 / iters;
         double err_ratio = -1.0;
-        if (debug == 0) {  // sampled fp64 reference
+        if (debug == 0 && res < 2) {  // sampled fp64 reference
             hout.resize((size_t)M * n_out);
             CHECK(hipMemcpy(hout.data(), bo.d, hout.size() * 2, hipMemcpyDeviceToHost));
             std::mt19937 rng(99);
