@@ -362,9 +362,13 @@ def distill_step_leg(teacher, dev, world=1, dry=False, parity=True):
     pe = torch.randn(1, 77, cfg["context_dim"], generator=gen).to(dev)
     ue = torch.randn(1, 77, cfg["context_dim"], generator=gen).to(dev)
 
+    # T2V_BATCH_TEACHER=1: the teacher's cond / uncond forwards as ONE call on the 2-clip batch (distill_step(batch_teacher=True): same
+    # numbers per clip, weights read once); default off = two calls, the order of operations the reference has
+    batch_teacher = os.environ.get("T2V_BATCH_TEACHER", "0") == "1"
+
     def step():
         return distill_step(student, teacher, solver, sched, lat, pe, ue, optimizer=opt, grad_sync=sync,
-                            autocast_dtype=torch.bfloat16 if cuda else None, student_engine=eng)
+                            autocast_dtype=torch.bfloat16 if cuda else None, student_engine=eng, batch_teacher=batch_teacher)
 
     def fence():
         if world > 1:
@@ -444,7 +448,8 @@ def distill_step_leg(teacher, dev, world=1, dry=False, parity=True):
            "finite": bool(torch.isfinite(sync.flat).all() and torch.isfinite(opt.flat_param).all()),
            "lora_params_m": round(sync.numel / 1e6, 1), "student": "native gradient engine (flash attention backward, token-contracted "
            "weight gradients), train mode",
-           "teacher": "2 forwards on the inference engine, TRAIN mode (TemporalConvBlock dropouts live, as the reference runs its teacher)",
+           "teacher": ("1 forward of the [cond | uncond] 2-clip batch" if batch_teacher else "2 forwards") +
+                      " on the inference engine, TRAIN mode (TemporalConvBlock dropouts live, as the reference runs its teacher)",
            "ms_per_step_eval_teacher": round(ms_eval_teacher, 1),
            "grad_exchange": ("gradient arena all-reduced in %d segments from inside the backward (%.1f MB fp32, backend %s) + the "
                              "conditioning branch's tensors after it; allreduce_ms = ONE blocking all-reduce of the whole flat "
