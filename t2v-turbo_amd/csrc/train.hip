@@ -62,36 +62,54 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
     if (ty >= ty_n) return;   // (256 is not a multiple of tx_n: the last few threads have no row)
     const long long r_begin = (long long)blockIdx.x * rows_per_block;
     const long long r_end = r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows;
-    for (long long r = r_begin + ty; r < r_end; r += ty_n) {
-        const uint64_t row0 = (uint64_t)r * (uint64_t)ncols;
+    // RI rows per thread and pass: all their loads are issued before the first mask is drawn (one 16-byte load in flight per thread
+    // left the kernel latency-bound at ~3 TB/s of traffic)
+    constexpr int RI = 4;
+    for (long long rb = r_begin + ty; rb < r_end; rb += (long long)RI * ty_n) {
         for (int cc = tx; cc < per_row; cc += tx_n) {
             const int c = cc * W;
-            const uint64_t i0 = row0 + (uint64_t)c;   // flat element index: even (W = 2) / a multiple of 8 (ncols % 8 == 0)
-            float v[W], rs[W];
-            if constexpr (VEC8) {
-                unpack8(*(const uint4*)(x + r * ldx + c), v);
-                if (resid) unpack8(*(const uint4*)(resid + r * ldr + c), rs);
-            } else {
-                const uint32_t u = *(const uint32_t*)(x + r * ldx + c);
-                v[0] = __uint_as_float(u << 16); v[1] = __uint_as_float(u & 0xffff0000u);
-                if (resid) { const uint32_t q = *(const uint32_t*)(resid + r * ldr + c); rs[0] = __uint_as_float(q << 16); rs[1] = __uint_as_float(q & 0xffff0000u); }
-            }
-            if constexpr (VEC8) {
-                const uint32_t keep = dropout_keep_mask<2>(key, i0 >> 2, thr);
+            uint4 ux[RI], ur[RI];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = ((keep >> k) & 1u) ? v[k] * inv_keep : 0.f;
-            } else {
-                const uint64_t w = dropout_quad(key, i0 >> 2);
-                const int e0 = (int)(i0 & 2);
-                v[0] = dropout_keep16(w, e0, thr) ? v[0] * inv_keep : 0.f;
-                v[1] = dropout_keep16(w, e0 + 1, thr) ? v[1] * inv_keep : 0.f;
+            for (int k = 0; k < RI; ++k) {
+                const long long r = rb + (long long)k * ty_n;
+                ux[k] = ur[k] = make_uint4(0, 0, 0, 0);
+                if (r < r_end) {
+                    if constexpr (VEC8) {
+                        ux[k] = *(const uint4*)(x + r * ldx + c);
+                        if (resid) ur[k] = *(const uint4*)(resid + r * ldr + c);
+                    } else {
+                        ux[k].x = *(const uint32_t*)(x + r * ldx + c);
+                        if (resid) ur[k].x = *(const uint32_t*)(resid + r * ldr + c);
+                    }
+                }
             }
-            if (resid) {
 #pragma unroll
-                for (int k = 0; k < W; ++k) v[k] += rs[k];
+            for (int k = 0; k < RI; ++k) {
+                const long long r = rb + (long long)k * ty_n;
+                if (r >= r_end) continue;
+                const uint64_t i0 = (uint64_t)r * (uint64_t)ncols + (uint64_t)c;   // flat element index: even (W = 2) / a multiple of 8 (VEC8)
+                float v[W], rs[W];
+                if constexpr (VEC8) {
+                    unpack8(ux[k], v);
+                    unpack8(ur[k], rs);
+                    const uint32_t keep = dropout_keep_mask<2>(key, i0 >> 2, thr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ((keep >> e) & 1u) ? v[e] * inv_keep : 0.f;
+                } else {
+                    v[0] = __uint_as_float(ux[k].x << 16); v[1] = __uint_as_float(ux[k].x & 0xffff0000u);
+                    rs[0] = __uint_as_float(ur[k].x << 16); rs[1] = __uint_as_float(ur[k].x & 0xffff0000u);
+                    const uint64_t w = dropout_quad(key, i0 >> 2);
+                    const int e0 = (int)(i0 & 2);
+                    v[0] = dropout_keep16(w, e0, thr) ? v[0] * inv_keep : 0.f;
+                    v[1] = dropout_keep16(w, e0 + 1, thr) ? v[1] * inv_keep : 0.f;
+                }
+                if (resid) {
+#pragma unroll
+                    for (int e = 0; e < W; ++e) v[e] += rs[e];
+                }
+                if constexpr (VEC8) *(uint4*)(out + r * ldo + c) = pack8(v);
+                else *(uint32_t*)(out + r * ldo + c) = pack2bf(v[0], v[1]);
             }
-            if constexpr (VEC8) *(uint4*)(out + r * ldo + c) = pack8(v);
-            else *(uint32_t*)(out + r * ldo + c) = pack2bf(v[0], v[1]);
         }
     }
 }
@@ -122,7 +140,7 @@ extern "C" int t2v_dropout_bf16(const void* x, int ldx, const void* resid, int l
     const int ty_n = 256 / tx_n;
     // about 2048 blocks (8 per CU) of whole rows; at least one pass of the block's row arrangement each
     long long rpb = (rows + 2047) / 2048;
-    rpb = ((rpb + ty_n - 1) / ty_n) * ty_n;
+    rpb = ((rpb + ty_n - 1) / ty_n) * ty_n;   // (whole row groups of the block; large tensors get >= 4 of them per thread, the kernel's register blocking)
     const long long blocks = (rows + rpb - 1) / rpb;
     if (vec8)
         hipLaunchKernelGGL(dropout_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
