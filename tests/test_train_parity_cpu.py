@@ -65,3 +65,23 @@ def test_lora_grad_oracle_reproduces_the_mid_width_reference_fixture():
     d, ref = torch.from_numpy(digests(grads)), gg["digests"]
     assert float(((d[:, 0] - ref[:, 0]).abs() / ref[:, 0]).max()) < 1e-4
     assert float(((d[:, 1:] - ref[:, 1:]).abs() / ref[:, :1]).max()) < 1e-3
+
+
+def test_train_mode_masks_with_the_split_aware_lora_form_cpu():
+    """``t2v_gemm_plan`` says the plain launch of a conv leaf would split K (the device library does for the 5x8 / 10x16 levels' long-K
+    convs): the engine then keeps that leaf's LoRA branch as up-projection launches in front of a plain base leaf and the other leaves
+    in the epilogue form (engine._lora_epilogue_pays, engine_unet_bwd.linear).  Same gate as the all-epilogue run above, on a backend
+    whose plan splits every conv and every second linear launch."""
+    from t2v_turbo_amd import native as nt
+
+    class SplittingPlan(EmuOps):
+        n_asked = n_split = 0
+
+        def gemm_plan(self, a0, w, out, *, mode=nt.GEMM_LINEAR, **_):
+            type(self).n_asked += 1
+            split = mode != nt.GEMM_LINEAR or type(self).n_asked % 2 == 0
+            type(self).n_split += int(split)
+            return 0, (4 if split else 1)
+
+    run_train_mode_with_replayed_masks("cpu", SplittingPlan(strict=True), 2e-5, 1e-4, 0.99999, 1e-3)
+    assert SplittingPlan.n_split > 20 and SplittingPlan.n_asked > SplittingPlan.n_split
