@@ -290,7 +290,8 @@ def test_attn_spatial_bwd_flash(ops, n_img, seq, heads):
 
 
 @pytest.mark.parametrize("M,R,C,lda,ldb,splits", [(200, 64, 64, 64, 64, 0), (40960, 320, 64, 384, 192, 0), (130, 4, 64, 64, 64, 3),
-                                                  (10240, 576, 640, 576, 640, 0), (40960, 1, 320, 8, 320, 0)])
+                                                  (10240, 576, 640, 576, 640, 0), (40960, 1, 320, 8, 320, 0),
+                                                  (40960, 64, 320, 64, 320, 0), (10240, 192, 640, 192, 640, 0), (2560, 2560, 64, 2560, 64, 0)])
 def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
     """Token-contracted weight gradient (csrc/wgrad_tn.hip) against the emulated definition."""
     hip, emu = ops

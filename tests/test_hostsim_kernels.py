@@ -294,7 +294,8 @@ def test_transpose_pad(ops, rows, cols, batch, ld_in):
 
 
 @pytest.mark.parametrize("M,R,C,lda,ldb,splits", [(200, 64, 64, 64, 64, 0), (1000, 320, 64, 384, 192, 0), (130, 4, 64, 64, 64, 3),
-                                                  (77, 576, 200, 576, 200, 0), (640, 1, 320, 8, 320, 4), (64, 100, 36, 104, 40, 1)])
+                                                  (77, 576, 200, 576, 200, 0), (640, 1, 320, 8, 320, 4), (64, 100, 36, 104, 40, 1),
+                                                  (300, 64, 320, 64, 320, 0), (500, 192, 320, 192, 320, 0)])   # (the 64 x 256 and 128 x 128 tile shapes)
 def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
     """Token-contracted weight gradient out = alpha a^T b on token-major operands (column slices, ragged R / C / M, forced and
     automatic token splits): fp32 result against the emulated definition."""
