@@ -1,4 +1,5 @@
 #!/bin/bash
+# (variant libraries: csrc/wgrad_tn.hip of that experiment compiled with -DT2V_WGRAD_AHEAD=2 / 3 and linked with the product objects; neither the patch nor the libraries are in the tree)
 # round 4, call 17: t2v_wgrad_tn_group (64 x 64 tiles) with one / two / three token steps of loads in flight, and with more blocks
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
