@@ -12,12 +12,36 @@
 // registers BEFORE the LDS phase of step i (one workgroup then covers its own latency), the token range is split over about two
 // workgroups per CU (the partial slabs were as large as the operands when every CU got four), and the reduce kernel spreads the
 // splits over four thread groups per output (fixed assignment, fixed combine order: still deterministic).
-// The column gather is what ds_read_b64_tr_b16 exists for (not used: the LDS phase is not the bound).
+// Round 4: the column gather is done by ds_read_b64_tr_b16 (two reads per operand and MFMA instead of sixteen 2-byte reads and their
+// packing: the counters of the 2-byte version showed the LDS 40 % busy with 18 LDS and 17 VALU instructions per MFMA,
+// profiles/r04_wgrad_pmc.csv).
 #include "common.h"
 
 namespace {
 
-constexpr int WT_TOK = 64, WT_PITCH = 66;
+constexpr int WT_TOK = 64, WT_PITCH = 96;   // 96 elements = 48 words per token row: see lds_read_tr16 / wgrad_tile
+
+// ds_read_b64_tr_b16 (gfx950): every lane supplies the LDS address of FOUR contiguous 16-bit elements (8-byte aligned); within each
+// group of 16 lanes, lane l receives element (l & 3) of the values read by lanes (l >> 2), 4 + (l >> 2), 8 + (l >> 2), 12 + (l >> 2)
+// (measured on MI355X: tools/probes/tr_b16_probe.cpp).  With lane i of a group pointing at [token t0 + (i >> 2)][column c0 + 4 (i & 3)]
+// of a token-major tile, lane l gets tokens t0 .. t0 + 3 of column c0 + l: half an MFMA operand fragment.
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_read_tr16(const bf16_t* p, int lane) {
+#ifdef T2V_HOSTSIM
+    uint64_t mine;
+    memcpy(&mine, p, 8);
+    uint64_t out = 0;
+    for (int j = 0; j < 4; ++j) {
+        const uint64_t v = __shfl(mine, (lane & ~15) + 4 * j + ((lane & 15) >> 2), 64);
+        out |= ((v >> (16 * (lane & 3))) & 0xffffull) << (16 * j);
+    }
+    return make_uint2((uint32_t)out, (uint32_t)(out >> 32));
+#else
+    (void)lane;
+    const v4s_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)p);
+    return *(const uint2*)&v;
+#endif
+}
 
 // the first `n` (< 8, possibly <= 0) elements of an 8-element chunk, zeros behind them (the last column chunk of a ragged operand)
 __device__ __forceinline__ uint4 ragged_chunk(const bf16_t* p, int n) {
@@ -28,12 +52,22 @@ __device__ __forceinline__ uint4 ragged_chunk(const bf16_t* p, int n) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  The tiles of one token range share
+// operand rows (every r-tile of dU reads the same rows of t; dD's tiles share G and x), so they should meet in ONE L2: `xcd_contiguous`
+// renumbers the blocks so that consecutive ids run on the same XCD (the bijective form of csrc/gemm.hip).  Measured before it
+// (profiles/r04_wgrad_pmc.csv): 94 % of the kernel's L2 requests missed, 419 MB per launch on 135 MB of operands, i.e. the kernel ran at
+// the memory side's 6 TB/s on 3x the bytes.
+__device__ __forceinline__ int xcd_contiguous(int bid, int nblocks) {
+    const int xcd = bid & 7, pos = bid >> 3, q = nblocks >> 3, r = nblocks & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+}
+
 // one 64 x 64 output tile over the token range [m_begin, m_end): partial sums into `slab` ([R][C] fp32)
 __device__ __forceinline__ void wgrad_tile(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb, int R, int C, int r0,
                                            int c0, long long m_begin, long long m_end, float* __restrict__ slab,
                                            bf16_t (*sa)[WT_PITCH], bf16_t (*sb)[WT_PITCH]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int hi = lane >> 5, l31 = lane & 31;
+    const int hi = lane >> 5, l31 = lane & 31, i16 = lane & 15, g16 = (lane >> 4) & 1;
     const int wr = (wave >> 1) * 32, wc = (wave & 1) * 32;  // this wave's 32 x 32 sub-tile
     f32x16_t acc;
 #pragma unroll
@@ -60,23 +94,22 @@ __device__ __forceinline__ void wgrad_tile(const bf16_t* __restrict__ a, int lda
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int qd = tid + 256 * i, row = qd >> 3, ch = (qd & 7) * 8;
-            uint32_t* pa = (uint32_t*)&sa[row][ch];
-            uint32_t* pb = (uint32_t*)&sb[row][ch];
-            pa[0] = ua[i].x; pa[1] = ua[i].y; pa[2] = ua[i].z; pa[3] = ua[i].w;
-            pb[0] = ub[i].x; pb[1] = ub[i].y; pb[2] = ub[i].z; pb[3] = ub[i].w;
+            *(uint4*)&sa[row][ch] = ua[i];   // (192-byte token rows: 16-byte aligned)
+            *(uint4*)&sb[row][ch] = ub[i];
         }
         if (m0 + WT_TOK < m_end) gload(m0 + WT_TOK);  // next step's loads fly under this step's LDS phase
         __syncthreads();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {  // 16 tokens per MFMA: this lane's 8 are ks*16 + 8*hi + 0..7
+            // transpose reads: lane (i16, g16) of a half-wave points at [token t0 + (i16 >> 2)][column 16 g16 + 4 (i16 & 3)] and gets
+            // tokens t0 .. t0 + 3 (second read: + 4 .. + 7) of column 16 g16 + i16 = l31.  Token rows of 48 words: the 32 lanes of a
+            // half-wave (4 token rows x 2 column groups x 8 words) cover the 64 banks once, the other half-wave is the second pass.
             const int t0 = ks * 16 + 8 * hi;
-            uint32_t wa[4], wb[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                wa[e] = (uint32_t)sa[t0 + 2 * e][wr + l31] | ((uint32_t)sa[t0 + 2 * e + 1][wr + l31] << 16);
-                wb[e] = (uint32_t)sb[t0 + 2 * e][wc + l31] | ((uint32_t)sb[t0 + 2 * e + 1][wc + l31] << 16);
-            }
-            uint4 fa = make_uint4(wa[0], wa[1], wa[2], wa[3]), fb = make_uint4(wb[0], wb[1], wb[2], wb[3]);
+            const bf16_t* pa = &sa[t0 + (i16 >> 2)][wr + 16 * g16 + 4 * (i16 & 3)];
+            const bf16_t* pb = &sb[t0 + (i16 >> 2)][wc + 16 * g16 + 4 * (i16 & 3)];
+            const uint2 a0 = lds_read_tr16(pa, lane), a1 = lds_read_tr16(pa + 4 * WT_PITCH, lane);
+            const uint2 b0 = lds_read_tr16(pb, lane), b1 = lds_read_tr16(pb + 4 * WT_PITCH, lane);
+            uint4 fa = make_uint4(a0.x, a0.y, a1.x, a1.y), fb = make_uint4(b0.x, b0.y, b1.x, b1.y);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(bf16x8_t*)&fa, *(bf16x8_t*)&fb, acc, 0, 0, 0);
         }
     }
@@ -93,11 +126,15 @@ __device__ __forceinline__ void wgrad_tile(const bf16_t* __restrict__ a, int lda
 
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb, long long M,
                                                        int R, int C, long long tok_per_split, float* __restrict__ ws) {
-    __shared__ bf16_t sa[WT_TOK][WT_PITCH];
-    __shared__ bf16_t sb[WT_TOK][WT_PITCH];
-    const long long m_begin = (long long)blockIdx.z * tok_per_split;
+    __shared__ __attribute__((aligned(16))) bf16_t sa[WT_TOK][WT_PITCH];
+    __shared__ __attribute__((aligned(16))) bf16_t sb[WT_TOK][WT_PITCH];
+    // (linear id = x fastest: the order the dispatcher walks the grid in)
+    const int nb = gridDim.x * gridDim.y * gridDim.z;
+    const int id = xcd_contiguous((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, nb);
+    const int bx = id % gridDim.x, by = (id / gridDim.x) % gridDim.y, bz = id / (gridDim.x * gridDim.y);
+    const long long m_begin = (long long)bz * tok_per_split;
     const long long m_end = m_begin + tok_per_split < M ? m_begin + tok_per_split : M;
-    wgrad_tile(a, lda, b, ldb, R, C, blockIdx.y * 64, blockIdx.x * 64, m_begin, m_end, ws + (long long)blockIdx.z * R * C, sa, sb);
+    wgrad_tile(a, lda, b, ldb, R, C, by * 64, bx * 64, m_begin, m_end, ws + (long long)bz * R * C, sa, sb);
 }
 
 // Up to T2V_WGRAD_GROUP_MAX independent products in ONE launch (the weight gradients of one LoRA group: dU of each of its leaves
@@ -118,11 +155,12 @@ struct WgradGroup {
 };
 
 __global__ __launch_bounds__(256) void wgrad_tn_group_kernel(const WgradGroup g, float* __restrict__ ws) {
-    __shared__ bf16_t sa[WT_TOK][WT_PITCH];
-    __shared__ bf16_t sb[WT_TOK][WT_PITCH];
+    __shared__ __attribute__((aligned(16))) bf16_t sa[WT_TOK][WT_PITCH];
+    __shared__ __attribute__((aligned(16))) bf16_t sb[WT_TOK][WT_PITCH];
+    const int bid = xcd_contiguous(blockIdx.x, gridDim.x);
     int i = 0;
-    while (i + 1 < g.n && (int)blockIdx.x >= g.first_block[i + 1]) ++i;   // block-uniform
-    const int local = blockIdx.x - g.first_block[i];
+    while (i + 1 < g.n && bid >= g.first_block[i + 1]) ++i;   // block-uniform
+    const int local = bid - g.first_block[i];
     const int tiles_c = g.tiles_c[i], tiles = tiles_c * ((g.R[i] + 63) / 64);
     const int split = local / tiles, tile = local - split * tiles;
     const long long m_begin = (long long)split * g.tok_per_split[i];
