@@ -2,7 +2,7 @@
 # round 4, call 18: what bounds t2v_wgrad_tn_group? three separate --pmc passes (kernel-trace only) over tools/wgrad_pmc_target.py
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r4c18
+O=$R/gpurun_out/${RUN:-r4c18}
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
