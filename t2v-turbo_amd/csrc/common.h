@@ -54,6 +54,19 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id (x fastest), and each XCD has its own L2: blocks that share an
+// operand (the query tiles of one attention head, the output tiles of one token range) should have CONSECUTIVE ids on ONE XCD.
+// xcd_contiguous renumbers the linear ids bijectively that way; xcd_block3 applies it to a 3-D grid.
+__device__ __forceinline__ int xcd_contiguous(int bid, int nblocks) {
+    const int xcd = bid & 7, pos = bid >> 3, q = nblocks >> 3, r = nblocks & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+}
+__device__ __forceinline__ void xcd_block3(int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int id = xcd_contiguous(((int)blockIdx.z * gy + (int)blockIdx.y) * gx + (int)blockIdx.x, gx * gy * gz);
+    bx = id % gx; by = (id / gx) % gy; bz = id / (gx * gy);
+}
+
 // counter-based dropout bits: one splitmix64 finaliser per QUAD of adjacent elements of the row-major [rows][ncols] matrix (flat
 // index i = row * ncols + col: word = quad i >> 2, 16 bits per element, element i & 3 = bits [16 (i & 3), +16)), compared with
 // thr16 = (p * 2^32) >> 16.  Shared by t2v_dropout_bf16 (train.hip) and the dropout / LoRA epilogues of t2v_gemm.  (Rounds 1-3 drew

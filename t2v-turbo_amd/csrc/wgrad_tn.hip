@@ -54,13 +54,9 @@ __device__ __forceinline__ uint4 ragged_chunk(const bf16_t* p, int n) {
 
 // Workgroups are dealt to the 8 XCDs round-robin by their linear id, and each XCD has its own L2.  The tiles of one token range share
 // operand rows (every r-tile of dU reads the same rows of t; dD's tiles share G and x), so they should meet in ONE L2: `xcd_contiguous`
-// renumbers the blocks so that consecutive ids run on the same XCD (the bijective form of csrc/gemm.hip).  Measured before it
+// renumbers the blocks so that consecutive ids run on the same XCD (common.h; the bijective form of csrc/gemm.hip).  Measured before it
 // (profiles/r04_wgrad_pmc.csv): 94 % of the kernel's L2 requests missed, 419 MB per launch on 135 MB of operands, i.e. the kernel ran at
 // the memory side's 6 TB/s on 3x the bytes.
-__device__ __forceinline__ int xcd_contiguous(int bid, int nblocks) {
-    const int xcd = bid & 7, pos = bid >> 3, q = nblocks >> 3, r = nblocks & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-}
 
 // one 64 x 64 output tile over the token range [m_begin, m_end): partial sums into `slab` ([R][C] fp32)
 __device__ __forceinline__ void wgrad_tile(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb, int R, int C, int r0,

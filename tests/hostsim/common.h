@@ -46,6 +46,17 @@ inline float wave_max(float v) {
     return v;
 }
 
+// XCD-contiguous block renumbering (csrc/common.h): any bijection is correct; the simulator runs the blocks one after the other
+inline int xcd_contiguous(int bid, int nblocks) {
+    const int xcd = bid & 7, pos = bid >> 3, q = nblocks >> 3, r = nblocks & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+}
+inline void xcd_block3(int& bx, int& by, int& bz) {
+    const int gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    const int id = xcd_contiguous(((int)blockIdx.z * gy + (int)blockIdx.y) * gx + (int)blockIdx.x, gx * gy * gz);
+    bx = id % gx; by = (id / gx) % gy; bz = id / (gx * gy);
+}
+
 // counter-based dropout bits (csrc/common.h)
 inline uint64_t splitmix64(uint64_t z) {
     z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
