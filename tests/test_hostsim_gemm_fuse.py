@@ -242,3 +242,24 @@ def test_unsupported_requests_are_refused_not_ignored(sim):
     a4, w4 = _bf(_rt(M, 4 * K)), _bf(_rt(N, 4 * K))
     assert sim.gemm_fuse_supported(a4, w4, out, M=M, N=N, colstat=cs)
     assert not sim.gemm_fuse_supported(a4, w4, out, M=M, N=N, colstat=cs, split_k=2)   # split-K: the reduce kernel finishes, not the tile
+
+
+def test_gemm_plan_reports_what_the_launch_would_do(sim):
+    """t2v_gemm_plan: tile id and K splits resolved as the launch resolves them, nothing launched.  A long-K conv on few rows splits K
+    (given a workspace), the same launch with a dropout / LoRA epilogue is pinned to one split — the fact the gradient engine's choice of
+    the LoRA form rests on (engine._lora_epilogue_pays)."""
+    n, h, wd, c0, N = 2, 8, 8, 640, 128
+    M = n * h * wd
+    x, w = _bf(_rt(M, c0, seed=1)), _bf(_rt(N, 9 * c0, seed=2, scale=0.01))
+    out = torch.zeros(M, N, dtype=torch.bfloat16)
+    kw = dict(M=M, N=N, mode=nt.GEMM_CONV3X3, n_img=n, h=h, wd=wd)
+    cfg, splits = sim.gemm_plan(x, w, out, **kw)
+    assert cfg > 0 and splits > 1, (cfg, splits)
+    cfg1, one = sim.gemm_plan(x, w, out, split_k=1, **kw)
+    assert one == 1
+    t, u = _bf(_rt(M, 64, seed=3)), _bf(_rt(N, 64, seed=4))
+    seed = torch.tensor([7], dtype=torch.int64)
+    _, s_lora = sim.gemm_plan(x, w, out, lora=(t, u, N, 1.0), dropout=(0.1, seed, 3, N, 0), **kw)
+    assert s_lora == 1
+    before = out.clone()
+    assert torch.equal(out, before)   # (nothing ran)
