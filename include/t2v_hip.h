@@ -97,7 +97,9 @@ typedef struct t2v_gemm_desc {
     /* dropout between the product and the residual (0 threshold = off): out = keep ? (alpha*acc + bias) / (1 - p) : 0, then
      * + rowvec + residual.  The mask is t2v_dropout_bf16's: one splitmix64 word per QUAD of adjacent elements of a
      * row-major [rows][drop_ncols] matrix in which this launch's output starts at column drop_col0 (both multiples of 4), 16 bits per
-     * element against drop_thr >> 16 (drop_thr = p * 2^32); the 64-bit seed is read from device memory.  LoraInjected*.forward's dropout(up(down(x))) * scale
+     * element against drop_thr >> 16 (drop_thr = p * 2^32): p is resolved to 2^-16, so the drop probability is p' = (drop_thr >> 16) / 65536
+     * and the caller passes drop_inv_keep = 1 / (1 - p') = 65536 / (65536 - (drop_thr >> 16)) (E[out] = in exactly; p < 2^-16 keeps
+     * everything at scale 1); the 64-bit seed is read from device memory.  LoraInjected*.forward's dropout(up(down(x))) * scale
      * (utils/lora.py:45-50) as the epilogue of the up-projection.  Not combined with GEGLU / split-K. */
     const void* drop_seed;
     unsigned drop_thr, drop_site;
@@ -421,7 +423,8 @@ int t2v_wgrad_tn_group(const t2v_wgrad_problem* problems, int n, float* ws, long
  * sides: cols % 8 == 0, ld_in % 8 == 0, ld_out % 8 == 0 and >= roundup(rows, 64), 16-byte aligned bases, batch strides % 8. */
 int t2v_transpose_pad_bf16(const void* in, int ld_in, int rows, int cols, void* out, int ld_out, int batch, long long in_stride,
                            long long out_stride, void* stream);
-/* t2v_dropout_bf16: out[r][c] = keep(r, c) ? x[r][c] / (1 - p) : 0  (+ resid[r][c]) over rows x ncols bf16 (ncols even), where
+/* t2v_dropout_bf16: out[r][c] = keep(r, c) ? x[r][c] / (1 - p') : 0  (+ resid[r][c]) over rows x ncols bf16 (ncols even), p' = ((p * 2^32) >> 16) / 65536
+ * (the probability the 16-bit mask really drops with: the scale keeps E[out] = x exactly), where
  * keep is a pure function of (*seed, site, i = r * ncols + c): word = splitmix64(seed + site * 0x9E3779B97F4A7C15 + (i >> 2) *
  * 0xD1B54A32D192ED03), element i keeps iff bits [16 (i & 3), +16) of the word >= (p * 2^32) >> 16 (p resolved to 2^-16).  The backward calls it again with the same (seed,
  * site) on the gradient.  seed: device pointer to one uint64 (a replayed launch list follows the step's seed).  In-place is

@@ -14,9 +14,12 @@ Used by ``tests/test_gpu_train_parity.py`` (16 frames) and by ``bench.py``'s dis
 import torch
 
 
-def student_reference(state_dict, unet_cfg, rank, x, ts, ctx, fps, tc, r_out, threads=None, checkpoint=True):
+def student_reference(state_dict, unet_cfg, rank, x, ts, ctx, fps, tc, r_out, threads=None, checkpoint=True, prepare=None):
     """``state_dict``: of the LoRA-injected student (any device / dtype).  Returns (y, d<y, r_out>/dx, [d/d(lora tensor)]) on
-    the CPU in fp32, LoRA tensors in ``lora.lora_parameters`` order (up0, down0, up1, down1, ...), eval mode."""
+    the CPU in fp32, LoRA tensors in ``lora.lora_parameters`` order (up0, down0, up1, down1, ...), eval mode.
+    ``prepare(ref)``: called on the fp32 CPU module before the forward — the train-mode gate puts the module in train mode there
+    and replaces every ``nn.Dropout`` the device engine applied by that engine's own mask (tests/mask_replay.py); with dropout
+    modules replaced by fixed masks the checkpointed recomputation is the same function, so checkpointing stays on."""
     from t2v_turbo_amd import lora
     from t2v_turbo_amd.unet3d import UNetModel
     if threads:
@@ -33,6 +36,8 @@ def student_reference(state_dict, unet_cfg, rank, x, ts, ctx, fps, tc, r_out, th
     params = lora.lora_parameters(ref)
     for p in params:
         p.requires_grad_(True)
+    if prepare is not None:
+        prepare(ref)
     xg = x.detach().to("cpu", torch.float32).clone().requires_grad_(True)
     y = ref(xg, ts.cpu(), context=ctx.detach().to("cpu", torch.float32), fps=fps,
             timestep_cond=None if tc is None else tc.detach().to("cpu", torch.float32))

@@ -63,9 +63,11 @@ __device__ __forceinline__ void hwait_vmcnt() { tile80::wait_vmcnt<N>(); }
 
 // NWL of the 8 waves stage weights (W_IT pieces of 1 KiB per stage each), the other 8 - NWL the activation sub-slabs (A_IT pieces
 // per sub-slab each).
-template <int WM, int WN, int KG, int NP, int NWS, int NA, int NWL, int A_IT, int FX>
+template <int WM, int WN, int KG, int NP, int NWS, int NA, int NWL, int A_IT, int FX, int NB = 5>
 struct HaloCfg {
     static_assert(WM * WN * KG == 8, "eight waves");
+    static_assert(NB == 5 || NB == 4, "channel blocks (of 16) per wave tile");
+    static constexpr int WTN = 16 * NB;                    // channels per wave tile
     static_assert(FX == 16 || FX == 32, "tile width");
     static constexpr int HALVES = FX / 16;                 // 16-token MFMA blocks per tile row
     static_assert(WM % HALVES == 0, "a wave owns five rows of one 16-column half");
@@ -74,7 +76,7 @@ struct HaloCfg {
     static constexpr int SLAB_ROWS = (S + 2) * PT;
     static constexpr int NAL = 8 - NWL;
     static_assert(SLAB_ROWS <= A_IT * NAL * 16, "activation buffer too small for the halo slab");
-    static constexpr int BM = WM * 80, BN = WN * 80;
+    static constexpr int BM = WM * 80, BN = WN * WTN;
     static_assert(BM == S * FX, "tile geometry");
     static constexpr int W_PIECES = NP * BN / 16;          // 1 KiB pieces per weight stage
     static_assert(W_PIECES % NWL == 0, "weight pieces per loader wave");
@@ -83,7 +85,7 @@ struct HaloCfg {
     static constexpr int WS_BYTES = NP * BN * 64;
     static constexpr int RING_BYTES = NA * A_BYTES + NWS * WS_BYTES;
     static constexpr int OUT_BYTES = tile80::Epi<BM, BN>::BYTES;   // the epilogue's staging area + the tile's global row table
-    static constexpr int RED_BYTES = (KG - 1) * WM * WN * 25 * 1024;
+    static constexpr int RED_BYTES = (KG - 1) * WM * WN * NB * 5 * 1024;
     static constexpr int SMEM = RING_BYTES > OUT_BYTES ? (RING_BYTES > RED_BYTES ? RING_BYTES : RED_BYTES) : (OUT_BYTES > RED_BYTES ? OUT_BYTES : RED_BYTES);
     static_assert(SMEM <= 160 * 1024, "LDS");
     static_assert(NP % KG == 0, "every k-group takes the same number of pairs of a stage");
@@ -115,12 +117,13 @@ struct HaloCfg {
     static_assert(W_IT * (NWS - 1) <= 60, "vmcnt field");
 };
 
-template <int WM, int WN, int KG, int NP, int NWS, int NA, int NWL, int A_IT, int FX>
+template <int WM, int WN, int KG, int NP, int NWS, int NA, int NWL, int A_IT, int FX, int NB>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_halo_kernel(const HaloParams p) {
     // (the host pass of hipcc does not know the buffer-descriptor builtins and would silently drop the kernel's stub: it sees an empty body)
 #if defined(__HIP_DEVICE_COMPILE__) || defined(T2V_HOSTSIM)
-    using C = HaloCfg<WM, WN, KG, NP, NWS, NA, NWL, A_IT, FX>;
-    constexpr int BM = C::BM, BN = C::BN, W_IT = C::W_IT, PPS = C::PPS, PT = C::PT, S = C::S, HALVES = C::HALVES, Fx = FX;
+    using C = HaloCfg<WM, WN, KG, NP, NWS, NA, NWL, A_IT, FX, NB>;
+    constexpr int BM = C::BM, BN = C::BN, W_IT = C::W_IT, PPS = C::PPS, PT = C::PT, S = C::S, HALVES = C::HALVES, Fx = FX, WTN = C::WTN;
+    constexpr int NMF = 5 * NB;   // MFMAs per (sub-slab, tap) pair and wave
     constexpr int T = 9;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const t2v_gemm_desc& d = p.d;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- fragment addressing -------------------------------------------------------------------------------------
     // weights (MFMA A operand: rows = channels): row 16 bn + l15 of the pair tile, chunk lq ^ swizzle(l15): one lane constant,
     // the five blocks 1 KiB apart
-    const int w_lane = (wave_n * 80 + l15) * 64 + ((lq ^ (((l15 >> 2) & 1) << 1)) << 4) + kgroup * (BN * 64);
+    const int w_lane = (wave_n * WTN + l15) * 64 + ((lq ^ (((l15 >> 2) & 1) << 1)) << 4) + kgroup * (BN * 64);
     // activations (MFMA B operand: columns = tokens): block bm, tap (ty, tx) reads slab row (5 rg + bm + ty) PT + 16 half + tx + l15.
     // PT and 16 half are multiples of 8, so the swizzle bit (row & 4) is ((tx + l15) & 4): the per-lane part of the address depends
     // on tx only, the rest is a scalar, and the five blocks are PT rows = PT*64 bytes apart.
@@ -228,8 +231,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int a_rows0 = (rg * 5 * PT + half * 16) * 64;
     auto a_lane_of = [&](int tx) { const int t = l15 + tx; return a_rows0 + (t << 6) + ((lq << 4) ^ ((t & 4) << 3)); };
     const int a_lane0 = a_lane_of(0), a_lane1 = a_lane_of(1), a_lane2 = a_lane_of(2);
-    bf16x8_t fa[2][5], fw[2][5];
-    f32x4_t acc[5][5];   // [channel block][token block]
+    bf16x8_t fa[2][5], fw[2][NB];
+    f32x4_t acc[NB][5];   // [channel block][token block]
 
     // Fragments of one pair into register set `which`.  QB = JS * NP + I * KG: the pair of k-group 0 at this point of the
     // super-iteration; mine is QB + kgroup.  With one k-group everything is a compile-time constant (sub-slab QB / 9 in buffer
@@ -256,12 +259,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int bm = 0; bm < 5; ++bm) fa[which][bm] = *(const bf16x8_t*)(ab + bm * (PT * 64));
 #pragma unroll
-        for (int bn = 0; bn < 5; ++bn) fw[which][bn] = *(const bf16x8_t*)(wb + bn * 1024);
+        for (int bn = 0; bn < NB; ++bn) fw[which][bn] = *(const bf16x8_t*)(wb + bn * 1024);
     };
     auto mfmas = [&](int which, int first, int last) {
         if (HABL(16)) return;
 #pragma unroll
-        for (int bn = 0; bn < 5; ++bn)
+        for (int bn = 0; bn < NB; ++bn)
 #pragma unroll
             for (int bm = 0; bm < 5; ++bm)
                 if (bn * 5 + bm >= first && bn * 5 + bm < last)
@@ -280,9 +283,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // when consumed: see t2v_gemm); the other k-groups start at zero.  The residual is NOT folded in here: in this accumulator
     // layout a lane owns 4 channels of a row, so the tile would arrive in 8-byte pieces and the main loop could not start before
     // they had (measured: +11 us at 40960 x 320); it is added in the epilogue's row pass instead, with full-width loads.
-    const int ch_lane = n0 + wave_n * 80 + lq * 4;
+    const int ch_lane = n0 + wave_n * WTN + lq * 4;
 #pragma unroll
-    for (int bn = 0; bn < 5; ++bn)
+    for (int bn = 0; bn < NB; ++bn)
 #pragma unroll
         for (int bm = 0; bm < 5; ++bm) acc[bn][bm] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     if (kgroup == 0) {
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // row for the whole tile: five 16-byte loads per lane next to the five of the bias)
         const long long rv_row = d.rowvec ? (long long)(((long long)img * U * V) / d.rowvec_div) * d.ld_rowvec : 0;
 #pragma unroll
-        for (int bn = 0; bn < 5; ++bn) {
+        for (int bn = 0; bn < NB; ++bn) {
             const int ch = ch_lane + bn * 16;
             float4 v = (d.bias && ch < d.N) ? *(const float4*)(d.bias + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (d.rowvec && ch < d.N) {
@@ -330,14 +333,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if constexpr (I < PPS - 1) {
                     mfmas(CUR, 0, 1);
                     read_frags(std::integral_constant<int, QB + KG>{}, CUR ^ 1);
-                    mfmas(CUR, 1, 25);
-                    if (!HABL(64)) {
+                    mfmas(CUR, 1, NMF);
+                    if (!HABL(64)) {   // one fragment read behind each of the first 5 + NB MFMAs, the other MFMAs after them
 #pragma unroll
-                        for (int r = 0; r < 10; ++r) {
+                        for (int r = 0; r < 5 + NB; ++r) {
                             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         }
-                        __builtin_amdgcn_sched_group_barrier(0x008, 15, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, NMF - (5 + NB), 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 } else {
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         for (int c = 0; c < CNT; ++c)
                             if (!HABL(2)) issue_a(sub_base - C::SUBS + FIRST + c, ((FIRST + c) % NA) * C::A_BYTES);
                     }
-                    mfmas(CUR, 1, 25);
+                    mfmas(CUR, 1, NMF);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 return false;
@@ -375,32 +378,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the ring is dead
     asm volatile("" ::: "memory");
-    tile80::reduce_kgroups<KG, WM * WN>(smem, acc, kgroup, wv, lane);
-    tile80::epilogue<BM, BN>(
-        smem, d, acc, kgroup == 0, wave_n * 80 + lq * 4, tid, n0,
+    tile80::reduce_kgroups<KG, WM * WN, NB>(smem, acc, kgroup, wv, lane);
+    tile80::epilogue<BM, BN, NB>(
+        smem, d, acc, kgroup == 0, wave_n * WTN + lq * 4, tid, n0,
         [&](int bm) { return (rg * 5 + bm) * Fx + half * 16 + l15; },                       // tile order: row-major over the S x FX rectangle
         [&](int r) { const int s = r / Fx; return token_of(s, r - s * Fx); }, HABL(32));
 #endif
 }
 
-template <int WM, int WN, int KG, int NP, int NWS, int NA, int NWL, int A_IT, int FX>
+template <int WM, int WN, int KG, int NP, int NWS, int NA, int NWL, int A_IT, int FX, int NB = 5>
 int halo_launch(HaloParams& p, hipStream_t s) {
-    using C = HaloCfg<WM, WN, KG, NP, NWS, NA, NWL, A_IT, FX>;
+    using C = HaloCfg<WM, WN, KG, NP, NWS, NA, NWL, A_IT, FX, NB>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, KG, NP, NWS, NA, NWL, A_IT, FX>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        hipFuncSetAttribute((const void*)conv_halo_kernel<WM, WN, KG, NP, NWS, NA, NWL, A_IT, FX, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, KG, NP, NWS, NA, NWL, A_IT, FX>), dim3(p.tiles_m * p.tiles_n), dim3(512), C::SMEM, s, p);
+    hipLaunchKernelGGL((conv_halo_kernel<WM, WN, KG, NP, NWS, NA, NWL, A_IT, FX, NB>), dim3(p.tiles_m * p.tiles_n), dim3(512), C::SMEM, s, p);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
 
 struct HaloTile { int s, fx, bn, np, na; };
-// ids 1..4 (tile_cfg 40..43): 320x160 (10 rows x 32, one k-group), 320x80 (two k-groups), 160x80 on a 16-wide grid (10 x 16, four
+// ids 1..5 (tile_cfg 40..44): 320x160 (10 rows x 32, one k-group), 320x80 (two k-groups), 160x80 on a 16-wide grid (10 x 16, four
 // k-groups), 160x80 on a 32-wide grid (5 x 32, four k-groups)
-const HaloTile kHalo[] = {{0, 0, 0, 0, 0}, {10, 32, 160, 2, 2}, {10, 32, 80, 2, 2}, {10, 16, 80, 4, 4}, {5, 32, 80, 4, 4}};
-constexpr int kNumHalo = 4;
+// id 5 (tile_cfg 44): 320x128 on 80 x 64 wave tiles (4 channel blocks per wave: 9 fragment reads per 20 MFMAs instead of 10 per 25) for
+// widths that are multiples of 128 but not of 80 — the KL-VAE decoder's 128 / 256 / 512 channels, which the 80-wide tiles pad by a fifth
+const HaloTile kHalo[] = {{0, 0, 0, 0, 0}, {10, 32, 160, 2, 2}, {10, 32, 80, 2, 2}, {10, 16, 80, 4, 4}, {5, 32, 80, 4, 4}, {10, 32, 128, 2, 2}};
+constexpr int kNumHalo = 5;
 
 int halo_dispatch(int cfg, HaloParams& p, hipStream_t s) {
     switch (cfg) {
@@ -409,6 +414,7 @@ int halo_dispatch(int cfg, HaloParams& p, hipStream_t s) {
         case 2: return halo_launch<4, 1, 2, 2, 6, 2, 2, 5, 32>(p, s);
         case 3: return halo_launch<2, 1, 4, 4, 3, 4, 4, 5, 16>(p, s);
         case 4: return halo_launch<2, 1, 4, 4, 3, 4, 4, 5, 32>(p, s);
+        case 5: return halo_launch<4, 2, 1, 2, 3, 2, 4, 8, 32, 4>(p, s);
         default: return T2V_EINVAL;
     }
 }

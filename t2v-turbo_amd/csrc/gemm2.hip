@@ -241,8 +241,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // the ring is dead
     asm volatile("" ::: "memory");
-    tile80::reduce_kgroups<KG, WM * WN>(smem, acc, kgroup, wv, lane);
-    tile80::epilogue<BM, BN>(
+    tile80::reduce_kgroups<KG, WM * WN, 5>(smem, acc, kgroup, wv, lane);
+    tile80::epilogue<BM, BN, 5>(
         smem, d, acc, kgroup == 0, wave_n * 80 + lq * 4, tid, n0,
         [&](int bm) { return wave_m * 80 + bm * 16 + l15; },
         [&](int r) { return m0 + r < d.M ? m0 + r : -1; }, false);

@@ -235,7 +235,8 @@ __global__ __launch_bounds__(1024) void gn_final_kernel(const float* partial, in
 // MODE 0: (mean, rstd) per group in `stats`.  MODE 1: per-channel affine in `coef` (gn_final_kernel ran).
 // MODE 2: slab partials in `partial` (nslab <= GN_FUSE_SLABS): every block finishes the statistics of its unit itself,
 // which saves the final launch where launch latency, not bandwidth, is what a small tensor pays for.
-template <int MODE>
+// CPT: 16-byte channel chunks per thread the instantiation is sized for (1: C <= 2048; the second chunk's affine costs 16 registers)
+template <int MODE, int CPT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0, int ld0, const bf16_t* x1, int c1,
                                                        int ld1, int rows_per_unit, int groups, int slab_rows, const float* stats,
                                                        const float* coef, const float* partial, int nslab_stats, float inv_count,
@@ -257,13 +258,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0,
         for (long long l = b * per + tid; l < l1; l += 256) pf_acc |= __builtin_nontemporal_load((const unsigned*)(pf + (l << 7)));
     }
     const int cx = tid % g.tx, ry = tid / g.tx;
+    const int r0 = slab * slab_rows;
+    const int r1 = min(r0 + slab_rows, rows_per_unit);
+    // The rows of the first batch do not depend on the statistics: their loads go out BEFORE the unit's statistics are finished
+    // (MODE 2: a chain of partial loads, four workgroup barriers and a little fp64 — 2-3 us during which the block used to have
+    // nothing in flight; on the fused-statistics path a slab is exactly one batch, so this is every load of the block).
+    uint4 u[GN_RPT];   // (channel chunk j = 0; a second chunk per thread — C > 2048 — is loaded in the loop as before)
+    if (ry < g.ty && cx < g.cpr) {
+#pragma unroll
+        for (int t = 0; t < GN_RPT; ++t) {
+            const int rr = r0 + ry + t * g.ty;
+            if (rr < r1) u[t] = *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, (long long)unit * rows_per_unit + rr, cx * 8);
+        }
+    }
     __shared__ double sh[MODE == 2 ? 256 : 1];
     __shared__ float sm[MODE == 2 ? 128 : 1], sr[MODE == 2 ? 128 : 1];
     if (MODE == 2) gn_finish_unit<256, 64>(partial, unit, nslab_stats, groups, inv_count, eps, sh, sm, sr);
     if (ry >= g.ty) return;
-    float sc[GN_MAX_CPT][8], sf[GN_MAX_CPT][8];
+    float sc[CPT][8], sf[CPT][8];
 #pragma unroll
-    for (int j = 0; j < GN_MAX_CPT; ++j) {
+    for (int j = 0; j < CPT; ++j) {
         const int ci = cx + j * g.tx;
         if (j < g.cpt && ci < g.cpr) {
             if (MODE == 1) {
@@ -294,18 +308,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0,
             }
         }
     }
-    const int r0 = slab * slab_rows;
-    const int r1 = min(r0 + slab_rows, rows_per_unit);
     for (int r = r0 + ry; r < r1; r += GN_RPT * g.ty) {
 #pragma unroll
-        for (int j = 0; j < GN_MAX_CPT; ++j) {
+        for (int j = 0; j < CPT; ++j) {
             const int ci = cx + j * g.tx;
             if (j < g.cpt && ci < g.cpr) {
-                uint4 u[GN_RPT];
+                if (!(j == 0 && r == r0 + ry)) {   // (the first batch of chunk 0 is already on its way: see above)
 #pragma unroll
-                for (int t = 0; t < GN_RPT; ++t) {
-                    const int rr = r + t * g.ty;
-                    if (rr < r1) u[t] = *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, (long long)unit * rows_per_unit + rr, ci * 8);
+                    for (int t = 0; t < GN_RPT; ++t) {
+                        const int rr = r + t * g.ty;
+                        if (rr < r1) u[t] = *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, (long long)unit * rows_per_unit + rr, ci * 8);
+                    }
                 }
 #pragma unroll
                 for (int t = 0; t < GN_RPT; ++t) {
@@ -533,6 +546,69 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* x, int ldx
     }
 }
 
+// ---- LayerNorm, row-group form (round 5): LPR lanes own one row — CPL 16-byte chunks each, chunk sub + k * LPR, so a group reads
+// whole 16 * LPR-byte runs — and a wave holds 64 / LPR rows x RI iterations in registers.  The one-row-per-wave kernel above leaves
+// 24 of 64 lanes idle at C = 320 (40 chunks) and pays two 6-stage butterflies per row; here every lane carries data at the UNet's
+// widths (320 / 640 / 1280 = 8 / 16 / 32 lanes x 5 chunks) and a reduction is log2(LPR) stages for 64 / LPR rows at once.  Same
+// two-pass arithmetic (mean, then centred variance), so results differ from the other kernel only by fp32 summation order.
+template <int LPR, int CPL, int RI>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* x, int ldx, int M, int C, const float* gamma,
+                                                             const float* beta, float eps, bf16_t* out, int ldo) {
+    constexpr int RPW = 64 / LPR;   // rows per wave and iteration
+    const int lane = threadIdx.x & 63, sub = lane % LPR, rl = lane / LPR;
+    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * (RPW * RI) + rl;
+    uint4 u[RI][CPL];
+#pragma unroll
+    for (int it = 0; it < RI; ++it)
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const long long row = row0 + it * RPW;
+            u[it][k] = row < M ? *(const uint4*)(x + row * ldx + (sub + k * LPR) * 8) : make_uint4(0, 0, 0, 0);
+        }
+    float gg[CPL][8], bb[CPL][8];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int c = (sub + k * LPR) * 8;
+        const float4 g0 = *(const float4*)(gamma + c), g1 = *(const float4*)(gamma + c + 4);
+        const float4 b0 = *(const float4*)(beta + c), b1 = *(const float4*)(beta + c + 4);
+        gg[k][0] = g0.x; gg[k][1] = g0.y; gg[k][2] = g0.z; gg[k][3] = g0.w; gg[k][4] = g1.x; gg[k][5] = g1.y; gg[k][6] = g1.z; gg[k][7] = g1.w;
+        bb[k][0] = b0.x; bb[k][1] = b0.y; bb[k][2] = b0.z; bb[k][3] = b0.w; bb[k][4] = b1.x; bb[k][5] = b1.y; bb[k][6] = b1.z; bb[k][7] = b1.w;
+    }
+    const float inv_c = 1.0f / (float)C;
+#pragma unroll
+    for (int it = 0; it < RI; ++it) {
+        const long long row = row0 + it * RPW;
+        float v[CPL][8];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            unpack8(u[it][k], v[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[k][e];
+        }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const float mean = s * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dlt = v[k][e] - mean; q += dlt * dlt; }
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rstd = rsqrtf(q * inv_c + eps);
+        if (row < M) {
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                float o8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = (v[k][e] - mean) * rstd * gg[k][e] + bb[k][e];
+                *(uint4*)(out + row * ldo + (sub + k * LPR) * 8) = pack8(o8);
+            }
+        }
+    }
+}
+
 // ---- row softmax, one wave per row, row in registers (n_pad <= 64*8*SM_MAX = 4096) -----------
 constexpr int SM_MAX = 8;
 __global__ __launch_bounds__(256) void softmax_rows_kernel(bf16_t* s, long long rows, int n, int n_pad, int ld) {
@@ -590,6 +666,13 @@ int gn_check(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, i
 
 }  // namespace
 
+// gn_apply_kernel<MODE, CPT> by the chunk count the channel width needs
+#define T2V_GN_APPLY_LAUNCH(MODE, cpt, ...)                                       \
+    do {                                                                          \
+        if ((cpt) <= 1) hipLaunchKernelGGL((gn_apply_kernel<MODE, 1>), __VA_ARGS__); \
+        else hipLaunchKernelGGL((gn_apply_kernel<MODE, 2>), __VA_ARGS__);           \
+    } while (0)
+
 static int gn_nslab(int C, int rows_per_unit, int groups) {
     const int sr = gn_slab_rows(C, rows_per_unit, groups);
     return (rows_per_unit + sr - 1) / sr;
@@ -640,7 +723,7 @@ extern "C" int t2v_gn_apply(const void* x0, int c0, int ld0, const void* x1, int
     T2V_REQUIRE(stats && gamma && beta && out && ldo % 8 == 0, T2V_EINVAL, "t2v_gn_apply: bad argument");
     if (!x1) { c1 = 0; ld1 = 0; }
     const int C = c0 + c1;
-    hipLaunchKernelGGL(gn_apply_kernel<0>, dim3(gn_nslab(C, rows_per_unit, groups), n_units), dim3(256), 0, (hipStream_t)stream,
+    T2V_GN_APPLY_LAUNCH(0, gn_geom(C).cpt, dim3(gn_nslab(C, rows_per_unit, groups), n_units), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, rows_per_unit, groups, gn_slab_rows(C, rows_per_unit, groups),
                        stats, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0.f, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)nullptr, 0LL);
     T2V_CHECK_LAUNCH();
@@ -757,7 +840,7 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
         hipLaunchKernelGGL(gn_partial_kernel, dim3(stat_nslab, n_units), dim3(256), (size_t)2 * gg.ty * C * sizeof(float), s,
                            (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, rows_per_unit, groups, stat_rows, ws);
         T2V_CHECK_LAUNCH();
-        hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
+        T2V_GN_APPLY_LAUNCH(2, gn_geom(C).cpt, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
                            ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, stat_nslab,
                            inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
         T2V_CHECK_LAUNCH();
@@ -766,7 +849,7 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
     rc = gn_launch_partial(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups, ws, s);
     if (rc) return rc;
     if (nslab <= gn_fuse_slabs(groups)) {
-        hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
+        T2V_GN_APPLY_LAUNCH(2, gn_geom(C).cpt, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
                            ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, nslab,
                            inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
         T2V_CHECK_LAUNCH();
@@ -776,7 +859,7 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
     hipLaunchKernelGGL(gn_final_kernel, dim3(n_units), dim3(1024), 0, s, (const float*)ws, nslab, groups, C, inv_count, eps, gamma, beta,
                        (float*)nullptr, coef);
     T2V_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1,
+    T2V_GN_APPLY_LAUNCH(1, gn_geom(C).cpt, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1,
                        rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)coef, (const float*)nullptr, 0, 0.f, 0.f,
                        gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
     T2V_CHECK_LAUNCH();
@@ -809,7 +892,7 @@ extern "C" int t2v_group_norm_cs(const float* cs0, const float* cs1, const void*
     hipLaunchKernelGGL(gn_partial_cs_kernel, dim3(nblk, n_units), dim3(256), (size_t)2 * C * sizeof(float), s, cs0, c0, cs1, c1,
                        slabs_per_unit, slabs_per_blk, groups, ws);
     T2V_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
+    T2V_GN_APPLY_LAUNCH(2, gn_geom(C).cpt, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
                        ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, nblk,
                        inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
     T2V_CHECK_LAUNCH();
@@ -845,7 +928,43 @@ extern "C" int t2v_layernorm(const void* x, int ldx, int M, int C, const float* 
                              void* out, int ldo, void* stream) {
     T2V_REQUIRE(x && gamma && beta && out && M > 0, T2V_EINVAL, "t2v_layernorm: bad argument");
     T2V_REQUIRE(C % 8 == 0 && C <= 64 * 8 * LN_MAX && ldx % 8 == 0 && ldo % 8 == 0, T2V_ESHAPE, "t2v_layernorm: unsupported C");
-    const int nj = (C / 8 + 63) / 64;
+    // row-group form where C / 8 chunks split evenly over 8 / 16 / 32 / 64 lanes with at most 5 chunks per lane (the UNet's 320 /
+    // 640 / 1280 and every power-of-two width from 64); T2V_LN_ROWGROUP=0: the one-row-per-wave kernels (round 1-4) for A/B
+    static const bool rowgroup = !(getenv("T2V_LN_ROWGROUP") && getenv("T2V_LN_ROWGROUP")[0] == '0');
+    const int cpr = C / 8;
+    if (rowgroup) {
+#define T2V_LNR_LAUNCH(LPR, CPL, RI)                                                                                                \
+    do {                                                                                                                            \
+        constexpr int rows_blk = 4 * (64 / LPR) * RI;                                                                               \
+        hipLaunchKernelGGL((layernorm_rows_kernel<LPR, CPL, RI>), dim3((M + rows_blk - 1) / rows_blk), dim3(256), 0,               \
+                           (hipStream_t)stream, (const bf16_t*)x, ldx, M, C, gamma, beta, eps, (bf16_t*)out, ldo);                  \
+        T2V_CHECK_LAUNCH();                                                                                                         \
+        return T2V_OK;                                                                                                              \
+    } while (0)
+        // two iterations per wave while that still leaves >= 2 workgroups per CU
+#define T2V_LNR_PICK(LPR, CPL)                                                        \
+    do {                                                                              \
+        if ((long long)M >= 512LL * 8 * (64 / LPR)) T2V_LNR_LAUNCH(LPR, CPL, 2);      \
+        else T2V_LNR_LAUNCH(LPR, CPL, 1);                                             \
+    } while (0)
+        for (int lpr = 8; lpr <= 64; lpr <<= 1) {
+            if (cpr % lpr || cpr / lpr > 5) continue;
+            const int cpl = cpr / lpr;
+#define T2V_LNR_CASE(LPR)                                  \
+    if (lpr == LPR) {                                      \
+        if (cpl == 1) T2V_LNR_PICK(LPR, 1);                \
+        else if (cpl == 2) T2V_LNR_PICK(LPR, 2);           \
+        else if (cpl == 3) T2V_LNR_PICK(LPR, 3);           \
+        else if (cpl == 4) T2V_LNR_PICK(LPR, 4);           \
+        else T2V_LNR_PICK(LPR, 5);                         \
+    }
+            T2V_LNR_CASE(8) T2V_LNR_CASE(16) T2V_LNR_CASE(32) T2V_LNR_CASE(64)
+#undef T2V_LNR_CASE
+        }
+#undef T2V_LNR_PICK
+#undef T2V_LNR_LAUNCH
+    }
+    const int nj = (cpr + 63) / 64;
 #define T2V_LN_LAUNCH(NJ, ROWS)                                                                                              \
     hipLaunchKernelGGL((layernorm_kernel<NJ, ROWS>), dim3((M + 4 * ROWS - 1) / (4 * ROWS)), dim3(256), 0, (hipStream_t)stream, \
                        (const bf16_t*)x, ldx, M, C, gamma, beta, eps, (bf16_t*)out, ldo)

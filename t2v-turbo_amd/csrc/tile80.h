@@ -37,17 +37,17 @@ struct Epi {
     static constexpr int CPR = BN / 8;                            // 16-byte output chunks per tile row
 };
 
-// Workgroup-level epilogue of a BM x BN tile whose accumulators sit in 80 x 80 wave tiles (acc[channel block][token block], a lane
-// owns 4 consecutive channels of one token per block).  `owner`: this wave's accumulators are the final ones (k-group 0).
+// Workgroup-level epilogue of a BM x BN tile whose accumulators sit in 80 x 16 NB (tokens x channels) wave tiles (acc[channel block]
+// [token block], NB = 5 or 4 channel blocks, a lane owns 4 consecutive channels of one token per block).  `owner`: this wave's accumulators are the final ones (k-group 0).
 //   row_of(bm)   -> tile row (0 .. BM) of this lane's token in block bm
 //   grow_of(r)   -> global output row of tile row r, < 0 outside the problem
-//   col0         =  wave_n * 80 + 4 * lq: this lane's first channel within the tile (block bn adds 16 bn)
+//   col0         =  wave_n * 16 NB + 4 * lq: this lane's first channel within the tile (block bn adds 16 bn)
 // Values: v = acc (bias / row vector already inside) [+ residual] [-> SiLU] -> bf16.  Without a residual the tile is rounded
 // once and parked as bf16.  With one, the accumulators are parked in FP32 (one phase = half of a large tile at a time), and the
 // row pass adds the residual — read in full 16-byte row chunks, not in the accumulator layout's 8-byte pieces — before the ONE
 // rounding; the statistics are taken from the final bf16 values, written back in place.
-template <int BM, int BN, class RowOf, class GRowOf>
-__device__ __forceinline__ void epilogue(char* smem, const t2v_gemm_desc& d, f32x4_t (&acc)[5][5], bool owner, int col0, int tid, int n0,
+template <int BM, int BN, int NB, class RowOf, class GRowOf>
+__device__ __forceinline__ void epilogue(char* smem, const t2v_gemm_desc& d, f32x4_t (&acc)[NB][5], bool owner, int col0, int tid, int n0,
                                          RowOf row_of, GRowOf grow_of, bool skip_stores) {
     using E = Epi<BM, BN>;
     constexpr int P16 = E::P16, P32 = E::P32, CPR = E::CPR;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void epilogue(char* smem, const t2v_gemm_desc& d, f32
             for (int bm = 0; bm < 5; ++bm) {
                 char* st = smem + row_of(bm) * P16 + col0 * 2;
 #pragma unroll
-                for (int bn = 0; bn < 5; ++bn) {
+                for (int bn = 0; bn < NB; ++bn) {
                     f32x4_t v = acc[bn][bm];
                     if (d.act == T2V_ACT_SILU) { v[0] = silu_f(v[0]); v[1] = silu_f(v[1]); v[2] = silu_f(v[2]); v[3] = silu_f(v[3]); }
                     *(uint2*)(st + bn * 32) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
@@ -130,7 +130,7 @@ __device__ __forceinline__ void epilogue(char* smem, const t2v_gemm_desc& d, f32
             for (int bm = 0; bm < 5; ++bm) {
                 char* st = smem + (row_of(bm) - ph * ROWS) * P32 + col0 * 4;
 #pragma unroll
-                for (int bn = 0; bn < 5; ++bn) *(f32x4_t*)(st + bn * 64) = acc[bn][bm];
+                for (int bn = 0; bn < NB; ++bn) *(f32x4_t*)(st + bn * 64) = acc[bn][bm];
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -179,13 +179,13 @@ __device__ __forceinline__ void epilogue(char* smem, const t2v_gemm_desc& d, f32
 
 // k-groups: sum the partial accumulators of groups 1 .. KG-1 into group 0's through LDS (fixed order: deterministic).  Every wave of
 // the workgroup calls it after the ring is dead; WPG = waves per k-group, wv = this wave's index within its group.
-template <int KG, int WPG>
-__device__ __forceinline__ void reduce_kgroups(char* smem, f32x4_t (&acc)[5][5], int kgroup, int wv, int lane) {
+template <int KG, int WPG, int NB>
+__device__ __forceinline__ void reduce_kgroups(char* smem, f32x4_t (&acc)[NB][5], int kgroup, int wv, int lane) {
     if constexpr (KG > 1) {
         if (kgroup > 0) {
-            char* dst = smem + ((kgroup - 1) * WPG + wv) * (25 * 1024) + lane * 16;
+            char* dst = smem + ((kgroup - 1) * WPG + wv) * (NB * 5 * 1024) + lane * 16;
 #pragma unroll
-            for (int bn = 0; bn < 5; ++bn)
+            for (int bn = 0; bn < NB; ++bn)
 #pragma unroll
                 for (int bm = 0; bm < 5; ++bm) *(f32x4_t*)(dst + (bn * 5 + bm) * 1024) = acc[bn][bm];
         }
@@ -195,9 +195,9 @@ __device__ __forceinline__ void reduce_kgroups(char* smem, f32x4_t (&acc)[5][5],
         if (kgroup == 0) {
 #pragma unroll
             for (int g = 1; g < KG; ++g) {
-                const char* src = smem + ((g - 1) * WPG + wv) * (25 * 1024) + lane * 16;
+                const char* src = smem + ((g - 1) * WPG + wv) * (NB * 5 * 1024) + lane * 16;
 #pragma unroll
-                for (int bn = 0; bn < 5; ++bn)
+                for (int bn = 0; bn < NB; ++bn)
 #pragma unroll
                     for (int bm = 0; bm < 5; ++bm) acc[bn][bm] += *(const f32x4_t*)(src + (bn * 5 + bm) * 1024);
             }

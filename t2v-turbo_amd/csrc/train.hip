@@ -124,7 +124,7 @@ extern "C" int t2v_dropout_bf16(const void* x, int ldx, const void* resid, int l
                 "t2v_dropout_bf16: 4-byte aligned rows");
     const double t = (double)p * 4294967296.0;
     const uint32_t thr = (t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t) >> 16;   // 16 bits per element
-    const float inv_keep = 1.0f / (1.0f - p);
+    const float inv_keep = 65536.0f / (65536.0f - (float)thr);   // the scale of the QUANTISED drop probability thr / 65536 (E[out] = x exactly)
     const bool vec8 = ncols % 8 == 0 && ldx % 8 == 0 && ldo % 8 == 0 && (!resid || ldr % 8 == 0) && (uintptr_t)x % 16 == 0 &&
                       (uintptr_t)out % 16 == 0 && (!resid || (uintptr_t)resid % 16 == 0);
     const int per_row = ncols / (vec8 ? 8 : 2);

@@ -124,7 +124,11 @@ def effective_weight_bias(mod, merge=True):
 
 
 def leaf_out_channels(mod):
-    return effective_weight_bias(mod)[0].shape[0]
+    """Output channels of a Linear / Conv leaf (a LoRA-injected leaf has its frozen base's) without merging anything."""
+    base = getattr(mod, "linear", None) or getattr(mod, "conv", None)
+    if base is not None and hasattr(mod, "lora_up") and hasattr(mod, "lora_down"):
+        return base.weight.shape[0]
+    return mod.weight.shape[0]
 
 
 class Packer:
@@ -159,18 +163,22 @@ class Packer:
 
     def conv(self, mod):
         """[N, taps*Cin], tap-major: Conv2d [N,C,3,3] -> (ky,kx,c); Conv3d [N,C,3,1,1] -> (kt,c)."""
-        def make():
-            w = self.wb(mod)[0]
-            if w.dim() == 5:
-                w = w[:, :, :, 0, 0].permute(0, 2, 1)
-            else:
-                w = w.permute(0, 2, 3, 1)
-            return w.reshape(w.shape[0], -1).to(self.device, self.wdtype).contiguous()
-        return self._memo(("conv", id(mod)), make)
+        return self._memo(("conv", id(mod)), lambda: self._conv_tap_major(mod))
+
+    def _conv_tap_major(self, mod):
+        w = self.wb(mod)[0]
+        if w.dim() == 5:
+            w = w[:, :, :, 0, 0].permute(0, 2, 1)
+        else:
+            w = w.permute(0, 2, 3, 1)
+        return w.reshape(w.shape[0], -1).to(self.device, self.wdtype).contiguous()
 
     def conv_slab(self, mod):
         """Slab-major pack of a 3x3 conv for t2v_conv_halo: [N][C/32][9][32], rows zero-padded to whole weight stages (native.pack_conv_slab)."""
-        return self._memo(("conv_slab", id(mod)), lambda: nt.pack_conv_slab(self.conv(mod)))
+        def make():
+            cached = self.cache.get(("conv", id(mod)))   # (no second, tap-major copy is left behind for a conv the halo kernel takes)
+            return nt.pack_conv_slab(cached if cached is not None else self._conv_tap_major(mod))
+        return self._memo(("conv_slab", id(mod)), make)
 
     def mat_t(self, mod):
         """[K, N]^T pack of a Linear / 1x1 conv: the weight of its data gradient (dx = dy @ W)."""
@@ -422,9 +430,8 @@ class _Engine:
         module's packed forward weights (data-gradient convs pass the flipped / transposed pack and no bias).  With
         ``fuse_gn`` the launch also writes its output's column statistics for the GroupNorm that follows every conv of the UNet."""
         own_w = w is None
-        w = self.pk.conv(mod) if w is None else w
         bias = self.pk.bias(mod) if isinstance(bias, str) else bias
-        N = w.shape[0]
+        N = leaf_out_channels(mod) if own_w else w.shape[0]
         if mode == nt.GEMM_CONV3X3_S2:
             ho, wo = (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1
         elif mode == nt.GEMM_CONV3X3_UP2:
@@ -435,34 +442,41 @@ class _Engine:
         out = self.buf(M, N, out_dtype)
         kw = dict(M=M, N=N, a1=x.p1, mode=mode, n_img=x.n_img, h=x.h, wd=x.w, frames=frames, bias=bias, rowvec=rowvec,
                   rowvec_div=rowvec_div, residual=residual)
+        # the slab-major pack of the halo kernel, if this launch can go there at all (None: it cannot).  The tap-major pack of
+        # t2v_gemm is only built when a launch really needs it: a conv the halo kernel takes holds its weights ONCE per plan.
+        ws = self._halo_pack(x, mod, w, own_w, frozen_pack, N, mode, out)
+        if ws is not None and not self.ops.conv_halo_supported(x.parts[0], ws, out, **kw):
+            ws = None
         zf = None
-        if extra is not None and not self._lora_epilogue_pays(x, w, out, kw, own_w):
-            # (the gradient engine's LoRA branch as up-projection launches whose sum z is this launch's residual: the base leaf keeps
-            # its split-K plan / goes to the halo kernel)
-            zf, kw["residual"] = fallback()
-            extra = None
-        # 3x3 convs whose width fills whole 80-channel tiles go to the halo-slab kernel (csrc/conv_halo.hip: the activation tile and
-        # its halo stay in LDS across the nine taps; 14-32 % faster than the tuned t2v_gemm tiles at the UNet's three upper levels,
+        if extra is not None:
+            if w is None:
+                w = self.pk.conv(mod)
+            if not self._lora_epilogue_pays(x, w, out, kw, ws is not None):
+                # (the gradient engine's LoRA branch as up-projection launches whose sum z is this launch's residual: the base leaf
+                # keeps its split-K plan / goes to the halo kernel)
+                zf, kw["residual"] = fallback()
+                extra = None
+                if ws is not None and not self.ops.conv_halo_supported(x.parts[0], ws, out, **kw):   # (the residual is new)
+                    ws = None
+        # 3x3 convs go to the halo-slab kernel (csrc/conv_halo.hip: the activation tile and its halo stay in LDS across the nine
+        # taps; 14-32 % faster than the tuned t2v_gemm tiles at the UNet's three upper levels,
         # profiles/r04_conv_halo_v3_static_schedule.csv) when the launch has the module's own weights and a plain epilogue
-        if (self.conv_halo and (own_w or frozen_pack) and extra is None and mode == nt.GEMM_CONV3X3 and N % 80 == 0
-                and hasattr(self.ops, "conv_halo_supported") and out.dtype == self.adt and w.dtype == self.adt):
-            # (``frozen_pack``: a caller-given pack of FROZEN weights — the data-gradient convs' flipped base weights, which live in the
-            # Packer's cache — is repacked once; packs that are rewritten every step, like the LoRA groups', must not be cached here)
-            ws = self.pk.conv_slab(mod) if own_w else self.pk._memo(("conv_slab_of", id(w)), lambda: (w, nt.pack_conv_slab(w)))[1]
+        if ws is not None and extra is None:
             cs = None
             if want_cs and self.fuse_gn and M % 32 == 0:
                 cs = self.buf(M // 32, 2 * N, torch.float32)
                 if not self.ops.conv_halo_supported(x.parts[0], ws, out, colstat=cs, **kw):
                     self.pool.put(cs)
                     cs = None
-            if cs is not None or self.ops.conv_halo_supported(x.parts[0], ws, out, **kw):
-                if cs is not None:
-                    self.pool.link(out, cs)
-                    kw["colstat"] = cs
-                self.ops.conv_halo(x.parts[0], ws, out, **kw)
-                if zf is not None:
-                    self.pool.put(zf)
-                return Act(out, x.n_img, ho, wo, cs=[cs])
+            if cs is not None:
+                self.pool.link(out, cs)
+                kw["colstat"] = cs
+            self.ops.conv_halo(x.parts[0], ws, out, **kw)
+            if zf is not None:
+                self.pool.put(zf)
+            return Act(out, x.n_img, ho, wo, cs=[cs])
+        if w is None:
+            w = self.pk.conv(mod)
         if extra is not None:   # (the gradient engine: the LoRA branch in this launch's epilogue; ``fallback`` builds it as a residual)
             if self.ops.gemm_fuse_supported(x.parts[0], w, out, **kw, **extra):
                 kw.update(extra)
@@ -476,20 +490,40 @@ class _Engine:
             self.pool.put(zf)
         return Act(out, x.n_img, ho, wo, cs=[cs])
 
+    # output widths the halo kernel's wave tiles cover without padding: 80-channel wave tiles (the UNet's 320 / 640 / 1280)
+    def _halo_width_ok(self, N):
+        return N % 80 == 0
+
+    def _halo_pack(self, x, mod, w, own_w, frozen_pack, N, mode, out):
+        """The slab-major weight pack (``native.pack_conv_slab``) if the launch meets the halo kernel's static conditions, else None.
+        Checked BEFORE anything is packed: stride-1 3x3, the module's own or a frozen caller-given pack, 64-channel parts (the
+        kernel walks 32-channel sub-slabs of 64-aligned parts), bf16 in and out."""
+        if not (self.conv_halo and (own_w or frozen_pack) and mode == nt.GEMM_CONV3X3 and self._halo_width_ok(N)
+                and hasattr(self.ops, "conv_halo_supported") and out.dtype == self.adt and self.pk.wdtype == self.adt):
+            return None
+        if any(part.shape[1] % 64 for part in x.parts):
+            return None
+        if own_w:
+            return self.pk.conv_slab(mod)
+        if w.dtype != self.adt:
+            return None
+        # (``frozen_pack``: a caller-given pack of FROZEN weights — the data-gradient convs' flipped base weights, which live in the
+        # Packer's cache — is repacked once; packs that are rewritten every step, like the LoRA groups', must not be cached here)
+        return self.pk._memo(("conv_slab_of", id(w)), lambda: (w, nt.pack_conv_slab(w)))[1]
+
     # where a LoRA conv leaf does better WITHOUT the epilogue form (profiles/r04_student_gemm_shapes.csv): (a) the plain launch would
     # split K (2560 x 1280 x 23040: 453 us in one split vs 162 us in four), (b) a 3x3 conv over >= ``lora_halo_min_c`` input channels
-    # that the halo kernel takes (40960 x 320 x 5760: 157 us fused vs 112 + 20 us as halo conv + up-projection)
+    # that the halo kernel REALLY takes (40960 x 320 x 5760: 157 us fused vs 112 + 20 us as halo conv + up-projection) — asked of
+    # t2v_conv_halo_supported, not assumed: a launch it refuses would end on plain t2v_gemm + up-projection launches, the slowest form
     lora_split_aware = os.environ.get("T2V_LORA_SPLIT_AWARE", "1") == "1"
     lora_halo_min_c = int(os.environ.get("T2V_LORA_HALO_MIN_C", "640"))
 
-    def _lora_epilogue_pays(self, x, w, out, kw, own_w):
+    def _lora_epilogue_pays(self, x, w, out, kw, halo_takes):
         ops = self.ops
         if self.lora_split_aware and hasattr(ops, "gemm_plan") and ops.gemm_plan(x.parts[0], w, out, **kw)[1] > 1:
             return False
-        mode, N = kw["mode"], kw["N"]
         cin = sum(p.shape[1] for p in x.parts)
-        if (self.lora_halo_min_c and cin >= self.lora_halo_min_c and self.conv_halo and own_w and mode == nt.GEMM_CONV3X3 and N % 80 == 0
-                and hasattr(ops, "conv_halo_supported") and out.dtype == self.adt and w.dtype == self.adt):
+        if self.lora_halo_min_c and cin >= self.lora_halo_min_c and halo_takes:
             return False
         return True
 
@@ -547,7 +581,10 @@ class UNetEngine(_Engine):
                None if timestep_cond is None else (tuple(timestep_cond.shape), timestep_cond.dtype),
                None if motion_cond is None else (tuple(motion_cond.shape), motion_cond.dtype), x.device)
         plan = self.plans.get(key)
-        drops = self._active_tconv_dropouts() if m.training else {}
+        # (a root module in eval mode whose sub-blocks were put back in train mode has live dropouts too: they are either applied
+        # — the TemporalConvBlock ones — or refused, never silently ignored.  The Dropout(p > 0) modules are listed once per weight
+        # version, so the per-call check is a loop over ~10^2 flags, not a walk over the module tree.)
+        drops = self._active_tconv_dropouts() if (m.training or self._any_live_dropout()) else {}
         if plan is None or plan["training"] != m.training or plan.get("drop_sig") != tuple(sorted(drops.values())):
             self.drop_ps = drops   # id(nn.Dropout) -> p of the TemporalConvBlock dropouts that are live (train-mode frozen network)
             plan = self._own(self._record(x, timesteps, context, fps, timestep_cond, motion_cond))
@@ -580,6 +617,13 @@ class UNetEngine(_Engine):
     # Dropout(p = 0.1) layers of every TemporalConvBlock (openaimodel3d.py:282-294) are LIVE in the reference's teacher forwards.
     # The inference dataflow applies them with the counter-based masks of t2v_dropout_bf16 between the GroupNorm + SiLU and the
     # (3,1,1) conv, exactly where the gradient engine puts them for the student; any other active Dropout still refuses.
+    def _any_live_dropout(self):
+        cache = getattr(self, "_dropout_mods", None)
+        if cache is None or cache[0] != self.fingerprint:
+            from .nn_util import walk_modules
+            cache = self._dropout_mods = (self.fingerprint, [mod for mod in walk_modules(self.model) if isinstance(mod, nn.Dropout) and mod.p > 0])
+        return any(mod.training for mod in cache[1])
+
     def _active_tconv_dropouts(self):
         from .nn_util import walk_modules
         from .unet3d import TemporalConvBlock

@@ -246,7 +246,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                         continue
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        ops.replay(launches, ops.stream())
+                        ops.replay(launches, ops.stream(), cache=False)   # (a temporary sub-list: nothing to reuse)
                     built.append((g, None))
                 plan[gkey] = built
                 return self._replay(plan, which)

@@ -22,6 +22,15 @@ class VAEDecodeEngine(_Engine):
         if type(self).__name__ in ("VAEDecodeEngine", "VAEEncodeEngine"):
             self.fuse_gn = os.environ.get("T2V_FUSE_GN", "1") == "1"
 
+    # The decoder's stride-1 3x3 convs (ae_modules.py:183-203: 128 / 256 / 512 channels over 40x64 ... 320x512 images, 25 TFLOP per
+    # clip) are the halo-slab kernel's best case — large images, whole 10 x 32 tiles — but their widths are not multiples of its
+    # 80-channel wave tiles.  The kernel pads the last channel tile (rows >= N are out-of-range DMA lanes = zeros, never stored):
+    # 128 -> 160, 256 -> 320, 512 -> 560 / 640 columns of MFMA work.  T2V_VAE_HALO=0: the tuned t2v_gemm tiles (rounds 1-4).
+    vae_halo = os.environ.get("T2V_VAE_HALO", "1") == "1"
+
+    def _halo_width_ok(self, N):
+        return N % 80 == 0 or (self.vae_halo and N % 16 == 0 and N >= 64)
+
     @on_tensor_device
     def decode_frames(self, z, scale):
         """z (b, zc, t, h, w) -> (b, out_ch, t, 8h, 8w) in z.dtype; z is multiplied by ``scale`` first."""

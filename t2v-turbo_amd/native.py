@@ -66,6 +66,18 @@ def conv_halo_pack_cols(channels):
     return ((channels // 32 * 9 + 7) // 8) * 8 * 32
 
 
+def dropout_thr16(p):
+    """The 16-bit keep threshold the device compares an element's mask bits with: (p * 2^32) >> 16 (csrc/common.h)."""
+    t = float(p) * 4294967296.0
+    return (0xFFFFFFFF if t >= 4294967295.0 else int(t)) >> 16
+
+
+def dropout_inv_keep(p):
+    """1 / (1 - p') with p' = thr16 / 65536, the drop probability the 16-bit mask really has (p = 0.1 -> 6553 / 65536): the scale
+    that keeps E[dropout(x)] = x exactly.  p < 2^-16 quantises to 'keep everything' at scale 1."""
+    return 65536.0 / (65536.0 - dropout_thr16(p))
+
+
 def pack_conv_slab(w_tap_major, taps=9):
     """[N, 9 * C] tap-major 3x3 conv weights (``Packer.conv``) -> the K order of t2v_conv_halo: (32-channel sub-slab, tap, channel),
     i.e. [N][C / 32][9][32] flattened — one (sub-slab, tap) pair is 64 contiguous bytes of every row — zero-padded to
@@ -284,6 +296,47 @@ def load_tune_table(path=None):
     return {(r["mode"], r["M"], r["N"], r["K"], r["batch"]): (r["cfg"], r["split"]) for r in rows}
 
 
+class TuneTable(dict):
+    """The tile table with a NEAREST-SHAPE fallback.  gemm_tune.json holds exactly the shapes the tuner recorded (the bench latent
+    16x40x64, the 16-frame VAE, the training step); any other frame count or resolution (app.py:342-348 offers 16-48 frames) gave
+    every launch to the library heuristic.  What a tile choice depends on is mostly (mode, N, K) — the operand widths, the epilogue
+    — and whether M fills the chip: a missing key takes the tile of the tuned entry with the same (mode, N, K, batch) whose M is
+    nearest in ratio (within 0.4 .. 2.5x), and its K split only when M is within a third (else the library's own split rule).
+    ``T2V_GEMM_TUNE_NEAREST=0``: exact keys only (rounds 1-4).  ``stats`` counts exact / nearest / miss lookups."""
+
+    def __init__(self, table=(), nearest=None):
+        super().__init__(table)
+        self.nearest = (os.environ.get("T2V_GEMM_TUNE_NEAREST", "1") == "1") if nearest is None else nearest
+        self.stats = {"exact": 0, "nearest": 0, "miss": 0}
+        self._index = None
+
+    def _near(self):
+        if self._index is None or self._index[0] != len(self):
+            idx = {}
+            for (mode, M, N, K, batch), (cfg, split) in self.items():
+                idx.setdefault((mode, N, K, batch), []).append((M, cfg, split))
+            self._index = (len(self), idx)
+        return self._index[1]
+
+    def lookup(self, key):
+        hit = dict.get(self, key)
+        if hit is not None:
+            self.stats["exact"] += 1
+            return hit
+        if self.nearest and len(self):
+            import math
+            mode, M, N, K, batch = key
+            cands = self._near().get((mode, N, K, batch))
+            if cands and M > 0:
+                m_t, cfg, split = min(cands, key=lambda e: abs(math.log(e[0] / M)))
+                ratio = m_t / M
+                if 0.4 <= ratio <= 2.5:
+                    self.stats["nearest"] += 1
+                    return (cfg, split if 0.75 <= ratio <= 1.34 else 0)
+        self.stats["miss"] += 1
+        return None
+
+
 class HipOps:
     """Tensor-level view of the C-ABI.  Every method launches on torch's current stream; while
     ``recording`` is a list, the raw (function, args) tuples are appended to it as well so that a
@@ -299,7 +352,7 @@ class HipOps:
         self.recording = None
         self._keep = []  # objects that must outlive recorded calls (descs, host arrays)
         self._ws = {}
-        self.tune = load_tune_table()
+        self.tune = TuneTable(load_tune_table())
 
     def workspace(self, device):
         """split-K partial-sum workspace shared by all GEMM launches of this backend (one stream)."""
@@ -376,24 +429,36 @@ class HipOps:
         flush(len(recording))
         return segs
 
-    def replay(self, recording, stream):
+    max_progs = 16   # compiled launch lists kept (least recently used beyond this are dropped, one at a time)
+
+    def replay(self, recording, stream, cache=True):
+        """Issue a recorded launch list.  ``cache=False``: a one-shot list (the sub-lists an engine cuts for hipGraph capture) —
+        compiled, replayed and forgotten.  Cached programs are an LRU keyed by the list's identity: a plan that was dropped
+        elsewhere (weight change, plan eviction) ages out here instead of pinning its descriptors until 64 entries pile up, and
+        eviction never throws away the programs of the plans that are still in use."""
         if not self.c_replay or not hasattr(self.lib, "t2v_replay"):
             for fn, args, name in recording:
                 rc = fn(*args, stream)
                 if rc != 0:
                     _check(rc, name)
             return
-        cache = getattr(self, "_progs", None)
-        if cache is None:
-            cache = self._progs = {}
-        key = id(recording)
-        hit = cache.get(key)
-        if hit is None or hit[0] is not recording or hit[1] != len(recording):
-            if len(cache) > 64:
-                cache.clear()
-            hit = cache[key] = (recording, len(recording), self.compile_recording(recording))
+        if not cache:
+            prog = self.compile_recording(recording)
+        else:
+            progs = getattr(self, "_progs", None)
+            if progs is None:
+                import collections
+                progs = self._progs = collections.OrderedDict()
+            key = id(recording)
+            hit = progs.get(key)
+            if hit is None or hit[0] is not recording or hit[1] != len(recording):
+                hit = progs[key] = (recording, len(recording), self.compile_recording(recording))
+            progs.move_to_end(key)
+            while len(progs) > self.max_progs:
+                progs.popitem(last=False)
+            prog = hit[2]
         failed = C.c_int(-1)
-        for seg in hit[2]:
+        for seg in prog:
             if seg[0] == "c":
                 rc = self.lib.t2v_replay(seg[1], seg[2], stream, C.byref(failed))
                 if rc != 0:
@@ -469,12 +534,15 @@ class HipOps:
             p_drop, seed_t, site, ncols, col0 = dropout
             t = float(p_drop) * 4294967296.0
             d.drop_thr = 0xFFFFFFFF if t >= 4294967295.0 else int(t)
-            d.drop_seed, d.drop_site, d.drop_inv_keep = _p(seed_t), int(site), 1.0 / (1.0 - float(p_drop))
+            d.drop_seed, d.drop_site, d.drop_inv_keep = _p(seed_t), int(site), dropout_inv_keep(p_drop)
             d.drop_ncols, d.drop_col0 = int(ncols), int(col0)
             split_k = 1
         taps = {GEMM_LINEAR: 1, GEMM_TCONV3: 3}.get(mode, 9)
         # a split_k argument without a tile id is a hint (the training engine's token-contracted weight gradients): a tuned entry wins
-        tuned = self.tune.get((mode, M, N, taps * (d.c0 + d.c1), batch)) if tile_cfg == 0 else None
+        tuned = None
+        if tile_cfg == 0:
+            key = (mode, M, N, taps * (d.c0 + d.c1), batch)
+            tuned = self.tune.lookup(key) if hasattr(self.tune, "lookup") else self.tune.get(key)
         d.tile_cfg, d.split_k = tuned if tuned else (tile_cfg, split_k)
         if d.drop_thr:
             d.split_k = 1

@@ -113,7 +113,7 @@ class EmuOps:
                     keep = self.dropout_keep(int(seed_t.reshape(-1)[0]), site, M, ncols, p_drop)
                     if getattr(self, "masks", None) is not None:
                         self.masks[site] = keep
-                    z = torch.where(keep[:, col0:col0 + N], z / (1.0 - p_drop), torch.zeros(()))
+                    z = torch.where(keep[:, col0:col0 + N], z * nt.dropout_inv_keep(p_drop), torch.zeros(()))
                 y = y + sc * z
             elif dropout is not None and dropout[0] > 0:  # the dropout epilogue of t2v_gemm: the mask of dropout() on its column block
                 p_drop, seed_t, site, ncols, col0 = dropout
@@ -121,7 +121,7 @@ class EmuOps:
                 keep = self.dropout_keep(int(seed_t.reshape(-1)[0]), site, M, ncols, p_drop)
                 if getattr(self, "masks", None) is not None:
                     self.masks[site] = keep
-                y = torch.where(keep[:, col0:col0 + N], y / (1.0 - p_drop), torch.zeros(()))
+                y = torch.where(keep[:, col0:col0 + N], y * nt.dropout_inv_keep(p_drop), torch.zeros(()))
             if act == nt.ACT_GEGLU:
                 g = y.reshape(M, N // 64, 2, 32)
                 y = (g[:, :, 0] * F.gelu(g[:, :, 1])).reshape(M, N // 2)
@@ -144,7 +144,7 @@ class EmuOps:
                 out2[:, :N] = F.layer_norm(y, (N,), gamma.float(), beta.float(), eps).to(out2.dtype)
 
     # ---- t2v_conv_halo: the same 3x3 convolution on the slab-major weight pack (csrc/conv_halo.hip) ----------------------------
-    HALO_TILES = ((10, 32, 160, 4), (10, 32, 80, 4), (10, 16, 80, 8), (5, 32, 80, 8))   # (rows, columns, channels, pairs per stage pair)
+    HALO_TILES = ((10, 32, 160, 4), (10, 32, 80, 4), (10, 16, 80, 8), (5, 32, 80, 8), (10, 32, 128, 4))   # (rows, columns, channels, pairs per stage pair)
 
     def conv_halo_supported(self, a0, w, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
                             rowvec=None, rowvec_div=0, residual=None, act=nt.ACT_NONE, alpha=1.0, batch=1, tile_cfg=0, split_k=0,
@@ -159,7 +159,7 @@ class EmuOps:
             return 0
         assert w.shape[1] >= nt.conv_halo_pack_cols(c0 + c1), "slab-major pack narrower than conv_halo_pack_cols"
         U, V = h, wd
-        pick = tile_cfg - 39 if 40 <= tile_cfg < 44 else 0
+        pick = tile_cfg - 39 if 40 <= tile_cfg < 40 + len(self.HALO_TILES) else 0
         best, best_id = -1.0, 0
         for i, (S, fx, bn, _) in enumerate(self.HALO_TILES, start=1):
             if pick and i != pick:
@@ -618,7 +618,7 @@ class EmuOps:
         keep = self.dropout_keep(int(seed.reshape(-1)[0]), site, x.shape[0], ncols, p)
         if getattr(self, "masks", None) is not None:
             self.masks[site] = keep
-        v = torch.where(keep, x[:, :ncols].float() / (1.0 - p), torch.zeros(()))
+        v = torch.where(keep, x[:, :ncols].float() * nt.dropout_inv_keep(p), torch.zeros(()))
         if resid is not None:
             v = v + resid[:, :ncols].float()
         out[:, :ncols] = v.to(out.dtype)
@@ -653,7 +653,7 @@ class ReplayOps:
     def stream():
         return None
 
-    def replay(self, recording, stream):
+    def replay(self, recording, stream, cache=True):
         self.replays += 1
         for fn, a, k in recording:
             fn(*a, **k)

@@ -7,6 +7,7 @@ with the engine's mask, re-laid into the row / channel order torch sees at that 
 backend, masks captured as they are drawn) and the GPU suite (masks regenerated on the host from the recorded site
 geometry: ``tests.emu_ops.EmuOps.dropout_keep`` is bit-identical to the device mask, tests/test_gpu_unet_grad.py)."""
 import torch
+from t2v_turbo_amd import native as nt
 
 
 def patch_engine_masks(m, eng, masks):
@@ -37,7 +38,7 @@ def patch_engine_masks(m, eng, masks):
                 B, F, h, w = meta
                 k = keep.view(B, F, h, w, -1).permute(0, 4, 1, 2, 3)
             assert k.shape == t.shape, (kind, k.shape, t.shape)
-            return t * k / (1.0 - p)
+            return t * k * nt.dropout_inv_keep(p)   # the engine's scale: 1 / (1 - thr16 / 65536)
         drop.forward = fwd
 
     for sid, (drops, kind, meta) in enumerate(eng.drop_sites):

@@ -58,3 +58,22 @@ def test_header_is_plain_c():
     hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "t2v_hip.h")
     r = subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_tune_table_nearest_shape_fallback():
+    """native.TuneTable: exact key first; else the entry with the same (mode, N, K, batch) and the nearest M within 0.4 .. 2.5x — its
+    tile, and its K split only when M is within a third; anything else is a miss (library heuristic)."""
+    from t2v_turbo_amd.native import TuneTable
+    t = TuneTable({(0, 40960, 320, 320, 1): (23, 1), (0, 10240, 320, 320, 1): (11, 1), (1, 640, 1280, 11520, 1): (4, 4)}, nearest=True)
+    assert t.lookup((0, 40960, 320, 320, 1)) == (23, 1)
+    assert t.lookup((0, 30000, 320, 320, 1)) == (23, 0)       # nearest in ratio is 40960 (1.37x: tile only)
+    assert t.lookup((0, 12288, 320, 320, 1)) == (11, 1)       # 10240 is within a third: split kept
+    assert t.lookup((0, 8192, 320, 320, 1)) == (11, 1)
+    assert t.lookup((0, 2048, 320, 320, 1)) is None           # 5x away from every entry
+    assert t.lookup((0, 40960, 320, 640, 1)) is None          # another K
+    assert t.lookup((1, 512, 1280, 11520, 1)) == (4, 4)
+    assert t.lookup((1, 1024, 1280, 11520, 1)) == (4, 0)
+    assert t.stats == {"exact": 1, "nearest": 5, "miss": 2}
+    t.nearest = False
+    assert t.lookup((0, 8192, 320, 320, 1)) is None
+    assert TuneTable({}).lookup((0, 1, 1, 64, 1)) is None

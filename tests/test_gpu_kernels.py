@@ -566,6 +566,21 @@ def test_conv_halo_virtual_concat_ragged_and_silu(pair):
     _halo_case(pair, n_img=2, h=20, w=32, c0=64, c1=256, N=48, cfg=40, residual=True, seed=9)   # ragged channel tile
 
 
+def test_conv_halo_vae_decoder_widths(pair):
+    # 128 / 256 / 512 output channels (KL-VAE decoder, ae_modules.py:183-203) on padded 80-channel wave tiles, at decoder image sizes
+    _halo_case(pair, n_img=2, h=80, w=128, c0=128, N=128, residual=True, colstat=True, seed=21, repeat=2)
+    _halo_case(pair, n_img=2, h=40, w=64, c0=256, N=256, colstat=True, seed=22)
+    _halo_case(pair, n_img=2, h=40, w=64, c0=512, N=512, residual=True, colstat=True, seed=23)
+    _halo_case(pair, n_img=1, h=80, w=128, c0=512, N=256, colstat=True, seed=24)
+
+
+def test_conv_halo_64_channel_wave_tiles(pair):
+    # tile id 44 (320x128 on 80 x 64 wave tiles) forced: exact widths, a ragged one (N = 192), row vector + SiLU, virtual concat
+    _halo_case(pair, n_img=2, h=40, w=64, c0=128, N=128, cfg=44, rowvec=True, residual=True, colstat=True, seed=31, repeat=3)
+    _halo_case(pair, n_img=2, h=20, w=32, c0=256, c1=256, N=512, cfg=44, colstat=True, seed=32)
+    _halo_case(pair, n_img=1, h=12, w=64, c0=64, N=192, cfg=44, rowvec=True, act=2, seed=33)
+
+
 def test_conv_halo_unet_level_shapes_repeatable(pair):
     # the three levels at full size (one frame pair each), library's own tile choice; 3 back-to-back launches into the same output
     _halo_case(pair, n_img=2, h=40, w=64, c0=320, N=320, rowvec=True, residual=True, colstat=True, seed=10, repeat=3)

@@ -99,6 +99,23 @@ def test_conv3x3_ragged_rows_and_channels(sim):
     _case(sim, n_img=1, h=12, w=32, c0=64, N=48, cfg=41, residual=True, seed=5)
 
 
+def test_conv3x3_vae_decoder_widths(sim):
+    # the KL-VAE decoder's widths (ae_modules.py:183-203): 128 / 256 / 512 channels are not multiples of the 80-channel wave tile;
+    # the last channel tile is padded (128 = 80 + 48 or one 160-wide tile, 256 = 160 + 96, 512 = 6 x 80 + 32), with the epilogue
+    # variants the decoder uses (residual; column statistics of the next GroupNorm)
+    _case(sim, n_img=1, h=10, w=32, c0=128, N=128, residual=True, colstat=True, seed=21)
+    _case(sim, n_img=1, h=20, w=32, c0=64, N=256, colstat=True, seed=22)
+    _case(sim, n_img=1, h=10, w=32, c0=64, N=512, cfg=41, residual=True, colstat=True, seed=23)
+
+
+def test_conv3x3_64_channel_wave_tiles(sim):
+    # tile id 44: 320x128 on 80 x 64 wave tiles (four channel blocks per wave) — what the heuristic picks for N = 128 / 256 / 512;
+    # forced here on a ragged width too (N = 192: the second channel tile is half empty), with a row vector and SiLU
+    _case(sim, n_img=1, h=10, w=32, c0=128, N=128, cfg=44, residual=True, colstat=True, seed=31)
+    _case(sim, n_img=1, h=20, w=32, c0=64, c1=64, N=256, cfg=44, rowvec=True, colstat=True, seed=32)
+    _case(sim, n_img=1, h=12, w=64, c0=64, N=192, cfg=44, rowvec=True, act=nt.ACT_SILU, seed=33)
+
+
 def test_heuristic_picks_a_tile_and_matches(sim):
     _case(sim, n_img=2, h=10, w=16, c0=64, N=80, seed=6)
     _case(sim, n_img=2, h=20, w=32, c0=128, N=160, seed=7)

@@ -13,6 +13,7 @@ import torch
 
 from oracle.synth import synth_state_dict
 from t2v_turbo_amd import native as nt
+from tests.emu_ops import EmuOps
 from tests.util import load, manifest, rel_l2, tiny_unet_params
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim"))
@@ -298,3 +299,46 @@ def test_c_side_replay_equals_the_python_loop(full_ops):
     bad = (C.c_ulonglong * 3)(9999, 1, 0)
     failed = C.c_int(-7)
     assert sim.lib.t2v_replay(bad, 3, None, C.byref(failed)) < 0
+
+
+def _rt5(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).bfloat16().float()
+
+
+def _bf5(t):
+    return t.to(torch.bfloat16).contiguous()
+
+
+# ---------------------------------------------------------------------------------- round 5: row-group LayerNorm, GroupNorm apply with hoisted loads
+@pytest.mark.parametrize("M,Cc", [(70, 320), (37, 640), (19, 1280), (130, 64), (9, 128), (40, 192), (33, 1024), (5, 2048), (21, 48)])
+def test_layernorm_row_group_and_fallback_widths(full_ops, M, Cc):
+    """t2v_layernorm: the row-group kernels (8 / 16 / 32 / 64 lanes per row x <= 5 chunks: 320, 640, 1280, powers of two, ragged row
+    counts that leave lane groups without a row) and the one-row-per-wave fallback (48 channels = 6 chunks) against the emulation."""
+    sim, emu = full_ops(), EmuOps()
+    x = _rt5(M, Cc, seed=M + Cc, scale=2.0) + 0.5
+    g = torch.Generator().manual_seed(Cc)
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    o_s, o_e = torch.zeros(M, Cc, dtype=torch.bfloat16), torch.zeros(M, Cc)
+    sim.layernorm(_bf5(x), gamma, beta, 1e-5, o_s)
+    emu.layernorm(x, gamma, beta, 1e-5, o_e)
+    assert rel_l2(o_s.float(), o_e) < 6e-3
+
+
+@pytest.mark.parametrize("units,rows,c0,c1,silu", [(2, 96, 320, 0, True), (3, 64, 64, 128, False), (1, 2560, 320, 0, True),
+                                                   (2, 40, 1280, 1280, True), (1, 72, 2560, 0, False)])
+def test_group_norm_apply_with_hoisted_first_batch(full_ops, units, rows, c0, c1, silu):
+    """t2v_group_norm (statistics pass + apply whose blocks finish the statistics themselves, or the three-launch form for many slabs):
+    the apply kernel now issues its first batch of rows before it finishes the statistics; one and two chunks per thread (C > 2048),
+    virtual concats, ragged slabs."""
+    sim, emu = full_ops(), EmuOps()
+    Cc = c0 + c1
+    x0 = _rt5(units * rows, c0, seed=rows + c0, scale=1.5) + 0.25
+    x1 = (_rt5(units * rows, c1, seed=rows + c1 + 1, scale=0.7) - 0.5) if c1 else None
+    g = torch.Generator().manual_seed(Cc + rows)
+    gamma, beta = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    ws = torch.zeros(max(int(sim.group_norm_ws_floats(units, rows, 32, Cc)), 1))
+    o_s, o_e = torch.zeros(units * rows, Cc, dtype=torch.bfloat16), torch.zeros(units * rows, Cc)
+    sim.group_norm(_bf5(x0), None if x1 is None else _bf5(x1), units, rows, 1e-5, gamma, beta, silu, ws, o_s, 32)
+    emu.group_norm(x0, x1, units, rows, 1e-5, gamma, beta, silu, torch.zeros(8), o_e, 32)
+    assert rel_l2(o_s.float(), o_e) < 6e-3

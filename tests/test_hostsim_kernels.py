@@ -306,3 +306,4 @@ def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
     emu.wgrad_tn(a[:, :R], b[:, :C], o_e, alpha=0.5)
     sim.wgrad_tn(_bf(a)[:, :R], _bf(b)[:, :C], o_s[:, :C], alpha=0.5, splits=splits)
     assert rel_l2(o_s[:, :C], o_e) < 1e-5 and float(o_s[:, C:].min()) == 7.0
+

@@ -4,7 +4,7 @@ replay with the masks REGENERATED from the recorded site geometry (what the GPU 
 import torch
 
 from tests.emu_ops import EmuOps
-from tests.test_gpu_train_parity import run_train_mode_with_replayed_masks, run_trainer_route
+from tests.test_gpu_train_parity import run_student_train_mode_vs_reference_oracle, run_train_mode_with_replayed_masks, run_trainer_route
 
 
 def test_trainer_route_two_steps_cpu():
@@ -85,3 +85,13 @@ def test_train_mode_masks_with_the_split_aware_lora_form_cpu():
 
     run_train_mode_with_replayed_masks("cpu", SplittingPlan(strict=True), 2e-5, 1e-4, 0.99999, 1e-3)
     assert SplittingPlan.n_split > 20 and SplittingPlan.n_asked > SplittingPlan.n_split
+
+
+def test_student_train_mode_vs_reference_oracle_body_cpu():
+    """Dry run of tests/test_gpu_train_parity.py::test_full_width_student_in_train_mode_with_replayed_masks at tiny width on the emulated
+    backend: randomly initialised student, train mode, masks regenerated from the site geometry and patched into the module that
+    oracle/lora_grad_oracle.student_reference builds from the state dict (its ``prepare`` hook)."""
+    from tests.util import tiny_unet_params
+    cfg = tiny_unet_params()
+    run_student_train_mode_vs_reference_oracle(torch.device("cpu"), EmuOps(strict=True), cfg, (1, 4, 2, 8, 8), None, 20,
+                                               2e-5, 1e-4, 0.99999, 1e-3, seed_model=11)

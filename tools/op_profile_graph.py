@@ -18,6 +18,8 @@ from tools.gemm_profile_graph import graph_time  # noqa: E402
 def algo_bytes(name, a):
     if name in ("t2v_gn_stats", "t2v_gn_apply", "t2v_group_norm"):
         return {"t2v_gn_stats": 1, "t2v_gn_apply": 2, "t2v_group_norm": 2}[name] * 2.0 * a[6] * a[7] * (a[1] + a[4])
+    if name == "t2v_group_norm_cs":   # (cs0, cs1, x0, c0, ld0, x1, c1, ld1, units, rows, ...): one read + one write of the tensor
+        return 2 * 2.0 * a[8] * a[9] * (a[3] + a[6])
     if name == "t2v_layernorm":
         return 4.0 * a[2] * a[3]
     if name == "t2v_attn_temporal":
