@@ -30,6 +30,21 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# what each translation unit includes besides common.h and the C-ABI header (an object is rebuilt when it is older than any of them)
+EXTRA_DEPS = {"gemm.hip": ["gemm2.h"], "gemm_exp.hip": ["gemm.hip", "gemm2.h"], "gemm_fuse.hip": ["gemm.hip", "gemm2.h"],
+              "conv_halo.hip": ["tile80.h"], "gemm2.hip": ["tile80.h", "gemm2.h"], "backward.hip": ["gn_bwd_common.h"],
+              "backward_unet.hip": ["gn_bwd_common.h"]}
+
+
+def _stale(src, obj):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [os.path.join(HERE, src), os.path.join(HERE, "common.h"), os.path.join(ROOT, "include", "t2v_hip.h"), os.path.abspath(__file__)]
+    deps += [os.path.join(HERE, d) for d in EXTRA_DEPS.get(src, [])]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
@@ -39,6 +54,9 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         o = os.path.join(HERE, s.replace(".hip", ".o" if not os.environ.get("T2V_HIP_LIB_OUT") else ".variant.o"))
         objs.append(o)
+        # (variant builds carry their own flags: always recompiled; the product build only recompiles what changed)
+        if not force and not os.environ.get("T2V_HIP_LIB_OUT") and not os.environ.get("T2V_EXTRA_HIPCC_FLAGS") and not _stale(s, o):
+            continue
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(HERE, s), "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -1,4 +1,4 @@
-// Implicit-GEMM 3x3 convolution (stride 1, pad 1) with an LDS-RESIDENT HALO SLAB (gfx950, bf16 MFMA, fp32 accumulate).
+// Implicit-GEMM 3x3 convolution (stride 1, pad 1; optionally over a nearest-x2 upsampled source) with an LDS-RESIDENT HALO SLAB (gfx950, bf16 MFMA, fp32 accumulate).
 //
 //   out[M,N] = epilogue( sum over taps t, channels c:  A[shift_t(m)][c] * W[n][t][c] )
 //
@@ -35,7 +35,8 @@
 
 struct HaloParams {
     t2v_gemm_desc d;
-    int U, V;              // per-image grid (rows, columns): token m = (img * U + u) * V + v
+    int U, V;              // per-image OUTPUT grid (rows, columns): token m = (img * U + u) * V + v
+    int ups;               // 1: nearest-x2 upsampling folded into the gather (T2V_GEMM_CONV3X3_UP2): the source grid is (U / 2, V / 2)
     int tiles_s, tiles_f;  // tiles per image along the rows / the columns
     int tiles_m, tiles_n;
     int nsub, nq, nstage;  // 32-channel sub-slabs, (sub-slab, tap) pairs, weight stages
@@ -161,10 +162,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ts_i = trem / p.tiles_f, tf_i = trem - ts_i * p.tiles_f;
     const int s0 = ts_i * S, f0 = tf_i * Fx;     // tile origin (image row, image column)
     const int U = p.U, V = p.V;
-    // global row of tile-relative (s, f) (< 0: outside the image)
+    // global OUTPUT row of tile-relative (s, f) (< 0: outside the image)
     auto token_of = [&](int s, int f) -> int {
         const int u = s0 + s, v = f0 + f;
         return (u >= 0 && u < U && v >= 0 && v < V) ? (img * U + u) * V + v : -1;
+    };
+    // global SOURCE row the conv reads at (tile-relative) position (s, f) of the output grid: the same token, or with nearest-x2
+    // upsampling (openaimodel3d.py:98-112: interpolate, then conv) the source pixel (u >> 1, v >> 1) of the half-size grid — the
+    // slab then holds every source row up to four times, which costs L1 / L2 hits, not a different kernel
+    const int ups = p.ups;
+    auto src_token_of = [&](int s, int f) -> int {
+        const int u = s0 + s, v = f0 + f;
+        return (u >= 0 && u < U && v >= 0 && v < V) ? (img * (U >> ups) + (u >> ups)) * (V >> ups) + (v >> ups) : -1;
     };
 
     char* const a_base = smem;
@@ -182,8 +191,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ld_ch16 = ((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 16;
     // (exact sizes: the loaders run ahead blindly past the last stage / sub-slab, and what they fetch there must not fault)
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)d.w, 0, (unsigned)d.N * (unsigned)d.ldw * 2u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.a0, 0, (unsigned)d.M * (unsigned)d.lda0 * 2u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_a1 = d.a1 ? __builtin_amdgcn_make_buffer_rsrc((void*)d.a1, 0, (unsigned)d.M * (unsigned)d.lda1 * 2u, 0x00020000) : rs_a0;
+    const unsigned m_src = (unsigned)d.M >> (2 * p.ups);   // source rows
+    const __amdgpu_buffer_rsrc_t rs_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)d.a0, 0, m_src * (unsigned)d.lda0 * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a1 = d.a1 ? __builtin_amdgcn_make_buffer_rsrc((void*)d.a1, 0, m_src * (unsigned)d.lda1 * 2u, 0x00020000) : rs_a0;
     if (w_loader) {
 #pragma unroll
         for (int j = 0; j < L_IT; ++j) {
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int j = 0; j < L_IT; ++j) {
             const int row = (lw + NAL * j) * 16 + (lane >> 2);
             const int sr = row / PT, fc = row - sr * PT;
-            ld_off[j] = (j < A_IT && sr < S + 2 && fc < Fx + 2) ? token_of(sr - 1, fc - 1) : -1;
+            ld_off[j] = (j < A_IT && sr < S + 2 && fc < Fx + 2) ? src_token_of(sr - 1, fc - 1) : -1;
         }
     }
     auto issue_w = [&](int stage, int slot_byte_off) {   // weight stage `stage` into the ring slot at this byte offset
@@ -435,7 +445,8 @@ static int halo_prepare(const t2v_gemm_desc* dd, HaloParams& p, int& cfg) {
     p.d = *dd;
     t2v_gemm_desc& d = p.d;
     if (!d.a1) { d.c1 = 0; d.lda1 = 0; }
-    if (d.mode != T2V_GEMM_CONV3X3) return T2V_OK;
+    if (d.mode != T2V_GEMM_CONV3X3 && d.mode != T2V_GEMM_CONV3X3_UP2) return T2V_OK;
+    p.ups = d.mode == T2V_GEMM_CONV3X3_UP2 ? 1 : 0;
     if (d.batch > 1 || d.alpha != 1.0f || d.out_f32 || d.split_k > 1 || d.drop_thr || d.ln_out || d.rowstat_out || d.lnf_stats || d.lora_t ||
         (d.act != T2V_ACT_NONE && d.act != T2V_ACT_SILU))
         return T2V_OK;
@@ -443,10 +454,10 @@ static int halo_prepare(const t2v_gemm_desc* dd, HaloParams& p, int& cfg) {
     if (((uintptr_t)d.a0 | (uintptr_t)d.w | (uintptr_t)d.out | (uintptr_t)d.a1) % 16) return T2V_OK;
     if (d.residual && (d.ldr % 8 || (uintptr_t)d.residual % 16)) return T2V_OK;
     if (d.bias && (uintptr_t)d.bias % 16) return T2V_OK;
-    if (d.rowvec && ((uintptr_t)d.rowvec % 16 || d.ld_rowvec % 4 || d.rowvec_div <= 0 || d.rowvec_div % (d.h_in * d.w_in))) return T2V_OK;
+    if (d.rowvec && ((uintptr_t)d.rowvec % 16 || d.ld_rowvec % 4 || d.rowvec_div <= 0 || d.rowvec_div % ((d.h_in << p.ups) * (d.w_in << p.ups)))) return T2V_OK;
     T2V_REQUIRE(d.n_img > 0 && d.h_in > 0 && d.w_in > 0, T2V_EINVAL, "t2v_conv_halo: conv geometry");
     const int C = d.c0 + d.c1;
-    p.U = d.h_in; p.V = d.w_in;
+    p.U = d.h_in << p.ups; p.V = d.w_in << p.ups;
     const int n_img = d.n_img;
     T2V_REQUIRE((long long)d.M == (long long)n_img * p.U * p.V, T2V_EINVAL, "t2v_conv_halo: M does not match the geometry");
     const int T = 9;
@@ -454,7 +465,7 @@ static int halo_prepare(const t2v_gemm_desc* dd, HaloParams& p, int& cfg) {
     p.nq = p.nsub * T;
     T2V_REQUIRE(d.ldw >= t2v_conv_halo_pack_cols(C), T2V_EINVAL, "t2v_conv_halo: ldw < the padded pack width (t2v_conv_halo_pack_cols)");
     // the DMA's per-lane byte offsets are 31-bit
-    if ((long long)d.M * (d.lda0 > d.lda1 ? d.lda0 : d.lda1) * 2 >= (1ll << 31) || (long long)d.N * d.ldw * 2 >= (1ll << 31)) return T2V_OK;
+    if (((long long)d.M >> (2 * p.ups)) * (d.lda0 > d.lda1 ? d.lda0 : d.lda1) * 2 >= (1ll << 31) || (long long)d.N * d.ldw * 2 >= (1ll << 31)) return T2V_OK;
     // tile choice: the largest tile whose grid fills >= 85 % of a whole number of 256-CU rounds; otherwise the best filler
     const int pick = d.tile_cfg >= 40 && d.tile_cfg < 40 + kNumHalo ? d.tile_cfg - 39 : g_halo_force;
     double best = -1.0;

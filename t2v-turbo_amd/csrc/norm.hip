@@ -232,11 +232,13 @@ __global__ __launch_bounds__(1024) void gn_final_kernel(const float* partial, in
     }
 }
 
+// (Round 5, measured and NOT kept: issuing the first batch of row loads before gn_finish_unit — so that the 2-3 us of statistics finish
+// would overlap the rows' flight — made the 117 fused-statistics GroupNorms of a UNet step 3 % SLOWER in-graph, 1.880 vs 1.821 ms
+// (profiles/r05_ops_ingraph_ab.csv): the in-order vmcnt wait for the partials then also waits for the 8 rows queued in front of them.)
 // MODE 0: (mean, rstd) per group in `stats`.  MODE 1: per-channel affine in `coef` (gn_final_kernel ran).
 // MODE 2: slab partials in `partial` (nslab <= GN_FUSE_SLABS): every block finishes the statistics of its unit itself,
 // which saves the final launch where launch latency, not bandwidth, is what a small tensor pays for.
-// CPT: 16-byte channel chunks per thread the instantiation is sized for (1: C <= 2048; the second chunk's affine costs 16 registers)
-template <int MODE, int CPT>
+template <int MODE>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0, int ld0, const bf16_t* x1, int c1,
                                                        int ld1, int rows_per_unit, int groups, int slab_rows, const float* stats,
                                                        const float* coef, const float* partial, int nslab_stats, float inv_count,
@@ -258,26 +260,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0,
         for (long long l = b * per + tid; l < l1; l += 256) pf_acc |= __builtin_nontemporal_load((const unsigned*)(pf + (l << 7)));
     }
     const int cx = tid % g.tx, ry = tid / g.tx;
-    const int r0 = slab * slab_rows;
-    const int r1 = min(r0 + slab_rows, rows_per_unit);
-    // The rows of the first batch do not depend on the statistics: their loads go out BEFORE the unit's statistics are finished
-    // (MODE 2: a chain of partial loads, four workgroup barriers and a little fp64 — 2-3 us during which the block used to have
-    // nothing in flight; on the fused-statistics path a slab is exactly one batch, so this is every load of the block).
-    uint4 u[GN_RPT];   // (channel chunk j = 0; a second chunk per thread — C > 2048 — is loaded in the loop as before)
-    if (ry < g.ty && cx < g.cpr) {
-#pragma unroll
-        for (int t = 0; t < GN_RPT; ++t) {
-            const int rr = r0 + ry + t * g.ty;
-            if (rr < r1) u[t] = *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, (long long)unit * rows_per_unit + rr, cx * 8);
-        }
-    }
     __shared__ double sh[MODE == 2 ? 256 : 1];
     __shared__ float sm[MODE == 2 ? 128 : 1], sr[MODE == 2 ? 128 : 1];
     if (MODE == 2) gn_finish_unit<256, 64>(partial, unit, nslab_stats, groups, inv_count, eps, sh, sm, sr);
     if (ry >= g.ty) return;
-    float sc[CPT][8], sf[CPT][8];
+    float sc[GN_MAX_CPT][8], sf[GN_MAX_CPT][8];
 #pragma unroll
-    for (int j = 0; j < CPT; ++j) {
+    for (int j = 0; j < GN_MAX_CPT; ++j) {
         const int ci = cx + j * g.tx;
         if (j < g.cpt && ci < g.cpr) {
             if (MODE == 1) {
@@ -308,17 +297,18 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x0, int c0,
             }
         }
     }
+    const int r0 = slab * slab_rows;
+    const int r1 = min(r0 + slab_rows, rows_per_unit);
     for (int r = r0 + ry; r < r1; r += GN_RPT * g.ty) {
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
+        for (int j = 0; j < GN_MAX_CPT; ++j) {
             const int ci = cx + j * g.tx;
             if (j < g.cpt && ci < g.cpr) {
-                if (!(j == 0 && r == r0 + ry)) {   // (the first batch of chunk 0 is already on its way: see above)
+                uint4 u[GN_RPT];
 #pragma unroll
-                    for (int t = 0; t < GN_RPT; ++t) {
-                        const int rr = r + t * g.ty;
-                        if (rr < r1) u[t] = *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, (long long)unit * rows_per_unit + rr, ci * 8);
-                    }
+                for (int t = 0; t < GN_RPT; ++t) {
+                    const int rr = r + t * g.ty;
+                    if (rr < r1) u[t] = *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, (long long)unit * rows_per_unit + rr, ci * 8);
                 }
 #pragma unroll
                 for (int t = 0; t < GN_RPT; ++t) {
@@ -666,13 +656,6 @@ int gn_check(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, i
 
 }  // namespace
 
-// gn_apply_kernel<MODE, CPT> by the chunk count the channel width needs
-#define T2V_GN_APPLY_LAUNCH(MODE, cpt, ...)                                       \
-    do {                                                                          \
-        if ((cpt) <= 1) hipLaunchKernelGGL((gn_apply_kernel<MODE, 1>), __VA_ARGS__); \
-        else hipLaunchKernelGGL((gn_apply_kernel<MODE, 2>), __VA_ARGS__);           \
-    } while (0)
-
 static int gn_nslab(int C, int rows_per_unit, int groups) {
     const int sr = gn_slab_rows(C, rows_per_unit, groups);
     return (rows_per_unit + sr - 1) / sr;
@@ -723,7 +706,7 @@ extern "C" int t2v_gn_apply(const void* x0, int c0, int ld0, const void* x1, int
     T2V_REQUIRE(stats && gamma && beta && out && ldo % 8 == 0, T2V_EINVAL, "t2v_gn_apply: bad argument");
     if (!x1) { c1 = 0; ld1 = 0; }
     const int C = c0 + c1;
-    T2V_GN_APPLY_LAUNCH(0, gn_geom(C).cpt, dim3(gn_nslab(C, rows_per_unit, groups), n_units), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(gn_apply_kernel<0>, dim3(gn_nslab(C, rows_per_unit, groups), n_units), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, rows_per_unit, groups, gn_slab_rows(C, rows_per_unit, groups),
                        stats, (const float*)nullptr, (const float*)nullptr, 0, 0.f, 0.f, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)nullptr, 0LL);
     T2V_CHECK_LAUNCH();
@@ -840,7 +823,7 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
         hipLaunchKernelGGL(gn_partial_kernel, dim3(stat_nslab, n_units), dim3(256), (size_t)2 * gg.ty * C * sizeof(float), s,
                            (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, rows_per_unit, groups, stat_rows, ws);
         T2V_CHECK_LAUNCH();
-        T2V_GN_APPLY_LAUNCH(2, gn_geom(C).cpt, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
+        hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
                            ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, stat_nslab,
                            inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
         T2V_CHECK_LAUNCH();
@@ -849,7 +832,7 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
     rc = gn_launch_partial(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups, ws, s);
     if (rc) return rc;
     if (nslab <= gn_fuse_slabs(groups)) {
-        T2V_GN_APPLY_LAUNCH(2, gn_geom(C).cpt, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
+        hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
                            ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, nslab,
                            inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
         T2V_CHECK_LAUNCH();
@@ -859,7 +842,7 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
     hipLaunchKernelGGL(gn_final_kernel, dim3(n_units), dim3(1024), 0, s, (const float*)ws, nslab, groups, C, inv_count, eps, gamma, beta,
                        (float*)nullptr, coef);
     T2V_CHECK_LAUNCH();
-    T2V_GN_APPLY_LAUNCH(1, gn_geom(C).cpt, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1,
+    hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1,
                        rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)coef, (const float*)nullptr, 0, 0.f, 0.f,
                        gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
     T2V_CHECK_LAUNCH();
@@ -892,7 +875,7 @@ extern "C" int t2v_group_norm_cs(const float* cs0, const float* cs1, const void*
     hipLaunchKernelGGL(gn_partial_cs_kernel, dim3(nblk, n_units), dim3(256), (size_t)2 * C * sizeof(float), s, cs0, c0, cs1, c1,
                        slabs_per_unit, slabs_per_blk, groups, ws);
     T2V_CHECK_LAUNCH();
-    T2V_GN_APPLY_LAUNCH(2, gn_geom(C).cpt, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
+    hipLaunchKernelGGL(gn_apply_kernel<2>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
                        ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)nullptr, (const float*)ws, nblk,
                        inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
     T2V_CHECK_LAUNCH();

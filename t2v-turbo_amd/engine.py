@@ -494,11 +494,15 @@ class _Engine:
     def _halo_width_ok(self, N):
         return N % 80 == 0
 
+    # conv modes the halo kernel takes: stride-1 3x3, and (round 5) the same over a nearest-x2 upsampled source (the Upsample convs of
+    # the UNet's decoder half and of the VAE decoder: openaimodel3d.py:98-112, ae_modules.py:141-156); T2V_HALO_UP2=0: stride-1 only
+    halo_modes = (nt.GEMM_CONV3X3, nt.GEMM_CONV3X3_UP2) if os.environ.get("T2V_HALO_UP2", "1") == "1" else (nt.GEMM_CONV3X3,)
+
     def _halo_pack(self, x, mod, w, own_w, frozen_pack, N, mode, out):
         """The slab-major weight pack (``native.pack_conv_slab``) if the launch meets the halo kernel's static conditions, else None.
-        Checked BEFORE anything is packed: stride-1 3x3, the module's own or a frozen caller-given pack, 64-channel parts (the
+        Checked BEFORE anything is packed: stride-1 3x3 (or nearest-x2 + 3x3), the module's own or a frozen caller-given pack, 64-channel parts (the
         kernel walks 32-channel sub-slabs of 64-aligned parts), bf16 in and out."""
-        if not (self.conv_halo and (own_w or frozen_pack) and mode == nt.GEMM_CONV3X3 and self._halo_width_ok(N)
+        if not (self.conv_halo and (own_w or frozen_pack) and mode in self.halo_modes and self._halo_width_ok(N)
                 and hasattr(self.ops, "conv_halo_supported") and out.dtype == self.adt and self.pk.wdtype == self.adt):
             return None
         if any(part.shape[1] % 64 for part in x.parts):

@@ -301,7 +301,7 @@ class TuneTable(dict):
     16x40x64, the 16-frame VAE, the training step); any other frame count or resolution (app.py:342-348 offers 16-48 frames) gave
     every launch to the library heuristic.  What a tile choice depends on is mostly (mode, N, K) — the operand widths, the epilogue
     — and whether M fills the chip: a missing key takes the tile of the tuned entry with the same (mode, N, K, batch) whose M is
-    nearest in ratio (within 0.4 .. 2.5x), and its K split only when M is within a third (else the library's own split rule).
+    nearest in ratio (tuned M between 0.3x and 2.5x of the asked one), and its K split only when M is within a third (else the library's own split rule).
     ``T2V_GEMM_TUNE_NEAREST=0``: exact keys only (rounds 1-4).  ``stats`` counts exact / nearest / miss lookups."""
 
     def __init__(self, table=(), nearest=None):
@@ -330,7 +330,7 @@ class TuneTable(dict):
             if cands and M > 0:
                 m_t, cfg, split = min(cands, key=lambda e: abs(math.log(e[0] / M)))
                 ratio = m_t / M
-                if 0.4 <= ratio <= 2.5:
+                if 0.3 <= ratio <= 2.5:
                     self.stats["nearest"] += 1
                     return (cfg, split if 0.75 <= ratio <= 1.34 else 0)
         self.stats["miss"] += 1
@@ -483,11 +483,12 @@ class HipOps:
     def conv_halo(self, a0, w, out, **kw):
         """3x3 / (3,1,1) conv on the halo-slab kernel (csrc/conv_halo.hip): same arguments as ``gemm`` except that ``w`` is the
         SLAB-MAJOR pack ``pack_conv_slab`` makes ([N][C/32][9][32], zero-padded to whole weight stages).  Ask ``conv_halo_supported`` first."""
-        self._call("t2v_conv_halo", C.byref(self._gemm_desc(a0, w, out, **kw)))
+        self._call("t2v_conv_halo", C.byref(self._gemm_desc(a0, w, out, tune_exact=True, **kw)))
 
     def conv_halo_supported(self, a0, w, out, **kw):
-        """0: not taken by the halo kernel (use ``gemm`` with the tap-major pack); 1: taken."""
-        rc = self.lib.t2v_conv_halo_supported(C.byref(self._gemm_desc(a0, w, out, **kw)))
+        """0: not taken by the halo kernel (use ``gemm`` with the tap-major pack); 1: taken.  (Only an EXACT tile-table entry counts
+        here — a tuned K split keeps a conv on t2v_gemm, as in rounds 1-4; a nearest-shape guess made for t2v_gemm must not.)"""
+        rc = self.lib.t2v_conv_halo_supported(C.byref(self._gemm_desc(a0, w, out, tune_exact=True, **kw)))
         if rc < 0:
             _check(rc, "t2v_conv_halo_supported")
         return rc
@@ -509,7 +510,7 @@ class HipOps:
     def _gemm_desc(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
                    rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
                    a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None, ln=None,
-                   rowstat=None, colstat=None, lnf=None, lora=None):
+                   rowstat=None, colstat=None, lnf=None, lora=None, tune_exact=False):
         d = GemmDesc()
         d.a0, d.c0, d.lda0 = _p(a0), a0.shape[1], _row_stride(a0)
         if a1 is not None:
@@ -542,7 +543,7 @@ class HipOps:
         tuned = None
         if tile_cfg == 0:
             key = (mode, M, N, taps * (d.c0 + d.c1), batch)
-            tuned = self.tune.lookup(key) if hasattr(self.tune, "lookup") else self.tune.get(key)
+            tuned = self.tune.lookup(key) if (hasattr(self.tune, "lookup") and not tune_exact) else self.tune.get(key)
         d.tile_cfg, d.split_k = tuned if tuned else (tile_cfg, split_k)
         if d.drop_thr:
             d.split_k = 1

@@ -150,15 +150,16 @@ class EmuOps:
                             rowvec=None, rowvec_div=0, residual=None, act=nt.ACT_NONE, alpha=1.0, batch=1, tile_cfg=0, split_k=0,
                             dropout=None, ln=None, rowstat=None, colstat=None, lnf=None, lora=None, **_):
         """Mirror of halo_prepare (csrc/conv_halo.hip): 0 not taken, 1 taken."""
-        if mode != nt.GEMM_CONV3X3 or batch > 1 or alpha != 1.0 or out.dtype not in (self.act_dtype, torch.bfloat16) or split_k > 1:
+        if mode not in (nt.GEMM_CONV3X3, nt.GEMM_CONV3X3_UP2) or batch > 1 or alpha != 1.0 or out.dtype not in (self.act_dtype, torch.bfloat16) or split_k > 1:
             return 0
+        ups = 1 if mode == nt.GEMM_CONV3X3_UP2 else 0
         if dropout is not None or ln is not None or rowstat is not None or lnf is not None or lora is not None or act not in (nt.ACT_NONE, nt.ACT_SILU):
             return 0
         c0, c1 = a0.shape[1], (0 if a1 is None else a1.shape[1])
-        if c0 % 64 or c1 % 64 or N % 16 or (rowvec is not None and (rowvec_div <= 0 or rowvec_div % (h * wd))):
+        if c0 % 64 or c1 % 64 or N % 16 or (rowvec is not None and (rowvec_div <= 0 or rowvec_div % ((h << ups) * (wd << ups)))):
             return 0
         assert w.shape[1] >= nt.conv_halo_pack_cols(c0 + c1), "slab-major pack narrower than conv_halo_pack_cols"
-        U, V = h, wd
+        U, V = h << ups, wd << ups
         pick = tile_cfg - 39 if 40 <= tile_cfg < 40 + len(self.HALO_TILES) else 0
         best, best_id = -1.0, 0
         for i, (S, fx, bn, _) in enumerate(self.HALO_TILES, start=1):

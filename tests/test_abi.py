@@ -61,7 +61,7 @@ def test_header_is_plain_c():
 
 
 def test_tune_table_nearest_shape_fallback():
-    """native.TuneTable: exact key first; else the entry with the same (mode, N, K, batch) and the nearest M within 0.4 .. 2.5x — its
+    """native.TuneTable: exact key first; else the entry with the same (mode, N, K, batch) and the nearest M within 0.3 .. 2.5x — its
     tile, and its K split only when M is within a third; anything else is a miss (library heuristic)."""
     from t2v_turbo_amd.native import TuneTable
     t = TuneTable({(0, 40960, 320, 320, 1): (23, 1), (0, 10240, 320, 320, 1): (11, 1), (1, 640, 1280, 11520, 1): (4, 4)}, nearest=True)

@@ -513,13 +513,15 @@ def test_gemm_layernorm_second_output(pair, M, K, res):
 
 
 # ---------------------------------------------------------------------------------- t2v_conv_halo (csrc/conv_halo.hip)
-def _halo_case(pair, *, n_img, h, w, c0, N, c1=0, cfg=0, rowvec=False, residual=False, act=0, colstat=False, seed=0, repeat=1):
+def _halo_case(pair, *, n_img, h, w, c0, N, c1=0, cfg=0, rowvec=False, residual=False, act=0, colstat=False, seed=0, repeat=1, ups=0):
     """3x3 conv on the halo-slab kernel (slab-major pack) against the emulated conv on the same bf16-rounded data; with a residual
-    both add it to the bf16-rounded product (the kernel's row pass; tests/emu_ops.py::conv_halo)."""
+    both add it to the bf16-rounded product (the kernel's row pass; tests/emu_ops.py::conv_halo).  ``ups`` = 1: nearest-x2 upsampled
+    source (T2V_GEMM_CONV3X3_UP2; (h, w) is the source grid)."""
     from t2v_turbo_amd import native as nt
-    M, K = n_img * h * w, 9 * (c0 + c1)
-    a0 = _rt(M, c0, seed=seed)
-    a1 = _rt(M, c1, seed=seed + 1) if c1 else None
+    m_src = n_img * h * w
+    M, K = m_src << (2 * ups), 9 * (c0 + c1)
+    a0 = _rt(m_src, c0, seed=seed)
+    a1 = _rt(m_src, c1, seed=seed + 1) if c1 else None
     wt = nt.pack_conv_slab(_rt(N, K, seed=seed + 2, scale=K ** -0.5))
     b, rv, res = _rt(N, seed=seed + 3), (_rt(n_img, N, seed=seed + 4) if rowvec else None), (_rt(M, N, seed=seed + 5) if residual else None)
     outs, stats = [], []
@@ -529,7 +531,8 @@ def _halo_case(pair, *, n_img, h, w, c0, N, c1=0, cfg=0, rowvec=False, residual=
         dev = "cuda" if side == 0 else "cpu"
         out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16 if side == 0 else torch.float32)
         cs = torch.full((M // 32, N, 2), float("nan"), device=dev) if colstat else None
-        kw = dict(M=M, N=N, a1=cvt(a1), mode=nt.GEMM_CONV3X3, n_img=n_img, h=h, wd=w, bias=f32(b), rowvec=f32(rv), rowvec_div=h * w if rowvec else 0,
+        kw = dict(M=M, N=N, a1=cvt(a1), mode=nt.GEMM_CONV3X3_UP2 if ups else nt.GEMM_CONV3X3, n_img=n_img, h=h, wd=w, bias=f32(b), rowvec=f32(rv),
+                  rowvec_div=((h * w) << (2 * ups)) if rowvec else 0,
                   residual=cvt(res), act=act, tile_cfg=cfg)
         if colstat:
             kw["colstat"] = cs
@@ -579,6 +582,15 @@ def test_conv_halo_64_channel_wave_tiles(pair):
     _halo_case(pair, n_img=2, h=40, w=64, c0=128, N=128, cfg=44, rowvec=True, residual=True, colstat=True, seed=31, repeat=3)
     _halo_case(pair, n_img=2, h=20, w=32, c0=256, c1=256, N=512, cfg=44, colstat=True, seed=32)
     _halo_case(pair, n_img=1, h=12, w=64, c0=64, N=192, cfg=44, rowvec=True, act=2, seed=33)
+
+
+def test_conv_halo_over_nearest_x2_upsampled_source(pair):
+    # the Upsample convs (interpolate x2 + 3x3 conv) of the UNet's decoder half at full size (one frame pair) and of the VAE decoder
+    _halo_case(pair, n_img=2, h=20, w=32, c0=640, N=640, colstat=True, seed=41, ups=1, repeat=2)       # -> 40x64
+    _halo_case(pair, n_img=2, h=10, w=16, c0=1280, N=1280, colstat=True, seed=42, ups=1)               # -> 20x32
+    _halo_case(pair, n_img=2, h=5, w=8, c0=1280, N=1280, colstat=True, seed=43, ups=1)                 # -> 10x16 (whole-frame tiles)
+    _halo_case(pair, n_img=1, h=80, w=128, c0=256, N=256, colstat=True, seed=44, ups=1)                # VAE: -> 160x256
+    _halo_case(pair, n_img=2, h=6, w=16, c0=64, c1=64, N=80, cfg=41, rowvec=True, residual=True, act=2, seed=45, ups=1)   # ragged rows
 
 
 def test_conv_halo_unet_level_shapes_repeatable(pair):

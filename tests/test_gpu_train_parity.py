@@ -226,7 +226,12 @@ def test_mid_width_student_on_device_vs_the_reference_lora_gradient_fixture():
           + ", ".join(f"({i}, {float(pe[i]):.3f}, {float(ref[i, 0]):.2e})" for i in worst), flush=True)
     assert e_out < OUT_TOL and e_dx < DX_TOL
     assert float(norm_err.max()) < 0.10, int(norm_err.argmax())
-    assert float(proj_err.max()) < 0.30 and float(proj_err.median()) < 0.06, int(proj_err.max(dim=1).values.argmax())
+    # what the device achieves (round 5, profiles/r05_midwidth_projection_error.txt): per-tensor worst projection error / norm — median
+    # 0.042, p90 0.082, p99 0.136, max 0.209 (a 1.3-norm tensor; the four next-worst 0.150-0.157).  A projection error is the
+    # tensor's relative gradient error (0.04-0.06 with bf16 activations: cosine 0.998-0.999) times a standard-normal sample (two
+    # random directions per tensor, tests/golden/make_golden_lora_grad.py::digests), so over ~2 300 samples the maximum sits at
+    # ~3.5 sigma = 0.2 by construction: the bounds sit just above what was measured, not at the 0.30 the test started with
+    assert float(pe.max()) < 0.25 and float(qs[2]) < 0.16 and float(qs[0]) < 0.06 and float(proj_err.median()) < 0.04, qs.tolist()
 
 
 # ------------------------------------------------------------------------------------------------------------- (iv)

@@ -37,18 +37,20 @@ def sim():
     return ops
 
 
-def _case(sim, *, n_img, h, w, c0, N, c1=0, cfg=0, bias=True, rowvec=False, residual=False, act=0, colstat=False, seed=0):
-    mode = nt.GEMM_CONV3X3
-    M = n_img * h * w
+def _case(sim, *, n_img, h, w, c0, N, c1=0, cfg=0, bias=True, rowvec=False, residual=False, act=0, colstat=False, seed=0, ups=0):
+    """``ups`` = 1: T2V_GEMM_CONV3X3_UP2 — (h, w) is the SOURCE grid, the output grid is (2h, 2w)."""
+    mode = nt.GEMM_CONV3X3_UP2 if ups else nt.GEMM_CONV3X3
+    m_src = n_img * h * w
+    M = m_src << (2 * ups)
     K = 9 * (c0 + c1)
-    a0 = _rt(M, c0, seed=seed).bfloat16()
-    a1 = _rt(M, c1, seed=seed + 1).bfloat16() if c1 else None
+    a0 = _rt(m_src, c0, seed=seed).bfloat16()
+    a1 = _rt(m_src, c1, seed=seed + 1).bfloat16() if c1 else None
     wt = _rt(N, K, seed=seed + 2, scale=K ** -0.5).bfloat16()
     ws = nt.pack_conv_slab(wt)
     assert ws.shape[1] == nt.conv_halo_pack_cols(c0 + c1) == sim.lib.t2v_conv_halo_pack_cols(c0 + c1)
     assert torch.equal(nt.unpack_conv_slab(ws, c0 + c1), wt)
     b = _rt(N, seed=seed + 3) if bias else None
-    div = h * w
+    div = (h * w) << (2 * ups)
     rv = _rt(M // div, N, seed=seed + 4) if rowvec else None
     res = _rt(M, N, seed=seed + 5).bfloat16() if residual else None
     kw = dict(M=M, N=N, a1=a1, mode=mode, n_img=n_img, h=h, wd=w, bias=b, rowvec=rv, rowvec_div=div if rowvec else 0,
@@ -114,6 +116,16 @@ def test_conv3x3_64_channel_wave_tiles(sim):
     _case(sim, n_img=1, h=10, w=32, c0=128, N=128, cfg=44, residual=True, colstat=True, seed=31)
     _case(sim, n_img=1, h=20, w=32, c0=64, c1=64, N=256, cfg=44, rowvec=True, colstat=True, seed=32)
     _case(sim, n_img=1, h=12, w=64, c0=64, N=192, cfg=44, rowvec=True, act=nt.ACT_SILU, seed=33)
+
+
+def test_conv3x3_over_nearest_x2_upsampled_source(sim):
+    # T2V_GEMM_CONV3X3_UP2 (Upsample: interpolate x2, then conv): the slab is gathered from the half-size source grid
+    # 10x16 -> 20x32 (two 10-row tiles per image), with the epilogue variants; 5x16 -> 10x32 on the 64-channel wave tiles; a source
+    # whose output grid is ragged against the tile rows (6x16 -> 12x32)
+    _case(sim, n_img=2, h=10, w=16, c0=64, N=160, cfg=40, rowvec=True, colstat=True, seed=41, ups=1)
+    _case(sim, n_img=1, h=5, w=16, c0=128, N=128, cfg=44, residual=True, colstat=True, seed=42, ups=1)
+    _case(sim, n_img=1, h=6, w=16, c0=64, c1=64, N=80, cfg=41, act=nt.ACT_SILU, seed=43, ups=1)
+    _case(sim, n_img=3, h=5, w=8, c0=64, N=160, cfg=42, colstat=True, seed=44, ups=1)      # 10x16 output: whole-frame tiles, four k-groups
 
 
 def test_heuristic_picks_a_tile_and_matches(sim):
