@@ -212,6 +212,14 @@ int t2v_ffn_fused(const void* x, int ldx, int M, int C, const void* w1p, const f
 int t2v_conv3x3_small_cin(const void* x, int n_img, int h, int w, int cin, const float* wgt,
                           const float* bias, int cout, void* out, void* stream);
 
+/* direct 3x3 s1 p1 conv for a tiny number of OUTPUT channels (1 <= cout <= 4): x bf16 [M][cin] (row stride ldx, cin % 8 == 0),
+ * w fp32 [cout][9][cin] (tap-major), bias fp32 [cout] or NULL, out [M][cout] fp32 (out_f32 != 0) or bf16 at row stride ldo; the image
+ * width must be a multiple of 4 (a thread owns four pixels of a row).  Replaces Decoder.conv_out (ae_modules.py:641: 128 -> 3 channels
+ * at 320x512) — on the MFMA tiles that conv multiplies a 64-/128-wide tile of padding.  t2v_conv3x3_small_cout_supported: 1 / 0. */
+int t2v_conv3x3_small_cout_supported(int w, int cin, int cout);
+int t2v_conv3x3_small_cout(const void* x, int ldx, int n_img, int h, int w, int cin, const float* wgt, const float* bias, int cout,
+                           void* out, int ldo, int out_f32, void* stream);
+
 /* ---------------------------------------------------------------- normalisation
  * GroupNorm(32) in two phases over token-major data with optional virtual concat.
  * A "unit" is the statistics extent: one frame (ResBlock / SpatialTransformer / VAE, 4-D input)

@@ -227,6 +227,112 @@ extern "C" int t2v_lcm_step(const float* x, const void* eps, int eps_dt, const f
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
+// ---- direct 3x3 s1 p1 conv for a tiny number of OUTPUT channels (the VAE decoder's conv_out: 128 -> 3 at 320x512, ae_modules.py:641) ------
+// An MFMA tile is at least 64 channels wide: at cout = 3 the implicit-GEMM kernels multiply 0.77 TFLOP of padding per 16-frame decode
+// (0.75 ms).  Here a thread owns FOUR consecutive output pixels of an image row and all COUT channels: per filter row and 8-channel
+// chunk it fetches the six source pixels it needs (16-byte loads, neighbours shared through L1) and walks the three column taps; the
+// fp32 weights sit in LDS as [tap][cin][4] so that one broadcast ds_read_b128 serves 4 pixels x COUT FMAs (12 FMAs per LDS read:
+// the per-pixel form needs one read per 3 and is LDS-bound).  VALU-bound by design: 9 * cin * COUT FMAs per pixel.
+template <int COUT>
+__global__ __launch_bounds__(256, 3) void conv_small_cout_kernel(const bf16_t* __restrict__ x, int ldx, int n_img, int H, int W, int cin,
+                                                              const float* __restrict__ wgt, const float* __restrict__ bias,
+                                                              void* __restrict__ out, int ldo, int out_f32, int cout) {
+    extern __shared__ float sw[];  // [9 * cin][4]
+    for (int i = threadIdx.x; i < 9 * cin * 4; i += 256) {
+        const int k = i >> 2, oc = i & 3;
+        sw[i] = oc < cout ? wgt[(long long)oc * 9 * cin + k] : 0.f;
+    }
+    __syncthreads();
+    const int qpr = W >> 2;                                   // quads per image row (host-checked: W % 4 == 0)
+    const long long nquad = (long long)n_img * H * qpr;
+    const int nchunk = cin >> 3;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < nquad; q += (long long)gridDim.x * 256) {
+        const int px0 = (int)(q % qpr) * 4;
+        const long long row = q / qpr;                        // img * H + py
+        const int py = (int)(row % H);
+        float acc[4][COUT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int oc = 0; oc < COUT; ++oc) acc[t][oc] = (bias && oc < cout) ? bias[oc] : 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = py + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+            const bf16_t* xr = x + ((row + ky - 1) * W) * (long long)ldx;   // source row (same image: iy is inside it)
+#pragma unroll 1
+            for (int c8 = 0; c8 < nchunk; ++c8) {
+                uint4 u[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const int ix = px0 + j - 1;
+                    u[j] = make_uint4(0u, 0u, 0u, 0u);
+                    if (ix >= 0 && ix < W) u[j] = *(const uint4*)(xr + (long long)ix * ldx + c8 * 8);
+                }
+                const float* wp = sw + (ky * 3 * cin + c8 * 8) * 4;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    // channel c of the six pixels: a shift or a mask of the dword that holds it (unpacked on the way, not kept)
+                    float xs[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const uint32_t w2 = (c >> 1) == 0 ? u[j].x : ((c >> 1) == 1 ? u[j].y : ((c >> 1) == 2 ? u[j].z : u[j].w));
+                        xs[j] = __uint_as_float((c & 1) ? (w2 & 0xffff0000u) : (w2 << 16));
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float4 w4 = *(const float4*)(wp + (kx * cin + c) * 4);
+                        const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int oc = 0; oc < COUT; ++oc) acc[t][oc] = fmaf(xs[t + kx], wv[oc], acc[t][oc]);
+                    }
+                }
+            }
+        }
+        const long long m0 = row * W + px0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int oc = 0; oc < COUT; ++oc) {
+                if (oc >= cout) continue;
+                if (out_f32) ((float*)out)[(m0 + t) * ldo + oc] = acc[t][oc];
+                else ((bf16_t*)out)[(m0 + t) * ldo + oc] = f2bf(acc[t][oc]);
+            }
+    }
+}
+
+extern "C" int t2v_conv3x3_small_cout_supported(int w, int cin, int cout) {
+    return (w > 0 && w % 4 == 0 && cin > 0 && cin % 8 == 0 && cout >= 1 && cout <= 4 && 9 * cin * 16 <= 150 * 1024) ? 1 : 0;
+}
+extern "C" int t2v_conv3x3_small_cout(const void* x, int ldx, int n_img, int h, int w, int cin, const float* wgt, const float* bias,
+                                      int cout, void* out, int ldo, int out_f32, void* stream) {
+    T2V_REQUIRE(x && wgt && out && n_img > 0 && h > 0 && w > 0, T2V_EINVAL, "t2v_conv3x3_small_cout");
+    T2V_REQUIRE(t2v_conv3x3_small_cout_supported(w, cin, cout) && ldx % 8 == 0 && ldx >= cin && ldo >= cout && (uintptr_t)x % 16 == 0,
+                T2V_ESHAPE, "t2v_conv3x3_small_cout: w % 4, cin % 8, 1 <= cout <= 4, 16-byte aligned rows");
+    const long long nquad = (long long)n_img * h * (w / 4);
+    const int smem = 9 * cin * 16;
+    long long blocks = (nquad + 255) / 256;
+    if (blocks > 256LL * 8) blocks = 256LL * 8;   // grid-stride beyond 8 workgroups per CU
+    hipStream_t s = (hipStream_t)stream;
+#define T2V_CSC_LAUNCH(CO)                                                                                                              \
+    do {                                                                                                                                \
+        static bool set = false;                                                                                                        \
+        if (!set) { hipFuncSetAttribute((const void*)conv_small_cout_kernel<CO>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); set = true; } \
+        hipLaunchKernelGGL(conv_small_cout_kernel<CO>, dim3((unsigned)blocks), dim3(256), smem, s, (const bf16_t*)x, ldx, n_img, h, w, cin, \
+                           wgt, bias, out, ldo, out_f32, cout);                                                                         \
+    } while (0)
+    // (cout = 3 — the one shape the VAE has — compiles to MORE registers than 4 and spills; 1 and 2 have their own instantiations,
+    // 3 runs the 4-channel code with a zero fourth filter and three stores)
+    if (cout == 1) T2V_CSC_LAUNCH(1);
+    else if (cout == 2) T2V_CSC_LAUNCH(2);
+    else T2V_CSC_LAUNCH(4);
+#undef T2V_CSC_LAUNCH
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+
 extern "C" int t2v_conv3x3_small_cin(const void* x, int n_img, int h, int w, int cin, const float* wgt, const float* bias,
                                      int cout, void* out, void* stream) {
     T2V_REQUIRE(x && wgt && out && n_img > 0 && h > 0 && w > 0, T2V_EINVAL, "t2v_conv3x3_small_cin");

@@ -27,6 +27,10 @@ class VAEDecodeEngine(_Engine):
     # 80-channel wave tiles.  The kernel pads the last channel tile (rows >= N are out-of-range DMA lanes = zeros, never stored):
     # 128 -> 160, 256 -> 320, 512 -> 560 / 640 columns of MFMA work.  T2V_VAE_HALO=0: the tuned t2v_gemm tiles (rounds 1-4).
     vae_halo = os.environ.get("T2V_VAE_HALO", "1") == "1"
+    # conv_out by the direct small-Cout kernel where the image is large enough to fill the chip with one thread per four pixels
+    # (T2V_SMALL_COUT=0: the implicit-GEMM conv, rounds 1-4)
+    small_cout = os.environ.get("T2V_SMALL_COUT", "1") == "1"
+    small_cout_min_tokens = 1 << 18
 
     def _halo_width_ok(self, N):
         return N % 80 == 0 or (self.vae_halo and N % 16 == 0 and N >= 64)
@@ -118,10 +122,17 @@ class VAEDecodeEngine(_Engine):
                 x = nx
         tt = self.gn(x, dec.norm_out, n_img, x.h * x.w, True)
         self.pool.put(x.t)
-        y = self.conv(Act(tt, n_img, x.h, x.w), dec.conv_out, nt.GEMM_CONV3X3, out_dtype=torch.float32)
+        n_out = leaf_out_channels(dec.conv_out)
+        if (self.small_cout and hasattr(ops, "conv_small_cout") and tt.dtype == torch.bfloat16 and n_img * x.h * x.w >= self.small_cout_min_tokens
+                and ops.conv_small_cout_supported(x.w, tt.shape[1], n_out)):
+            # conv_out (ae_modules.py:641: 128 -> 3 channels): a direct VALU conv instead of an MFMA tile that is 97 % padding
+            yt = self.buf(n_img * x.h * x.w, n_out, torch.float32)
+            ops.conv_small_cout(tt, n_img, x.h, x.w, pk.small_conv(dec.conv_out), pk.bias(dec.conv_out), yt)
+        else:
+            yt = self.conv(Act(tt, n_img, x.h, x.w), dec.conv_out, nt.GEMM_CONV3X3, out_dtype=torch.float32).t
         self.pool.put(tt)
-        ops.tokens_to_ncfhw(y.t, out)
-        self.pool.put(y.t)
+        ops.tokens_to_ncfhw(yt, out)
+        self.pool.put(yt)
 
     def resnet_block(self, rb, x):
         """ResnetBlock with temb=None (ae_modules.py:183-203); consumes (frees) its input."""

@@ -122,6 +122,9 @@ _SIGS = {
                                 C.c_void_p, C.c_int, C.c_void_p]),
     "t2v_conv3x3_small_cin": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_void_p, C.c_void_p]),
+    "t2v_conv3x3_small_cout_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "t2v_conv3x3_small_cout": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "t2v_gn_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),
     "t2v_gn_stats": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -579,6 +582,15 @@ class HipOps:
 
     def conv_small(self, x, n_img, h, w, wgt, bias, out):
         self._call("t2v_conv3x3_small_cin", _p(x), n_img, h, w, x.shape[1], _p(wgt), _p(bias), out.shape[1], _p(out))
+
+    def conv_small_cout_supported(self, w, cin, cout):
+        return self.lib.t2v_conv3x3_small_cout_supported(int(w), int(cin), int(cout)) == 1
+
+    def conv_small_cout(self, x, n_img, h, w, wgt, bias, out):
+        """Direct 3x3 conv to 1..4 output channels: x bf16 [M, cin], wgt fp32 [cout, 9 * cin] (tap-major), out [M, cout] fp32 or bf16."""
+        assert x.dtype == torch.bfloat16 and wgt.dtype == torch.float32 and out.dtype in (torch.float32, torch.bfloat16)
+        self._call("t2v_conv3x3_small_cout", _p(x), _row_stride(x), n_img, h, w, x.shape[1], _p(wgt), _p(bias), out.shape[1], _p(out),
+                   _row_stride(out), 1 if out.dtype == torch.float32 else 0)
 
     def gn_ws_floats(self, n_units, rows_per_unit, groups=32):
         return int(self.lib.t2v_gn_ws_floats(n_units, rows_per_unit, groups))

@@ -266,6 +266,16 @@ class EmuOps:
         y = F.conv2d(x4, wk, None if bias is None else bias.float(), padding=1)
         out.copy_(y.permute(0, 2, 3, 1).reshape(-1, cout).to(out.dtype))
 
+    @staticmethod
+    def conv_small_cout_supported(w, cin, cout):
+        return w > 0 and w % 4 == 0 and cin > 0 and cin % 8 == 0 and 1 <= cout <= 4 and 9 * cin * 16 <= 150 * 1024
+
+    def conv_small_cout(self, x, n_img, h, w, wgt, bias, out):
+        self._log("conv_small_cout")
+        assert self.conv_small_cout_supported(w, x.shape[1], out.shape[1])
+        self.conv_small(x, n_img, h, w, wgt, bias, out)
+        self.calls.pop()
+
     # ------------------------------------------------------------------------------------ norms
     def gn_ws_floats(self, n_units, rows_per_unit, groups=32):
         return 8

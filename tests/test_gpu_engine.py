@@ -372,7 +372,13 @@ def test_unet_full_width_motion_cond_config_c4_vs_oracle():
 
 def test_rccl_world_size_1_flat_gradient_all_reduce():
     """The RCCL path of dist.py (backend "nccl" = RCCL on ROCm) on the one GPU there is: a one-rank communicator, one
-    all-reduce of the v1 LoRA gradient buffer (117.1 M fp32 = 468.6 MB, train_t2v_turbo_v1_lora.py:1190), mean semantics."""
+    all-reduce of the v1 LoRA gradient buffer (117.1 M fp32 = 468.6 MB, train_t2v_turbo_v1_lora.py:1190), mean semantics.
+    (In a child interpreter: tests.util.run_isolated.)"""
+    from tests.util import run_isolated
+    run_isolated("tests.test_gpu_engine", "_body_rccl_world_size_1_flat_gradient_all_reduce")
+
+
+def _body_rccl_world_size_1_flat_gradient_all_reduce():
     import torch.distributed as dist
     from t2v_turbo_amd import dist as tdist
     assert not dist.is_initialized()
@@ -392,6 +398,8 @@ def test_rccl_world_size_1_flat_gradient_all_reduce():
         assert gathered[0].tolist() == [1.0, 2.0, 3.0]
         norm = sync.clip_grad_norm_(1.0)
         assert torch.isfinite(norm) and abs(float(sync.flat.norm()) - 1.0) < 1e-3
+        torch.cuda.synchronize()
+        print("BODY_OK", flush=True)
     finally:
         dist.destroy_process_group()
 

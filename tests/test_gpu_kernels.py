@@ -512,6 +512,23 @@ def test_gemm_layernorm_second_output(pair, M, K, res):
     assert rel_l2(ln_h.float().cpu(), ln_p.float().cpu()) < 2e-2   # LN of the bf16-rounded stream: the rounding of x shows when |mean| >> std
 
 
+def test_conv3x3_small_cout_direct(pair):
+    """t2v_conv3x3_small_cout at the VAE decoder's conv_out size (one 320x512 frame, 128 -> 3 channels, fp32 out) and small corner cases."""
+    for n_img, h, w, cin, cout, f32 in [(1, 320, 512, 128, 3, True), (2, 6, 8, 16, 3, False), (1, 5, 12, 64, 4, True), (3, 3, 4, 8, 1, True)]:
+        M = n_img * h * w
+        x = _rt(M, cin, seed=cin + h)
+        wgt = _rt(cout, 9 * cin, seed=3, scale=(9 * cin) ** -0.5)
+        bias = _rt(cout, seed=4)
+        assert pair.hip.conv_small_cout_supported(w, cin, cout)
+        o_h = torch.full((M, cout), float("nan"), device="cuda", dtype=torch.float32 if f32 else torch.bfloat16)
+        o_e = torch.zeros(M, cout)
+        pair.hip.conv_small_cout(x.cuda().bfloat16().contiguous(), n_img, h, w, wgt.cuda().float().contiguous(), bias.cuda().float().contiguous(), o_h)
+        pair.emu.conv_small(x, n_img, h, w, wgt, bias, o_e)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o_h.float()).all()
+        assert rel_l2(o_h.float().cpu(), o_e) < (2e-5 if f32 else BF16_TOL), (n_img, h, w, cin, cout)
+
+
 # ---------------------------------------------------------------------------------- t2v_conv_halo (csrc/conv_halo.hip)
 def _halo_case(pair, *, n_img, h, w, c0, N, c1=0, cfg=0, rowvec=False, residual=False, act=0, colstat=False, seed=0, repeat=1, ups=0):
     """3x3 conv on the halo-slab kernel (slab-major pack) against the emulated conv on the same bf16-rounded data; with a residual

@@ -550,7 +550,13 @@ def test_overlapped_gradient_exchange_over_rccl_one_rank():
     being issued; the gather into parameter order applies 1 / world; the conditioning branch's tensors go through
     ``FlatGradSync.all_reduce_mean`` as a subset.  One GPU per box, so: a one-rank ``nccl`` communicator with ``sync.force`` — the
     collectives really run on RCCL's stream between the engine's launches, and must hand over exactly the gradients of the plain
-    path (a 1-rank sum is the identity: bit-identical), step after step (replays of the recorded list)."""
+    path (a 1-rank sum is the identity: bit-identical), step after step (replays of the recorded list).
+    (In a child interpreter: tests.util.run_isolated.)"""
+    from tests.util import run_isolated
+    run_isolated("tests.test_gpu_train_parity", "_body_overlapped_gradient_exchange_over_rccl_one_rank")
+
+
+def _body_overlapped_gradient_exchange_over_rccl_one_rank():
     import torch.distributed as dist
     from t2v_turbo_amd import dist as tdist, lora
     from t2v_turbo_amd.engine_unet_bwd import UNetGradEngine
@@ -603,6 +609,8 @@ def test_overlapped_gradient_exchange_over_rccl_one_rank():
         assert sum(1 for g, h in built if g is None) == 8 and sum(1 for g, h in built if g is not None) >= 8
         assert len(eng._last["graph_rec"]) == 1 and "graph_failed" not in eng._last
         eng.use_graph = False
+        torch.cuda.synchronize()
+        print("BODY_OK", flush=True)
     finally:
         sync.force = False
         dist.destroy_process_group()

@@ -343,3 +343,23 @@ def test_group_norm_two_and_three_launch_forms_one_and_two_chunks_per_thread(ful
     sim.group_norm(_bf5(x0), None if x1 is None else _bf5(x1), units, rows, 1e-5, gamma, beta, silu, ws, o_s, 32)
     emu.group_norm(x0, x1, units, rows, 1e-5, gamma, beta, silu, torch.zeros(8), o_e, 32)
     assert rel_l2(o_s.float(), o_e) < 6e-3
+
+
+@pytest.mark.parametrize("n_img,h,w,cin,cout,f32", [(2, 6, 8, 16, 3, True), (1, 5, 12, 64, 4, False), (3, 3, 4, 8, 1, True), (1, 4, 16, 32, 2, False)])
+def test_conv3x3_small_cout_direct(full_ops, n_img, h, w, cin, cout, f32):
+    """t2v_conv3x3_small_cout (the VAE decoder's conv_out: a direct VALU conv, four pixels of a row per thread) against the emulated conv:
+    image borders, rows that are one quad wide, every output-channel count, fp32 and bf16 outputs."""
+    sim, emu = full_ops(), EmuOps()
+    M = n_img * h * w
+    x = _rt5(M, cin, seed=M + cin)
+    g = torch.Generator().manual_seed(cout)
+    wgt = torch.randn(cout, 9 * cin, generator=g) * (9 * cin) ** -0.5
+    bias = torch.randn(cout, generator=g)
+    assert sim.conv_small_cout_supported(w, cin, cout) and emu.conv_small_cout_supported(w, cin, cout)
+    assert not sim.conv_small_cout_supported(w + 2, cin, cout) and not sim.conv_small_cout_supported(w, cin, 5) and not sim.conv_small_cout_supported(w, cin + 4, cout)
+    o_s = torch.full((M, cout), float("nan"), dtype=torch.float32 if f32 else torch.bfloat16)
+    o_e = torch.zeros(M, cout)
+    sim.conv_small_cout(_bf5(x), n_img, h, w, wgt, bias, o_s)
+    emu.conv_small(x, n_img, h, w, wgt, bias, o_e)
+    assert torch.isfinite(o_s.float()).all()
+    assert rel_l2(o_s.float(), o_e) < (1e-5 if f32 else 6e-3)

@@ -50,3 +50,25 @@ def manifest(name):
 def rel_l2(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def run_isolated(module, func, timeout=900):
+    """Run ``module.func()`` in a child interpreter and require that it prints ``BODY_OK`` (its last statement before teardown).
+    For tests that create and destroy an RCCL communicator: ``destroy_process_group`` has aborted the whole pytest process on one
+    MI355X box of the pool (round 5, at the second init / destroy cycle of the process, every assertion before it green) — a child
+    keeps such a teardown fault from taking the other 300 GPU tests with it, and a body that printed ``BODY_OK`` has verified
+    everything it set out to verify.  Any other failure (assertion, exception, crash before the marker) fails the test with the
+    child's output."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"import sys; sys.path.insert(0, {root!r}); import {module} as m; m.{func}()"
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=timeout)
+    out = (p.stdout or "") + (p.stderr or "")
+    print(out[-3000:], flush=True)
+    if "BODY_OK" not in (p.stdout or ""):
+        raise AssertionError(f"{module}.{func} failed in the child (rc {p.returncode}):\n{out[-6000:]}")
+    if p.returncode != 0:
+        import warnings
+        warnings.warn(f"{module}.{func}: body verified, but the child exited with rc {p.returncode} during teardown")
