@@ -27,9 +27,12 @@ class VAEDecodeEngine(_Engine):
     # 80-channel wave tiles.  The kernel pads the last channel tile (rows >= N are out-of-range DMA lanes = zeros, never stored):
     # 128 -> 160, 256 -> 320, 512 -> 560 / 640 columns of MFMA work.  T2V_VAE_HALO=0: the tuned t2v_gemm tiles (rounds 1-4).
     vae_halo = os.environ.get("T2V_VAE_HALO", "1") == "1"
-    # conv_out by the direct small-Cout kernel where the image is large enough to fill the chip with one thread per four pixels
-    # (T2V_SMALL_COUT=0: the implicit-GEMM conv, rounds 1-4)
-    small_cout = os.environ.get("T2V_SMALL_COUT", "1") == "1"
+    # conv_out (128 -> 3 channels) by the direct small-Cout kernel (csrc/elementwise.hip, t2v_conv3x3_small_cout) instead of an MFMA tile
+    # that is 97 % padding.  MEASURED SLOWER on MI355X (round 5, same box, interleaved: decode 27.98 / 28.23 ms with it, 25.47 / 25.48 ms
+    # without, profiles/r05_vae_decode_ab.jsonl): ~3.3 ms against 0.75 ms — the matrix cores multiply the padding at 1 PFLOP/s, while the
+    # VALU form is bound by its own load -> 460-instruction chunk -> load chain at three waves per SIMD.  Opt-in (T2V_SMALL_COUT=1), kept
+    # as a tested negative result.
+    small_cout = os.environ.get("T2V_SMALL_COUT", "0") == "1"
     small_cout_min_tokens = 1 << 18
 
     def _halo_width_ok(self, N):
