@@ -156,7 +156,7 @@ def gemm_traffic():
     tools/pmc_traffic.py).  Counters cannot be read from inside the timed process, so this is the profile's number,
     labelled as such; null when the profile is absent."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"):  # the newest committed PMC passes
+    for name in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"):  # the newest committed PMC passes
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 g = json.load(f)["gemm"]
