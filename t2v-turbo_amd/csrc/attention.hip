@@ -22,6 +22,20 @@
 #define ATT_ABL(bit) false
 #endif
 
+// A/B switches of the spatial kernel's issue order (tools builds; the product build defines none of them):
+//   -DT2V_ATTN_NOFENCE   drop the three sched_barrier fences of the KV loop (the compiler may interleave fragment reads, softmax and MFMAs)
+//   -DT2V_ATTN_SETPRIO   s_setprio 1 around the two MFMA clusters (QK^T, PV), 0 for the softmax in between (cdna guide T5)
+#ifdef T2V_ATTN_NOFENCE
+#define T2V_ATTN_FENCE() do {} while (0)
+#else
+#define T2V_ATTN_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifdef T2V_ATTN_SETPRIO
+#define T2V_ATTN_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define T2V_ATTN_PRIO(n) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int KT = 64;          // keys per tile
@@ -116,7 +130,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WP
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
                 kf[h2][kk] = *(const bf16x8_t*)(sk + (h2 * 32 + l31) * 128 + (((kk * 2 + hi) ^ swz) << 4));
-        __builtin_amdgcn_sched_barrier(0);
+        T2V_ATTN_FENCE();
+        T2V_ATTN_PRIO(1);
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
 #pragma unroll
@@ -125,7 +140,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WP
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) s[h2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[h2][kk], qf[kk], s[h2], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_barrier(0);
+        T2V_ATTN_PRIO(0);
+        T2V_ATTN_FENCE();
         // V^T fragments for the PV product: issued now, they land under the softmax VALU work.  K-step ks = 2*h2 + st
         // contracts keys h2*32 + st*16 + 8*hi + 0..7 = chunk 4*h2 + 2*st + hi of the V^T row.
         bf16x8_t vfr[4][2];
@@ -134,7 +150,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WP
 #pragma unroll
             for (int db = 0; db < 2; ++db)
                 vfr[ks][db] = *(const bf16x8_t*)(sv + (db * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
-        __builtin_amdgcn_sched_barrier(0);
+        T2V_ATTN_FENCE();
         // ---- online softmax (this lane: one query, 32 of the 64 keys; partner lane^32 the rest) ---
         // scores stay raw; max is taken on them and exp2(fma(s, c, -c*max)) folds scale*log2(e): 3 VALU
         // ops per element (max, fma, exp2) instead of 5
@@ -180,6 +196,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WP
             l_run += lsum;
         }
         // ---- O^T += V^T P^T: the score registers already come out in contraction order ----------------------
+        T2V_ATTN_PRIO(1);
         if (!ATT_ABL(2))
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -193,6 +210,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WP
 #pragma unroll
             for (int db = 0; db < 2; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks][db], pb, o[db], 0, 0, 0);
         }
+        T2V_ATTN_PRIO(0);
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
