@@ -13,6 +13,7 @@
 //   (clip, pixel, head), rows fetched with the frame stride straight from the token-major
 //   buffers (no rearrange copies); tiny FLOPs, bandwidth bound.
 #include "common.h"
+#include <cstdlib>
 
 // ablation bits (tools/attn_one.py --debug) only exist in a -DT2V_ATTN_ABLATE build: runtime branches inside the
 // KV loop split its basic block (inexact s_waitcnt, no MFMA / VALU interleave)
@@ -55,7 +56,14 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base)
 #ifndef T2V_ATTN_WPE
 #define T2V_ATTN_WPE 3  // waves per SIMD the register budget is sized for (tools: -DT2V_ATTN_WPE=2 / 4 variants for A/B runs)
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WPE, T2V_ATTN_WPE))) void attn_spatial_kernel(const bf16_t* __restrict__ q, int ldq,
+// NW = waves per workgroup (4 or 8), 32 queries each: every workgroup streams ALL of its (image, head)'s K and V^T through LDS, so the
+// L2 -> LDS fill is seq_kv * 256 bytes per NW * 32 queries — 1.05 GB per launch at 2 560 tokens x 5 heads x 16 images with four waves
+// (5 TB/s in a 200 us launch), half of it with eight.  MEASURED (round 5, profiles/r05_attn_issue_order_variants.txt): halving that
+// stream changes nothing (224-228 vs 224 us at four waves per SIMD; 240-244 vs 211-220 us at three, where only one eight-wave workgroup
+// fits a CU) — the launch is not fill-bound; with r05_attn_pmc.csv (VALU active 45 %, matrix pipe 26 %, 11.7 VALU per MFMA) it runs at
+// the sum of the softmax's VALU work and the MFMA work of the same wave.  The product launches NW = 4; T2V_ATTN_NW=8 is a tools switch.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WPE, T2V_ATTN_WPE))) void attn_spatial_kernel(const bf16_t* __restrict__ q, int ldq,
                                                            const bf16_t* __restrict__ k, int ldk,
                                                            const bf16_t* __restrict__ vt, int ld_vt, long long vt_img_stride,
                                                            bf16_t* __restrict__ out, int ldo, int seq_q, int seq_kv,
@@ -65,7 +73,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WP
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, l31 = lane & 31;
     const int head = blockIdx.y, img = blockIdx.z, img_kv = img / kv_div;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (NW * 32) + wave * 32;
     const int qi = q0 + l31;
     const bool q_ok = qi < seq_q;
 
@@ -83,11 +91,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WP
     const bf16_t* vbase = vt + (long long)img_kv * vt_img_stride + (long long)head * 64 * ld_vt;
     const int ntile = (seq_kv + KT - 1) / KT;
 
-    // DMA lane roles: wave-instruction i (= wave + 4*j, j = 0,1) covers tile rows [8i, 8i+8)
-    int drow[2], dchunk[2];
+    // DMA lane roles: wave-instruction i (= wave + NW*j, j < 8 / NW) covers tile rows [8i, 8i+8)
+    constexpr int DJ = 8 / NW;
+    int drow[DJ], dchunk[DJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        drow[j] = (wave + 4 * j) * 8 + (lane >> 3);
+    for (int j = 0; j < DJ; ++j) {
+        drow[j] = (wave + NW * j) * 8 + (lane >> 3);
         dchunk[j] = ((lane & 7) ^ ((drow[j] >> 1) & 7)) * 8;
     }
     auto stage = [&](int t, int buf) {
@@ -95,14 +104,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WP
         char* sv = sk + K_TILE_BYTES;
         const int key0 = t * KT;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < DJ; ++j) {
             // LDS row r of the K tile holds key perm(r) = r with bits 2 and 3 swapped: the 8 score registers a lane
             // feeds into one PV K-step (rows {4hi + 0..3, 8 + 4hi + 0..3} of a 16-row group) are then 8 CONSECUTIVE
             // keys, i.e. one aligned 16-byte chunk of the V^T row (a single ds_read_b128 per fragment)
             const int key = key0 + ((drow[j] & ~12) | ((drow[j] & 4) << 1) | ((drow[j] & 8) >> 1));
             const bf16_t* ksrc = key < seq_kv ? kbase + (long long)key * ldk + dchunk[j] : zero;
-            dma16(ksrc, sk + (wave + 4 * j) * 1024);
-            dma16(vbase + (long long)drow[j] * ld_vt + key0 + dchunk[j], sv + (wave + 4 * j) * 1024);
+            dma16(ksrc, sk + (wave + NW * j) * 1024);
+            dma16(vbase + (long long)drow[j] * ld_vt + key0 + dchunk[j], sv + (wave + NW * j) * 1024);
         }
     };
 
@@ -124,6 +133,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WP
         // ---- S^T = K Q^T: all 8 K fragments are read up front (one batch of ds_read_b128, counted waits) so the
         // MFMAs run back to back instead of read -> wait -> MFMA eight times -------------------------------
         f32x16_t s[2];
+#ifdef T2V_ATTN_LOWREG   // K fragments of one 32-key half at a time (the second half's reads go out before the first half's MFMAs)
+        {
+            bf16x8_t kf0[4], kf1[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) kf0[kk] = *(const bf16x8_t*)(sk + l31 * 128 + (((kk * 2 + hi) ^ swz) << 4));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[0][r] = 0.f; s[1][r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) kf1[kk] = *(const bf16x8_t*)(sk + (32 + l31) * 128 + (((kk * 2 + hi) ^ swz) << 4));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[kk], qf[kk], s[0], 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[kk], qf[kk], s[1], 0, 0, 0);
+        }
+        T2V_ATTN_FENCE();
+#else
         bf16x8_t kf[2][4];
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
@@ -142,11 +167,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WP
         }
         T2V_ATTN_PRIO(0);
         T2V_ATTN_FENCE();
+#endif
         // V^T fragments for the PV product: issued now, they land under the softmax VALU work.  K-step ks = 2*h2 + st
         // contracts keys h2*32 + st*16 + 8*hi + 0..7 = chunk 4*h2 + 2*st + hi of the V^T row.
         bf16x8_t vfr[4][2];
+#ifdef T2V_ATTN_LOWREG   // (-DT2V_ATTN_LOWREG: only K-steps 0, 1 before the softmax; 2, 3 follow it, under the first four PV MFMAs — 16 registers fewer live across the softmax, for a four-waves-per-SIMD build)
+        constexpr int VF_EARLY = 2;
+#else
+        constexpr int VF_EARLY = 4;
+#endif
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < VF_EARLY; ++ks)
 #pragma unroll
             for (int db = 0; db < 2; ++db)
                 vfr[ks][db] = *(const bf16x8_t*)(sv + (db * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
@@ -196,6 +227,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T2V_ATTN_WP
             l_run += lsum;
         }
         // ---- O^T += V^T P^T: the score registers already come out in contraction order ----------------------
+#pragma unroll
+        for (int ks = VF_EARLY; ks < 4; ++ks)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                vfr[ks][db] = *(const bf16x8_t*)(sv + (db * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
         T2V_ATTN_PRIO(1);
         if (!ATT_ABL(2))
 #pragma unroll
@@ -391,10 +427,20 @@ extern "C" int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, 
     T2V_REQUIRE(heads <= 65535 && n_img <= 65535, T2V_ESHAPE, "t2v_attn_spatial: grid");
     if (vt_img_stride <= 0) vt_img_stride = (long long)heads * 64 * ld_vt;
     T2V_REQUIRE(vt_img_stride % 8 == 0, T2V_ESHAPE, "t2v_attn_spatial: vt_img_stride");
-    dim3 grid((seq_q + 127) / 128, heads, n_img);
-    hipLaunchKernelGGL(attn_spatial_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
-                       (const bf16_t*)k, ldk, (const bf16_t*)vt, ld_vt, vt_img_stride, (bf16_t*)out, ldo, seq_q, seq_kv, heads,
-                       kv_div, scale, (const bf16_t*)t2v_zero_page(), g_attn_debug);
+    // (T2V_ATTN_NW=8: 256 queries per workgroup — half the key / value stream, measured no faster: see the kernel's header)
+    static const int force_nw = getenv("T2V_ATTN_NW") ? atoi(getenv("T2V_ATTN_NW")) : 0;
+    const bool eight = force_nw == 8;
+    if (eight) {
+        dim3 grid((seq_q + 255) / 256, heads, n_img);
+        hipLaunchKernelGGL(attn_spatial_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
+                           (const bf16_t*)k, ldk, (const bf16_t*)vt, ld_vt, vt_img_stride, (bf16_t*)out, ldo, seq_q, seq_kv, heads,
+                           kv_div, scale, (const bf16_t*)t2v_zero_page(), g_attn_debug);
+    } else {
+        dim3 grid((seq_q + 127) / 128, heads, n_img);
+        hipLaunchKernelGGL(attn_spatial_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
+                           (const bf16_t*)k, ldk, (const bf16_t*)vt, ld_vt, vt_img_stride, (bf16_t*)out, ldo, seq_q, seq_kv, heads,
+                           kv_div, scale, (const bf16_t*)t2v_zero_page(), g_attn_debug);
+    }
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
