@@ -321,6 +321,10 @@ int t2v_lcm_step(const float* x, const void* eps, int eps_dt, const float* noise
  * compiles them out and these calls just store the value). */
 int t2v_gemm_debug(int bits);
 int t2v_attn_debug(int bits);
+/* which form of the spatial forward t2v_attn_spatial launches (tools / tests; the product default is 0 and the others are measured no
+ * faster): 0 = 4 waves x 32 queries per workgroup, 8 = 8 waves x 32, 64 = 4 waves x 64 queries (two query sets per wave, phases offset)
+ * on launches with >= 512 queries and keys, 65 = that form always.  Same arithmetic per query in every form: bit-identical outputs. */
+int t2v_attn_spatial_form(int form);
 /* t2v_group_norm has a ONE-launch form (registers hold the tensor, per-unit inter-workgroup barrier) for tensors that fit:
  * t2v_gn_coop_enable(1) / environment T2V_GN_COOP=1 selects it (default off: measured slower than the three-launch form on
  * MI355X for cache-resident tensors); t2v_gn_coop_error() returns 1 if a

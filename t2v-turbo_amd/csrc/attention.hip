@@ -265,6 +265,223 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(T2V_ATT
 }
 
 // ------------------------------------------------------------------------------------------------
+// attn_spatial_q64_kernel (round 5): the same arithmetic with SIXTY-FOUR queries per wave — two 32-query sets A and B that share every K / V^T
+// fragment read — and the two sets' phases offset by one in program order, so that one set's softmax VALU work is issued in the gaps of the
+// other set's MFMAs INSIDE one wave:
+//     QK_A | QK_B + softmax_A | PV_A + softmax_B | PV_B
+// Why: the counters of the 32-query kernel (profiles/r05_attn_pmc.csv) show the launch running at the SUM of a wave's softmax VALU time (45 % of
+// the SIMD cycles) and its MFMA time (26 %) at any occupancy — at head dimension 64 a 64-key tile is 16 MFMAs against ~190 VALU issue slots, and a
+// wave issues in order: with one query set per wave nothing of its own softmax can sit under its own MFMAs.  Per query the operations and their
+// order are exactly those of attn_spatial_kernel (bit-identical results).  The rescale of the running output (taken only when a running max
+// moved) and the masking of the last tile's padding keys are scalar branches BETWEEN the interleaved regions.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_spatial_q64_kernel(
+    const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk, const bf16_t* __restrict__ vt, int ld_vt,
+    long long vt_img_stride, bf16_t* __restrict__ out, int ldo, int seq_q, int seq_kv, int heads, int kv_div, float scale, const bf16_t* zero) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * AT_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi = lane >> 5, l31 = lane & 31;
+    const int head = blockIdx.y, img = blockIdx.z, img_kv = img / kv_div;
+    const int q0 = blockIdx.x * 256 + wave * 64;
+    int qi[2];
+    bool q_ok[2];
+    bf16x8_t qf[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        qi[a] = q0 + a * 32 + l31;
+        q_ok[a] = qi[a] < seq_q;
+        const bf16_t* qp = q + ((long long)img * seq_q + (q_ok[a] ? qi[a] : 0)) * ldq + head * 64 + hi * 8;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            uint4 u = q_ok[a] ? *(const uint4*)(qp + kk * 16) : make_uint4(0, 0, 0, 0);
+            qf[a][kk] = *(bf16x8_t*)&u;
+        }
+    }
+    const bf16_t* kbase = k + (long long)img_kv * seq_kv * ldk + head * 64;
+    const bf16_t* vbase = vt + (long long)img_kv * vt_img_stride + (long long)head * 64 * ld_vt;
+    const int ntile = (seq_kv + KT - 1) / KT;
+    int drow[2], dchunk[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        drow[j] = (wave + 4 * j) * 8 + (lane >> 3);
+        dchunk[j] = ((lane & 7) ^ ((drow[j] >> 1) & 7)) * 8;
+    }
+    auto stage = [&](int t, int buf) {   // (as in attn_spatial_kernel: K rows with bits 2 / 3 of the key index swapped, V^T rows as they lie)
+        char* sk = smem + buf * AT_STAGE;
+        char* sv = sk + K_TILE_BYTES;
+        const int key0 = t * KT;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int key = key0 + ((drow[j] & ~12) | ((drow[j] & 4) << 1) | ((drow[j] & 8) >> 1));
+            const bf16_t* ksrc = key < seq_kv ? kbase + (long long)key * ldk + dchunk[j] : zero;
+            dma16(ksrc, sk + (wave + 4 * j) * 1024);
+            dma16(vbase + (long long)drow[j] * ld_vt + key0 + dchunk[j], sv + (wave + 4 * j) * 1024);
+        }
+    };
+    f32x16_t o[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[a][0][r] = 0.f; o[a][1][r] = 0.f; }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const int swz = (lane >> 1) & 7;
+    const float c2 = scale * 1.4426950408889634f;
+
+    // one query set's scores -> probabilities (bf16, PV B-operand order) + the tile's contribution to its running sum; returns whether any
+    // lane's running max moved.  No control flow: the caller interleaves this with the other set's MFMAs.
+    auto softmax_set = [&](f32x16_t (&sc)[2], float m_old, float& m_new, float& lsum, bf16x8_t (&pb)[4]) {
+        float mloc = -INFINITY;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sc[h2][r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        m_new = fmaxf(m_old, mloc);
+        const float mc = m_new * c2;
+        lsum = 0.f;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sc[h2][r], c2, -mc));
+                sc[h2][r] = p;
+                lsum += p;
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int h2 = ks >> 1, st = ks & 1;
+            uint4 pu;
+            pu.x = pack2bf(sc[h2][st * 8 + 0], sc[h2][st * 8 + 1]);
+            pu.y = pack2bf(sc[h2][st * 8 + 2], sc[h2][st * 8 + 3]);
+            pu.z = pack2bf(sc[h2][st * 8 + 4], sc[h2][st * 8 + 5]);
+            pu.w = pack2bf(sc[h2][st * 8 + 6], sc[h2][st * 8 + 7]);
+            pb[ks] = *(bf16x8_t*)&pu;
+        }
+    };
+    auto mask_tail = [&](f32x16_t (&sc)[2], int key_base) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = sc[h2][r];
+                if (key_base + h2 * 32 + (r >> 3) * 16 + (r & 7) >= seq_kv) v = -INFINITY;
+                asm volatile("" : "+v"(v));
+                sc[h2][r] = v;
+            }
+    };
+    auto rescale = [&](int a, float m_new) {   // (wave-uniform branch at the call site)
+        const float alpha = __builtin_amdgcn_exp2f((m_run[a] - m_new) * c2);
+        l_run[a] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[a][0][r] *= alpha; o[a][1][r] *= alpha; }
+        m_run[a] = m_new;
+    };
+    // MFMA / VALU interleave of one overlapped region: 8 MFMAs, the other set's softmax spread behind them
+    auto interleave_hint = [&]() {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);
+        }
+    };
+
+    stage(0, 0);
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < ntile) stage(t + 1, buf ^ 1);
+        const char* sk = smem + buf * AT_STAGE;
+        const char* sv = sk + K_TILE_BYTES;
+        const int key_base = t * KT + 8 * hi;
+        const bool tail = (t + 1) * KT > seq_kv;
+        f32x16_t sA[2], sB[2];
+        // (the K fragments are read once per SET, right where they are multiplied: keeping one copy alive across both sets' QK phases
+        // costs 32 registers at the kernel's register peak — and LDS reads are not what this kernel waits for)
+        auto kfrag = [&](int h2, int kk) { return *(const bf16x8_t*)(sk + (h2 * 32 + l31) * 128 + (((kk * 2 + hi) ^ swz) << 4)); };
+        // ---- phase 1: QK_A ------------------------------------------------------------------------------------------------------
+        {
+            bf16x8_t kf[2][4];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) kf[h2][kk] = kfrag(h2, kk);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sA[h2][r] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) sA[h2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[h2][kk], qf[0][kk], sA[h2], 0, 0, 0);
+            }
+        }
+        if (tail) mask_tail(sA, key_base);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 2: QK_B under softmax_A ------------------------------------------------------------------------------------------
+        float mA, lsA, mB, lsB;
+        bf16x8_t pA[4], pB[4];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sB[h2][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) sB[h2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(h2, kk), qf[1][kk], sB[h2], 0, 0, 0);
+        }
+        softmax_set(sA, m_run[0], mA, lsA, pA);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {   // fragment read, its MFMA, a slice of the other set's softmax
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tail) mask_tail(sB, key_base);
+        if (__any(mA > m_run[0])) rescale(0, mA);
+        l_run[0] += lsA;
+        // V^T fragments (shared by both sets)
+        bf16x8_t vfr[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                vfr[ks][db] = *(const bf16x8_t*)(sv + (db * 32 + l31) * 128 + (((ks * 2 + hi) ^ swz) << 4));
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 3: PV_A under softmax_B ------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks][db], pA[ks], o[0][db], 0, 0, 0);
+        softmax_set(sB, m_run[1], mB, lsB, pB);
+        interleave_hint();
+        __builtin_amdgcn_sched_barrier(0);
+        if (__any(mB > m_run[1])) rescale(1, mB);
+        l_run[1] += lsB;
+        // ---- phase 4: PV_B --------------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[ks][db], pB[ks], o[1][db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const float l_tot = l_run[a] + __shfl_xor(l_run[a], 32, 64);
+        const float inv = 1.f / l_tot;
+        if (q_ok[a]) {
+            bf16_t* op = out + ((long long)img * seq_q + qi[a]) * ldo + head * 64 + 4 * hi;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    uint2 w;
+                    w.x = pack2bf(o[a][db][g * 4 + 0] * inv, o[a][db][g * 4 + 1] * inv);
+                    w.y = pack2bf(o[a][db][g * 4 + 2] * inv, o[a][db][g * 4 + 3] * inv);
+                    *(uint2*)(op + db * 32 + g * 8) = w;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Temporal attention: the sequence is the F frames of one pixel.  One wave per (clip, pixel, head), matrix cores for
 // both products (the VALU form of this kernel was instruction-bound at a third of the HBM rate):
 //   S^T = K Q^T   v_mfma_f32_16x16x32_bf16, A = K rows (key j = lane&15), B = Q rows (query i = lane&15); every lane
@@ -416,6 +633,11 @@ __global__ __launch_bounds__(256) void attn_temporal_probs_kernel(const bf16_t* 
 
 static int g_attn_debug = 0;
 extern "C" int t2v_attn_debug(int bits) { g_attn_debug = bits; return T2V_OK; }
+// Which form of the spatial forward t2v_attn_spatial launches: 0 = the product kernel (4 waves x 32 queries), 8 = eight waves per workgroup,
+// 64 = 64 queries per wave on launches with >= 512 queries and keys, 65 = 64 queries per wave always.  The last three are MEASURED NO FASTER
+// (profiles/r05_attn_issue_order_variants.txt) and exist for tools and tests; -1 (initial) = from T2V_ATTN_NW / T2V_ATTN_Q64 in the environment.
+static int g_attn_form = -1;
+extern "C" int t2v_attn_spatial_form(int form) { g_attn_form = form; return T2V_OK; }
 
 extern "C" int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, const void* vt, int ld_vt,
                                 long long vt_img_stride, void* out, int ldo, int n_img, int seq_q, int seq_kv, int heads,
@@ -427,10 +649,17 @@ extern "C" int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, 
     T2V_REQUIRE(heads <= 65535 && n_img <= 65535, T2V_ESHAPE, "t2v_attn_spatial: grid");
     if (vt_img_stride <= 0) vt_img_stride = (long long)heads * 64 * ld_vt;
     T2V_REQUIRE(vt_img_stride % 8 == 0, T2V_ESHAPE, "t2v_attn_spatial: vt_img_stride");
-    // (T2V_ATTN_NW=8: 256 queries per workgroup — half the key / value stream, measured no faster: see the kernel's header)
-    static const int force_nw = getenv("T2V_ATTN_NW") ? atoi(getenv("T2V_ATTN_NW")) : 0;
-    const bool eight = force_nw == 8;
-    if (eight) {
+    if (g_attn_form < 0) {   // T2V_ATTN_NW=8 / T2V_ATTN_Q64=1 (long launches) / 2 (always): tools switches, see t2v_attn_spatial_form
+        const int nw = getenv("T2V_ATTN_NW") ? atoi(getenv("T2V_ATTN_NW")) : 0, q = getenv("T2V_ATTN_Q64") ? atoi(getenv("T2V_ATTN_Q64")) : 0;
+        g_attn_form = q == 2 ? 65 : (q == 1 ? 64 : (nw == 8 ? 8 : 0));
+    }
+    const bool eight = g_attn_form == 8;
+    if (g_attn_form == 65 || (g_attn_form == 64 && seq_kv >= 512 && seq_q >= 512 && g_attn_debug == 0)) {
+        dim3 grid((seq_q + 255) / 256, heads, n_img);
+        hipLaunchKernelGGL(attn_spatial_q64_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                           (const bf16_t*)vt, ld_vt, vt_img_stride, (bf16_t*)out, ldo, seq_q, seq_kv, heads, kv_div, scale,
+                           (const bf16_t*)t2v_zero_page());
+    } else if (eight) {
         dim3 grid((seq_q + 255) / 256, heads, n_img);
         hipLaunchKernelGGL(attn_spatial_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
                            (const bf16_t*)k, ldk, (const bf16_t*)vt, ld_vt, vt_img_stride, (bf16_t*)out, ldo, seq_q, seq_kv, heads,

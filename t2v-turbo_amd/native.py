@@ -162,6 +162,7 @@ _SIGS = {
                                C.c_longlong, C.c_void_p, C.c_void_p]),
     "t2v_gemm_debug": (C.c_int, [C.c_int]),
     "t2v_attn_debug": (C.c_int, [C.c_int]),
+    "t2v_attn_spatial_form": (C.c_int, [C.c_int]),
     "t2v_gn_coop_enable": (C.c_int, [C.c_int]),
     "t2v_gn_coop_error": (C.c_int, []),
     "t2v_gn_bwd_ws_floats": (C.c_longlong, [C.c_int, C.c_int, C.c_int]),

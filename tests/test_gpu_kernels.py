@@ -254,6 +254,32 @@ def test_attn_spatial_flash(pair, n_img, seq_q, seq_kv, heads, kv_div):
     assert rel_l2(got, out_e) < 8e-3  # P is rounded to bf16 before the PV product
 
 
+@pytest.mark.parametrize("n_img,seq_q,seq_kv,heads,kv_div", [(2, 700, 700, 2, 1), (4, 300, 77, 3, 2), (1, 2560, 2560, 1, 1), (2, 40, 200, 2, 1)])
+def test_attn_spatial_forms_are_bit_identical(pair, n_img, seq_q, seq_kv, heads, kv_div):
+    """t2v_attn_spatial_form: eight waves per workgroup (8) and 64 queries per wave with the two query sets' phases offset (65) do the SAME
+    arithmetic per query as the product kernel (0) — outputs must be bit-identical: ragged query blocks of 128 / 256, the last tile's
+    padding keys, per-clip text keys (kv_div), a running max that moves.  (Both are measured no faster: tools / tests only.)"""
+    inner = heads * 64
+    n_kv = n_img // kv_div
+    kp = ((seq_kv + 63) // 64) * 64
+    q = _rt(n_img * seq_q, inner, seed=11, scale=2.0).cuda().bfloat16()
+    k = _rt(n_kv * seq_kv, inner, seed=12, scale=2.0).cuda().bfloat16()
+    vt = _rt(n_kv * inner, kp, seed=13).cuda().bfloat16()
+    vt[:, seq_kv:] = 1e30
+    outs = []
+    try:
+        for form in (0, 8, 65):
+            pair.hip.lib.t2v_attn_spatial_form(form)
+            o = torch.full((n_img * seq_q, inner), float("nan"), dtype=torch.bfloat16, device="cuda")
+            pair.hip.attn_spatial(q, k, vt, kp, o, n_img, seq_q, seq_kv, heads, kv_div, 0.125)
+            torch.cuda.synchronize()
+            outs.append(o.clone())
+    finally:
+        pair.hip.lib.t2v_attn_spatial_form(0)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_attn_spatial_online_softmax_rescale(pair):
     """Force the running max to jump at a late key tile (spike one key against every query)."""
     seq, inner = 256, 64

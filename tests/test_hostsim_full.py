@@ -363,3 +363,29 @@ def test_conv3x3_small_cout_direct(full_ops, n_img, h, w, cin, cout, f32):
     emu.conv_small(x, n_img, h, w, wgt, bias, o_e)
     assert torch.isfinite(o_s.float()).all()
     assert rel_l2(o_s.float(), o_e) < (1e-5 if f32 else 6e-3)
+
+
+@pytest.mark.parametrize("n_img,seq_q,seq_kv,heads,kv_div", [(1, 300, 130, 1, 1), (2, 70, 77, 2, 2)])
+def test_attn_spatial_forms_are_bit_identical_on_the_simulator(full_ops, n_img, seq_q, seq_kv, heads, kv_div):
+    """t2v_attn_spatial_form 8 (eight waves per workgroup) and 65 (64 queries per wave, the two query sets' phases offset) against the
+    product kernel on the simulator: same arithmetic per query, so bit-identical outputs — ragged query blocks, padding keys in the last
+    tile, per-clip keys."""
+    sim = full_ops()
+    inner = heads * 64
+    n_kv = n_img // kv_div
+    kp = ((seq_kv + 63) // 64) * 64
+    q = _bf5(_rt5(n_img * seq_q, inner, seed=11, scale=2.0))
+    k = _bf5(_rt5(n_kv * seq_kv, inner, seed=12, scale=2.0))
+    vt = _bf5(_rt5(n_kv * inner, kp, seed=13))
+    vt[:, seq_kv:] = 1e30
+    outs = []
+    try:
+        for form in (0, 8, 65):
+            sim.lib.t2v_attn_spatial_form(form)
+            o = torch.full((n_img * seq_q, inner), float("nan"), dtype=torch.bfloat16)
+            sim.attn_spatial(q, k, vt, kp, o, n_img, seq_q, seq_kv, heads, kv_div, 0.125)
+            outs.append(o.clone())
+    finally:
+        sim.lib.t2v_attn_spatial_form(0)
+    assert torch.isfinite(outs[0].float()).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -19,6 +19,7 @@ ops.lib.t2v_attn_debug(a.debug)
 kv = a.kv or a.seq
 inner = a.heads * 64
 kp = (kv + 63) // 64 * 64
+torch.manual_seed(0)
 q = torch.randn(a.nimg * a.seq, inner, device="cuda").bfloat16()
 k = torch.randn(a.nimg * kv, inner, device="cuda").bfloat16()
 vt = torch.randn(a.nimg * inner, kp, device="cuda").bfloat16()
@@ -31,4 +32,5 @@ for _ in range(a.iters):
     ops.attn_spatial(q, k, vt, kp, out, a.nimg, a.seq, kv, a.heads, 1, 0.125)
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / a.iters
-print(f"attn debug={a.debug} nimg={a.nimg} seq={a.seq} kv={kv} heads={a.heads}: {us:.1f} us  {4.0*a.nimg*a.heads*a.seq*kv*64/us/1e6:.1f} TF/s")
+chk = int(out.view(torch.int16).to(torch.int64).mul(torch.arange(out.numel(), device="cuda").view_as(out) % 8191 + 1).sum().item())
+print(f"attn debug={a.debug} nimg={a.nimg} seq={a.seq} kv={kv} heads={a.heads}: {us:.1f} us  {4.0*a.nimg*a.heads*a.seq*kv*64/us/1e6:.1f} TF/s  checksum {chk}")
