@@ -247,7 +247,10 @@ int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, int c1, int 
 /* GroupNorm(+SiLU) whose statistics pass reads the column statistics the producing t2v_gemm launches wrote
  * (t2v_gemm_desc::colstat_out) instead of the tensor: cs0 [rows/32][c0][2] for x0, cs1 [rows/32][c1][2] for the second part of
  * a virtual concat (NULL without one); rows_per_unit % 32 == 0.  Two launches; ws: t2v_group_norm_cs_ws_floats(...) floats.
- * Same result as t2v_group_norm up to the summation order of the statistics (fixed: deterministic). */
+ * Same result as t2v_group_norm up to the summation order of the statistics (fixed: deterministic).  The statistics launch has two
+ * forms, chosen by shape: one block per (group, unit) that leaves the per-channel affine (rstd gamma, beta - mean rstd gamma) in ws and
+ * an apply pass that streams with it (even channels per group, c0 even, cs0 / cs1 16-byte aligned, 2 (c0 + c1) <= the ws floats per
+ * unit, at most 32 slabs per thread), or per-slab-block partial sums that every block of the apply pass finishes for itself. */
 long long t2v_group_norm_cs_ws_floats(int n_units, int rows_per_unit, int groups);
 int t2v_group_norm_cs(const float* cs0, const float* cs1, const void* x0, int c0, int ld0, const void* x1, int c1, int ld1,
                       int n_units, int rows_per_unit, int groups, float eps, const float* gamma, const float* beta, int silu,

@@ -209,6 +209,71 @@ __global__ __launch_bounds__(256) void gn_partial_cs_kernel(const float* cs0, in
     }
 }
 
+// coef[unit][0][c] = rstd * gamma[c], coef[unit][1][c] = beta[c] - mean * rstd * gamma[c] STRAIGHT from the producers' column statistics:
+// block (group, unit) owns one group.  Thread (pair, lane) adds the (sum, sumsq) float4 of channel pair `pair` of the group over
+// the slabs lane, lane + nlane, ... (a thread's loads are independent, eight in flight per trip; NT = 1024 threads where 256 would
+// need more than eight loads each: one unit of 40 960 rows is 1 280 slabs), every wave adds its 64 double pairs by butterfly, thread 0
+// adds the waves' partials in order, finishes (mean, rstd) in double (-> `stats` when given: the training engine keeps them) and the
+// first cpg threads write the group's coefficients.
+// The apply pass (gn_apply_kernel<1>) then starts on its rows at once instead of finishing 80 partials per block behind three barriers.
+constexpr int GN_CSD_LOADS = 32;
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_coef_cs_kernel(const float* cs0, int c0, const float* cs1, int c1, int slabs_per_unit, int groups,
+                                                         float inv_count, float eps, const float* gamma, const float* beta, float* coef, float* stats) {
+    __shared__ double shs[NT / 64], shq[NT / 64];
+    __shared__ float smr[2];
+    const int C = c0 + c1, cpg = C / groups, ncp = cpg >> 1, nlane = NT / ncp;
+    const int unit = blockIdx.y, grp = blockIdx.x, tid = threadIdx.x;
+    const int pair = tid % ncp, lane = tid / ncp;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < nlane) {
+        const int c = grp * cpg + 2 * pair;
+        const float* src = c < c0 ? cs0 + 2 * c : cs1 + 2 * (c - c0);
+        const long long ldc = c < c0 ? 2LL * c0 : 2LL * c1;
+        src += (long long)unit * slabs_per_unit * ldc;
+        int sl = lane;
+        for (; sl + 7 * nlane < slabs_per_unit; sl += 8 * nlane) {   // eight loads in flight per trip, added in slab order
+            float4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = *(const float4*)(src + (long long)(sl + e * nlane) * ldc);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { acc.x += v[e].x; acc.y += v[e].y; acc.z += v[e].z; acc.w += v[e].w; }
+        }
+        for (; sl < slabs_per_unit; sl += nlane) {
+            const float4 v = *(const float4*)(src + (long long)sl * ldc);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    // wave sums by butterfly (fixed order), one partial per wave through LDS, thread 0 adds the waves in order
+    double ds = (double)acc.x + (double)acc.z, dq = (double)acc.y + (double)acc.w;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dq += __shfl_xor(dq, o, 64); }
+    if ((tid & 63) == 0) { shs[tid >> 6] = ds; shq[tid >> 6] = dq; }
+    __syncthreads();
+    if (tid == 0) {
+        double ts = 0.0, tq = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { ts += shs[w]; tq += shq[w]; }
+        const double mean = ts * (double)inv_count;
+        double var = tq * (double)inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        smr[0] = (float)mean;
+        smr[1] = (float)(1.0 / sqrt(var + (double)eps));
+        if (stats) {
+            stats[((long long)unit * groups + grp) * 2] = smr[0];
+            stats[((long long)unit * groups + grp) * 2 + 1] = smr[1];
+        }
+    }
+    if (!coef) return;
+    __syncthreads();
+    if (tid < cpg) {
+        const int c = grp * cpg + tid;
+        const float a = smr[1] * gamma[c];
+        coef[(long long)unit * 2 * C + c] = a;
+        coef[(long long)unit * 2 * C + C + c] = beta[c] - smr[0] * a;
+    }
+}
+
 // one block per unit: stats[unit][group] = (mean, rstd) and, when coef != null, the per-channel affine
 // coef[unit][0][c] = rstd*gamma[c], coef[unit][1][c] = beta[c] - mean*rstd*gamma[c] the apply pass streams with
 __global__ __launch_bounds__(1024) void gn_final_kernel(const float* partial, int nslab, int groups, int C, float inv_count, float eps,
@@ -852,6 +917,28 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
 // GroupNorm(+SiLU) on the column statistics of the producing GEMMs: [statistics from cs: gn_partial_cs_kernel] + [apply pass whose
 // blocks finish the unit's statistics themselves].  Two launches, the tensor is read once.
 constexpr int GN_CS_BLOCKS = 80;  // statistics blocks per unit (<= gn_fuse_slabs: the apply pass finishes them per block)
+// threads per block of the direct form for this shape, 0 = not eligible: odd channels per group or part width, too many slabs per thread,
+// or a group's 16 ncp bytes per slab are less than a 128-byte line while the statistics are too large to sit in the caches — the VAE
+// decoder's 256- and 128-channel levels have 42 / 84 MB of them per norm, read in 64- / 32-byte pieces 1-2 KB apart (measured: the
+// decode 0.2 ms slower, profiles/r05_gn_direct_ab.txt); there the partial-sums form reads whole rows of the array.
+static int gn_csd_threads(int c0, int c1, int groups, int slabs_per_unit, int n_units, const float* cs0, const float* cs1) {
+    static const bool direct_on = !(getenv("T2V_GN_CS_DIRECT") && getenv("T2V_GN_CS_DIRECT")[0] == '0');
+    const int C = c0 + c1, cpg = C / groups, ncp = cpg >> 1;
+    if (!direct_on || cpg % 2 || c0 % 2 || ncp < 1 || ncp > 256 || (uintptr_t)cs0 % 16 || (cs1 && (uintptr_t)cs1 % 16)) return 0;
+    if (ncp < 8 && (long long)n_units * slabs_per_unit * C * 8 > (8LL << 20)) return 0;
+    const int lanes256 = 256 / ncp;
+    const int nt = (slabs_per_unit + lanes256 - 1) / lanes256 > 8 ? 1024 : 256;
+    return (slabs_per_unit + nt / ncp - 1) / (nt / ncp) <= GN_CSD_LOADS ? nt : 0;
+}
+static void gn_csd_launch(int nt, const float* cs0, int c0, const float* cs1, int c1, int n_units, int slabs_per_unit, int groups, float inv_count,
+                          float eps, const float* gamma, const float* beta, float* coef, float* stats, hipStream_t s) {
+    if (nt == 1024)
+        hipLaunchKernelGGL(gn_coef_cs_kernel<1024>, dim3(groups, n_units), dim3(1024), 0, s, cs0, c0, cs1, c1, slabs_per_unit, groups,
+                           inv_count, eps, gamma, beta, coef, stats);
+    else
+        hipLaunchKernelGGL(gn_coef_cs_kernel<256>, dim3(groups, n_units), dim3(256), 0, s, cs0, c0, cs1, c1, slabs_per_unit, groups,
+                           inv_count, eps, gamma, beta, coef, stats);
+}
 extern "C" long long t2v_group_norm_cs_ws_floats(int n_units, int rows_per_unit, int groups) {
     (void)rows_per_unit;
     return (long long)n_units * GN_CS_BLOCKS * 2 * groups;
@@ -872,6 +959,19 @@ extern "C" int t2v_group_norm_cs(const float* cs0, const float* cs1, const void*
     const int slabs_per_blk = (slabs_per_unit + GN_CS_BLOCKS - 1) / GN_CS_BLOCKS;
     const int nblk = (slabs_per_unit + slabs_per_blk - 1) / slabs_per_blk;
     const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / groups));
+    // Direct form (round 5): one block per (group, unit) turns the column statistics into the per-channel affine, the apply pass
+    // streams with it.  Needs an even number of channels per group with both parts' widths even (a float4 = two channels of one
+    // part), at most GN_CSD_LOADS slabs per thread, and the coefficients in the workspace (2 C <= 2 * groups * GN_CS_BLOCKS floats per unit).
+    const int nt = C <= groups * GN_CS_BLOCKS ? gn_csd_threads(c0, c1, groups, slabs_per_unit, n_units, cs0, cs1) : 0;
+    if (nt) {
+        gn_csd_launch(nt, cs0, c0, cs1, c1, n_units, slabs_per_unit, groups, inv_count, eps, gamma, beta, ws, nullptr, s);
+        T2V_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nslab, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
+                           ld1, rows_per_unit, groups, slab_rows, (const float*)nullptr, (const float*)ws, (const float*)nullptr, 0,
+                           inv_count, eps, gamma, beta, silu, (bf16_t*)out, ldo, (const char*)prefetch, prefetch_bytes >> 7);
+        T2V_CHECK_LAUNCH();
+        return T2V_OK;
+    }
     hipLaunchKernelGGL(gn_partial_cs_kernel, dim3(nblk, n_units), dim3(256), (size_t)2 * C * sizeof(float), s, cs0, c0, cs1, c1,
                        slabs_per_unit, slabs_per_blk, groups, ws);
     T2V_CHECK_LAUNCH();
@@ -898,6 +998,11 @@ extern "C" int t2v_gn_stats_cs(const float* cs0, int c0, const float* cs1, int c
     const int slabs_per_blk = (slabs_per_unit + GN_CS_BLOCKS - 1) / GN_CS_BLOCKS;
     const int nblk = (slabs_per_unit + slabs_per_blk - 1) / slabs_per_blk;
     const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / groups));
+    if (const int nt = gn_csd_threads(c0, c1, groups, slabs_per_unit, n_units, cs0, cs1)) {   // one launch: a block per (group, unit)
+        gn_csd_launch(nt, cs0, c0, cs1, c1, n_units, slabs_per_unit, groups, inv_count, eps, nullptr, nullptr, nullptr, stats, s);
+        T2V_CHECK_LAUNCH();
+        return T2V_OK;
+    }
     hipLaunchKernelGGL(gn_partial_cs_kernel, dim3(nblk, n_units), dim3(256), (size_t)2 * C * sizeof(float), s, cs0, c0, cs1, c1,
                        slabs_per_unit, slabs_per_blk, groups, ws);
     T2V_CHECK_LAUNCH();

@@ -205,10 +205,14 @@ def test_optimizer_and_scheduler_kernels_on_the_real_library(full_ops):
     assert torch.allclose(o_s, o_e, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("c0,c1,units,rows,silu", [(320, 0, 2, 64, True), (128, 64, 1, 160, True), (64, 64, 3, 32, False)])
+@pytest.mark.parametrize("c0,c1,units,rows,silu", [(320, 0, 2, 64, True), (128, 64, 1, 160, True), (64, 64, 3, 32, False),
+                                                    (320, 0, 1, 13120, True), (64, 32, 2, 64, True), (640, 320, 2, 160, False)])
 def test_group_norm_from_the_producers_column_statistics(full_ops, c0, c1, units, rows, silu):
     """t2v_group_norm_cs (csrc/norm.hip): GroupNorm whose statistics come from per-32-row column sums (what t2v_gemm's colstat_out
-    writes) instead of a pass over the tensor — single tensors and virtual concats, several units, against the plain GroupNorm."""
+    writes) instead of a pass over the tensor — single tensors and virtual concats, several units, against the plain GroupNorm.
+    Both forms of the statistics launch: the direct one (one block per group writes the per-channel affine: 256 threads, and 1 024
+    for the one-unit 13 120-row case; a group straddling the two parts of a concat in the 128 + 64 and 640 + 320 cases) and the
+    partial-sums one (64 + 32: three channels per group, odd)."""
     from tests.emu_ops import EmuOps
     sim, emu = full_ops(), EmuOps()
     gen = torch.Generator().manual_seed(c0 + rows)
