@@ -234,8 +234,10 @@ int t2v_gn_stats(const void* x0, int c0, int ld0, const void* x1, int c1, int ld
 int t2v_gn_apply(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units,
                  int rows_per_unit, int groups, const float* stats, const float* gamma,
                  const float* beta, int silu, void* out, int ldo, void* stream);
-/* GroupNorm(+SiLU) in one call (what the engines use): statistics + normalise, 2 launches for tensors with few row slabs,
- * 3 otherwise.  ws: t2v_group_norm_ws_floats(n_units, rows_per_unit, groups, c0 + c1) floats.
+/* GroupNorm(+SiLU) in one call (what the engines use): statistics + normalise — ONE launch (a workgroup per (group, unit), the group's
+ * slice of the unit in registers, ws untouched) where a group has a multiple of 8 channels and rows_per_unit * channels-per-group / 8
+ * <= 4096 and no prefetch hint is given; else 2 launches for tensors with few row slabs, 3 otherwise.
+ * ws: t2v_group_norm_ws_floats(n_units, rows_per_unit, groups, c0 + c1) floats.
  * prefetch / prefetch_bytes (NULL / 0 = off): a buffer the NEXT launch will stream — the weights of the conv that follows every
  * GroupNorm of the UNet — touched with streaming loads by the normalise pass so that it sits in the 256 MB Infinity Cache when
  * that launch starts (a UNet step walks 2.8 GB of weights: nothing survives from the previous step).  Hint only. */

@@ -855,6 +855,90 @@ extern "C" int t2v_gn_coop_error(void) { return 0; }
 extern "C" int t2v_gn_coop_enable(int) { return T2V_OK; }
 #endif
 
+// ---- GroupNorm(+SiLU) of a SMALL unit in one launch, one workgroup per (group, unit) --------------------------------------------------
+// The norms that cannot take their statistics from a producer (split-K launches, the 5 x 8 level: 49 per UNet step, 1.6-6.5 MB each)
+// paid two latency-bound launches.  A group of a unit is independent of every other one: block (group, unit) holds its
+// rows_per_unit x cpg elements in registers (16-byte chunks, at most GG_MAXCH per thread, all loads issued first), reduces (sum, sumsq)
+// — per-thread floats over <= 32 elements, then doubles by wave butterfly and one LDS hand-off, fixed order — and normalises its
+// registers straight into the output: x is read once, no workspace, no second launch.  A group's row segment is cpg x 2 bytes
+// (80 / 160 bytes at C = 1 280 / 2 560): neighbouring groups share lines in L2.
+namespace {
+constexpr int GG_MAXCH = 4;
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_group_kernel(const bf16_t* __restrict__ x0, int c0, int ld0, const bf16_t* __restrict__ x1, int c1,
+                                                      int ld1, int rows_per_unit, int groups, float inv_count, float eps,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+                                                      bf16_t* __restrict__ out, int ldo) {
+    __shared__ double shs[NT / 64], shq[NT / 64];
+    __shared__ float smr[2];
+    const int C = c0 + c1, cpg = C / groups, cpr = cpg >> 3;
+    const int unit = blockIdx.y, grp = blockIdx.x, tid = threadIdx.x;
+    const int nchunk = rows_per_unit * cpr, ch0 = grp * cpg;
+    const long long row0 = (long long)unit * rows_per_unit;
+    uint4 u[GG_MAXCH];
+    int rr[GG_MAXCH], cc[GG_MAXCH];
+#pragma unroll
+    for (int j = 0; j < GG_MAXCH; ++j) {
+        const int idx = tid + j * NT;
+        rr[j] = idx / cpr;
+        cc[j] = ch0 + (idx - rr[j] * cpr) * 8;
+        u[j] = make_uint4(0u, 0u, 0u, 0u);
+        if (idx < nchunk) u[j] = *(const uint4*)gn_src(x0, c0, ld0, x1, ld1, row0 + rr[j], cc[j]);
+    }
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < GG_MAXCH; ++j) {   // (chunks past the end are zeros: they add nothing)
+        float f[8];
+        unpack8(u[j], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { a += f[e]; q = fmaf(f[e], f[e], q); }
+    }
+    double ds = (double)a, dq = (double)q;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ds += __shfl_xor(ds, o, 64); dq += __shfl_xor(dq, o, 64); }
+    if ((tid & 63) == 0) { shs[tid >> 6] = ds; shq[tid >> 6] = dq; }
+    __syncthreads();
+    if (tid == 0) {
+        double ts = 0.0, tq = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) { ts += shs[w]; tq += shq[w]; }
+        const double mean = ts * (double)inv_count;
+        double var = tq * (double)inv_count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        smr[0] = (float)mean;
+        smr[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const float mean = smr[0], rstd = smr[1];
+#pragma unroll
+    for (int j = 0; j < GG_MAXCH; ++j) {
+        if (tid + j * NT >= nchunk) break;
+        const float4 g0 = *(const float4*)(gamma + cc[j]), g1 = *(const float4*)(gamma + cc[j] + 4);
+        const float4 b0 = *(const float4*)(beta + cc[j]), b1 = *(const float4*)(beta + cc[j] + 4);
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float f[8];
+        unpack8(u[j], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sc = rstd * gm[e];
+            const float v = f[e] * sc + (bt[e] - mean * sc);
+            f[e] = silu ? silu_f(v) : v;
+        }
+        *(uint4*)(out + (row0 + rr[j]) * ldo + cc[j]) = pack8(f);
+    }
+}
+// threads per block of that form, 0 = not eligible (channels per group not a multiple of 8, a group that straddles the two parts of a
+// concat is fine — chunks never do, c0 % 8 == 0 —, more than GG_MAXCH chunks per thread at 1 024 threads, a prefetch hint to carry)
+int gn_group_threads(int c0, int c1, int rows_per_unit, int groups, long long prefetch_bytes) {
+    static const bool on = !(getenv("T2V_GN_GROUP") && getenv("T2V_GN_GROUP")[0] == '0');
+    const int cpg = (c0 + c1) / groups;
+    if (!on || prefetch_bytes > 0 || cpg % 8 || c0 % 8) return 0;
+    const long long nchunk = (long long)rows_per_unit * (cpg >> 3);
+    return nchunk <= 256 * GG_MAXCH ? 256 : nchunk <= 1024 * GG_MAXCH ? 1024 : 0;
+}
+}  // namespace
+
 // GroupNorm(+SiLU) in one call: slab partial sums, then either [finish + per-channel affine, streaming apply] or, for
 // tensors with few slabs, an apply pass whose blocks finish the statistics themselves (2 launches instead of 3).
 extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int n_units,
@@ -865,6 +949,17 @@ extern "C" int t2v_group_norm(const void* x0, int c0, int ld0, const void* x1, i
     T2V_REQUIRE(ws && gamma && beta && out && ldo % 8 == 0, T2V_EINVAL, "t2v_group_norm: bad argument");
     if (!x1) { c1 = 0; ld1 = 0; }
     hipStream_t s = (hipStream_t)stream;
+    if (const int nt = gn_group_threads(c0, c1, rows_per_unit, groups, prefetch_bytes)) {
+        const float inv = 1.0f / ((float)rows_per_unit * (float)((c0 + c1) / groups));
+        if (nt == 1024)
+            hipLaunchKernelGGL(gn_group_kernel<1024>, dim3(groups, n_units), dim3(1024), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1,
+                               rows_per_unit, groups, inv, eps, gamma, beta, silu, (bf16_t*)out, ldo);
+        else
+            hipLaunchKernelGGL(gn_group_kernel<256>, dim3(groups, n_units), dim3(256), 0, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1,
+                               rows_per_unit, groups, inv, eps, gamma, beta, silu, (bf16_t*)out, ldo);
+        T2V_CHECK_LAUNCH();
+        return T2V_OK;
+    }
 #ifndef T2V_HOSTSIM
     if (gn_try_coop(x0, c0, ld0, x1, c1, ld1, n_units, rows_per_unit, groups, eps, gamma, beta, silu, ws, out, ldo, s)) {
         T2V_CHECK_LAUNCH();

@@ -330,12 +330,16 @@ def test_layernorm_row_group_and_fallback_widths(full_ops, M, Cc):
 
 
 @pytest.mark.parametrize("units,rows,c0,c1,silu", [(2, 96, 320, 0, True), (3, 64, 64, 128, False), (1, 2560, 320, 0, True),
-                                                   (2, 40, 1280, 1280, True), (1, 72, 2560, 0, False)])
+                                                   (2, 40, 1280, 1280, True), (1, 72, 2560, 0, False), (1, 640, 1280, 0, True),
+                                                   (3, 40, 1280, 0, False), (1, 900, 1280, 0, True), (2, 40, 1280, 256, True)])
 def test_group_norm_two_and_three_launch_forms_one_and_two_chunks_per_thread(full_ops, units, rows, c0, c1, silu):
     """t2v_group_norm (statistics pass + apply whose blocks finish the statistics themselves, or the three-launch form for many slabs):
     one and two channel chunks per thread (C > 2048), virtual concats, ragged slabs — written for a variant of the apply kernel that
     issued its first rows before finishing the statistics (measured slower on MI355X and dropped: csrc/norm.hip); kept as coverage
-    of the width / slab-count corners."""
+    of the width / slab-count corners.  Round 5: where a group has a multiple of 8 channels and a unit's slice of it fits 4 chunks per
+    thread, the op is ONE launch with a workgroup per (group, unit) (gn_group_kernel): 256 threads (2 x 40 x 2 560, 1 x 72 x 2 560,
+    3 x 40 x 1 280), 1 024 threads (1 x 640 x 1 280), a group that straddles the two parts of a concat (1 280 + 256: 48 channels per
+    group), and 1 x 900 x 1 280 as the first shape past its limit."""
     sim, emu = full_ops(), EmuOps()
     Cc = c0 + c1
     x0 = _rt5(units * rows, c0, seed=rows + c0, scale=1.5) + 0.25
