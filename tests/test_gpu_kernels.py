@@ -197,7 +197,8 @@ def test_groupnorm(pair, C, c1, units, rows):
 @pytest.mark.parametrize("C,c1,units,rows", [(320, 0, 2, 77), (640, 320, 3, 40), (1280, 0, 1, 700), (2560, 1280, 2, 40),
                                               (320, 0, 1, 4000), (128, 0, 2, 9000), (960, 320, 1, 1500)])
 def test_group_norm_one_call(pair, C, c1, units, rows):
-    """t2v_group_norm: the fused-finish path (few slabs) and the 3-launch path (many slabs), vs the torch emulation."""
+    """t2v_group_norm: the workgroup-per-(group, unit) launch (1 280 x 1 x 700 on 1 024 threads, the 2 x 40 x 2 560 concat on 256), the
+    fused-finish path (few slabs) and the 3-launch path (many slabs), vs the torch emulation."""
     c0 = C - c1
     x0 = pair.act((_rt(units * rows, c0, seed=1) * 2.0 + 0.5).bfloat16().float())
     x1 = pair.act((_rt(units * rows, c1, seed=2) - 1.0).bfloat16().float()) if c1 else (None, None)
@@ -475,7 +476,9 @@ def test_fill_zero_edges(pair):
 def test_group_norm_one_launch_form_at_unet_sizes(pair, C, c1, units, rows):
     """The one-launch GroupNorm (registers hold the tensor, per-unit inter-workgroup barrier) at the sizes the UNet calls it with,
     against the three-launch form of the same entry point and the emulation; 200 back-to-back calls on alternating inputs (a stale
-    partial or a missed barrier generation shows as a wrong result), bit-identical on re-run, no barrier timeout recorded."""
+    partial or a missed barrier generation shows as a wrong result), bit-identical on re-run, no barrier timeout recorded.
+    (Round 5: shapes whose groups are a multiple of 8 channels wide with at most 4 096 chunks per (group, unit) — 1 280 x 1 x 640 and
+    2 560 x 16 x 40 here — take the workgroup-per-group launch (gn_group_kernel) in BOTH modes: it needs no barrier and comes first.)"""
     lib = pair.hip.lib
     c0 = C - c1
     xs = []
