@@ -181,6 +181,22 @@ int t2v_conv_halo_supported(const t2v_gemm_desc* d);
 int t2v_conv_halo_pack_cols(int channels);
 int t2v_conv_halo_force_config(int cfg);
 int t2v_conv_halo_debug(int bits);   /* ablation bits; honoured by -DT2V_HALO_ABLATE tool builds only */
+/* Short-K linear layers (K = 320 / 640) with the activation panel RESIDENT in LDS and the weights streamed into registers in MFMA
+ * fragment order (csrc/linear_pr.hip): same descriptor as t2v_gemm (mode T2V_GEMM_LINEAR, one source, no batch / split-K / rowvec /
+ * dropout / fused statistics / fp32 output; epilogue: bias, then GEGLU, or an optional residual), EXCEPT that `w` holds the
+ * FRAGMENT pack of the [N][K] matrix t2v_gemm takes (for GEGLU: of its 64-row [32 value | 32 gate] interleave), N % 64 == 0:
+ *     pack[chunk q = n / 64][step s = k / 16][block b = (n % 64) / 32][lane l][e = 0..7]  (bf16, N * K elements)
+ *         = W[64 q + 32 b + 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3)][16 s + 8 (l >> 5) + e],   i = l & 31
+ * i.e. every (chunk, step, block) is the 1 KiB v_mfma_f32_32x32x16_bf16 A operand of 32 output rows x 16 K, lane-major, with the
+ * rows of a block permuted so that a lane's 16 accumulator registers are 16 consecutive output channels.
+ * Replaces the same reference call sites as t2v_gemm's LINEAR mode at these widths: the GEGLU projection
+ * (lvdm/modules/attention.py:516-523), q | k | v (:71-76), to_out (:164), proj_in / proj_out (:373-389,471-513).
+ * t2v_linear_pr_supported: 0 = not taken (use t2v_gemm with the plain [N][K] matrix), 1 = taken; negative = invalid descriptor.
+ * Launches nothing. */
+int t2v_linear_pr(const t2v_gemm_desc* d, void* stream);
+int t2v_linear_pr_supported(const t2v_gemm_desc* d);
+int t2v_linear_pr_debug(int bits);         /* ablation bits; honoured by -DT2V_LPR_ABLATE tool builds only */
+int t2v_linear_pr_force_split(int ny);     /* tuning hook: column splits (workgroup rows) for every following call, 0 = library rule */
 /* tuning/test hooks: override tile id / split-K factor for every following call (0 = off) */
 int t2v_gemm_force_config(int cfg);
 /* t2v_gemm's second kernel family (csrc/gemm2.hip: static-schedule main loop, 80x80 wave tiles; tile ids 50 = 320x160, 51 = 160x160)

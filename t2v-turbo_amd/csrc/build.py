@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "gemm2.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "replay.hip"]
+SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "linear_pr.hip", "gemm2.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "replay.hip"]
 # T2V_HIP_LIB_OUT: build a variant (e.g. with ablation switches) next to the product library instead of over it
 LIB = os.path.abspath(os.environ["T2V_HIP_LIB_OUT"]) if os.environ.get("T2V_HIP_LIB_OUT") else os.path.join(PKG, "libt2v_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
@@ -25,13 +25,14 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "gn_bwd_common.h"), os.path.join(HERE, "tile80.h"), os.path.join(HERE, "gemm2.h"),
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "gn_bwd_common.h"), os.path.join(HERE, "tile80.h"), os.path.join(HERE, "gemm2.h"), os.path.join(HERE, "gelu_poly.h"),
                                                         os.path.join(ROOT, "include", "t2v_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 # what each translation unit includes besides common.h and the C-ABI header (an object is rebuilt when it is older than any of them)
-EXTRA_DEPS = {"gemm.hip": ["gemm2.h"], "gemm_exp.hip": ["gemm.hip", "gemm2.h"], "gemm_fuse.hip": ["gemm.hip", "gemm2.h"],
+EXTRA_DEPS = {"gemm.hip": ["gemm2.h", "gelu_poly.h"], "gemm_exp.hip": ["gemm.hip", "gemm2.h", "gelu_poly.h"], "gemm_fuse.hip": ["gemm.hip", "gemm2.h", "gelu_poly.h"],
+              "linear_pr.hip": ["gelu_poly.h"],
               "conv_halo.hip": ["tile80.h"], "gemm2.hip": ["tile80.h", "gemm2.h"], "backward.hip": ["gn_bwd_common.h"],
               "backward_unet.hip": ["gn_bwd_common.h"]}
 
@@ -52,10 +53,13 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     for s in SOURCES:
-        o = os.path.join(HERE, s.replace(".hip", ".o" if not os.environ.get("T2V_HIP_LIB_OUT") else ".variant.o"))
+        # a build with its own output path OR its own flags is a variant: its objects never share a name with the product's (a
+        # flagged object left behind as foo.o would look fresh to the next plain build and be linked into libt2v_hip.so)
+        variant = bool(os.environ.get("T2V_HIP_LIB_OUT") or os.environ.get("T2V_EXTRA_HIPCC_FLAGS"))
+        o = os.path.join(HERE, s.replace(".hip", ".variant.o" if variant else ".o"))
         objs.append(o)
-        # (variant builds carry their own flags: always recompiled; the product build only recompiles what changed)
-        if not force and not os.environ.get("T2V_HIP_LIB_OUT") and not os.environ.get("T2V_EXTRA_HIPCC_FLAGS") and not _stale(s, o):
+        # (variant builds are always recompiled; the product build only recompiles what changed)
+        if not force and not variant and not _stale(s, o):
             continue
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(HERE, s), "-o", o]
         if verbose:

@@ -208,6 +208,11 @@ class Packer:
             return wd.reshape(wd.shape[0], -1).to(self.device).contiguous()
         return self._memo(("small_dgrad", id(mod), cin_pad, cout_pad), make)
 
+    def lpr(self, w):
+        """Fragment pack (native.pack_linear_pr) of an [N, K] pack this Packer made — a plain ``mat`` / ``cat_mats`` matrix or the 64-row
+        [value | gate] interleave of ``geglu`` — for t2v_linear_pr; keyed by the source pack, which the cache keeps alive."""
+        return self._memo(("lpr", id(w)), lambda: nt.pack_linear_pr(w))
+
     def cat_mats(self, mods, tag):
         return self._memo((tag,) + tuple(id(m) for m in mods),
                           lambda: torch.cat([self.mat(m) for m in mods], dim=0).contiguous())
@@ -410,8 +415,27 @@ class _Engine:
                 self.last_rs = kw["rowstat"] = rs
             else:
                 self.pool.put(rs)
-        self.ops.gemm(a, w, out, **kw)
+        if self._lpr_takes(a, w, out, kw):
+            self.ops.linear_pr(a, self.pk.lpr(w), out, **kw)
+        else:
+            self.ops.gemm(a, w, out, **kw)
         return out
+
+    # Short-K linears on the panel-resident kernel (csrc/linear_pr.hip) where it measured faster than the tuned t2v_gemm tile
+    # (profiles/r06_linear_pr_vs_gemm.csv): the GEGLU projection and the q | k | v / q | k launches of the 320- and 640-channel levels.
+    # The N = C launches (to_out, proj_in / proj_out: one chunk per wave, HBM-bound) tie or lose there and stay on t2v_gemm.
+    linear_pr = os.environ.get("T2V_LINEAR_PR", "1") == "1"
+    linear_pr_min_n = {320: int(os.environ.get("T2V_LPR_MIN_N_320", "640")), 640: int(os.environ.get("T2V_LPR_MIN_N_640", "1920"))}
+
+    def _lpr_takes(self, a, w, out, kw):
+        if not self.linear_pr or any(k in kw for k in ("ln", "lnf", "colstat", "rowstat")) or not hasattr(self.ops, "linear_pr_supported"):
+            return False
+        K, N = a.shape[1], kw["N"]
+        if K not in self.linear_pr_min_n or w.shape[1] != K or w.shape[0] != N or w.stride(0) != K:
+            return False
+        if kw.get("act") != nt.ACT_GEGLU and N < self.linear_pr_min_n[K]:
+            return False
+        return self.ops.linear_pr_supported(a, w, out, **kw) == 1
 
     # LayerNorm as a by-product of the GEMM that produces its input.  Opt-in (T2V_FUSE_LN=1): measured on MI355X it removes 30
     # launches and 0.7 ms of t2v_layernorm per UNet step but adds 0.36 ms to the producing GEMMs (a second 26 MB write in their

@@ -99,6 +99,34 @@ def unpack_conv_slab(w_slab_major, channels, taps=9):
     return w_slab_major[:, :k].reshape(n, channels // 32, taps, 32).permute(0, 2, 1, 3).reshape(n, k).contiguous()
 
 
+def _lpr_row_perm(device=None):
+    """MFMA D-row i of a 32-row block holds output channel 16 ((i >> 2) & 1) + 4 (i >> 3) + (i & 3): a lane's 16 accumulator
+    registers (rows (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) are then the 16 consecutive channels 16 (lane >> 5) + r."""
+    i = torch.arange(32, device=device)
+    return 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)
+
+
+def pack_linear_pr(w):
+    """[N, K] bf16 Linear weights (for GEGLU: the 64-row [32 value | 32 gate] interleave ``Packer.geglu`` makes) -> the FRAGMENT
+    pack of t2v_linear_pr (include/t2v_hip.h): [chunk = n / 64][step = k / 16][block = (n % 64) / 32][lane][8], every (chunk, step,
+    block) the 1 KiB A operand of v_mfma_f32_32x32x16_bf16, lane l = row (l & 31) of the permuted block, K 16 s + 8 (l >> 5) .. + 8.
+    Returned as an [N, K] tensor (same bytes, other order) so that the descriptor plumbing is t2v_gemm's."""
+    n, k = w.shape
+    assert n % 64 == 0 and k % 16 == 0, "t2v_linear_pr: N % 64 == 0, K % 16 == 0"
+    wb = w.reshape(n // 32, 32, k)[:, _lpr_row_perm(w.device), :]          # [block, i, K] with permuted rows
+    wb = wb.reshape(n // 64, 2, 32, k // 16, 2, 8)                          # [q, b, i, s, hk, e]
+    return wb.permute(0, 3, 1, 4, 2, 5).reshape(n, k).contiguous()         # [q, s, b, hk, i, e]: lane = 32 hk + i
+
+
+def unpack_linear_pr(wp):
+    """Inverse of ``pack_linear_pr``."""
+    n, k = wp.shape
+    wb = wp.reshape(n // 64, k // 16, 2, 2, 32, 8).permute(0, 2, 4, 1, 3, 5).reshape(n // 32, 32, k)   # [block, i, K]
+    out = torch.empty_like(wb)
+    out[:, _lpr_row_perm(wp.device), :] = wb
+    return out.reshape(n, k).contiguous()
+
+
 _SIGS = {
     "t2v_version": (C.c_int, []),
     "t2v_init": (C.c_int, []),
@@ -111,6 +139,10 @@ _SIGS = {
     "t2v_conv_halo_force_config": (C.c_int, [C.c_int]),
     "t2v_conv_halo_debug": (C.c_int, [C.c_int]),
     "t2v_conv_halo_pack_cols": (C.c_int, [C.c_int]),
+    "t2v_linear_pr": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "t2v_linear_pr_supported": (C.c_int, [C.POINTER(GemmDesc)]),
+    "t2v_linear_pr_debug": (C.c_int, [C.c_int]),
+    "t2v_linear_pr_force_split": (C.c_int, [C.c_int]),
     "t2v_replay_lookup": (C.c_int, [C.c_char_p]),
     "t2v_replay": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.POINTER(C.c_int)]),
     "t2v_gemm2_enable": (C.c_int, [C.c_int]),
@@ -495,6 +527,18 @@ class HipOps:
         rc = self.lib.t2v_conv_halo_supported(C.byref(self._gemm_desc(a0, w, out, tune_exact=True, **kw)))
         if rc < 0:
             _check(rc, "t2v_conv_halo_supported")
+        return rc
+
+    def linear_pr(self, a0, wp, out, **kw):
+        """A short-K Linear on the panel-resident kernel (csrc/linear_pr.hip): same arguments as ``gemm`` except that ``wp`` is the
+        FRAGMENT pack ``pack_linear_pr`` makes of the [N, K] matrix.  Ask ``linear_pr_supported`` first."""
+        self._call("t2v_linear_pr", C.byref(self._gemm_desc(a0, wp, out, **dict(kw, tile_cfg=-1))))   # (tile_cfg != 0: no tile-table lookup)
+
+    def linear_pr_supported(self, a0, wp, out, **kw):
+        """0: not taken (use ``gemm`` with the plain matrix); 1: taken."""
+        rc = self.lib.t2v_linear_pr_supported(C.byref(self._gemm_desc(a0, wp, out, **dict(kw, tile_cfg=-1))))
+        if rc < 0:
+            _check(rc, "t2v_linear_pr_supported")
         return rc
 
     def gemm_fuse_supported(self, a0, w, out, **kw):

@@ -143,6 +143,27 @@ class EmuOps:
                 gamma, beta, eps, out2 = ln
                 out2[:, :N] = F.layer_norm(y, (N,), gamma.float(), beta.float(), eps).to(out2.dtype)
 
+    # ---- t2v_linear_pr: short-K Linear on the fragment pack (csrc/linear_pr.hip) ---------------------------------------------------
+    def linear_pr_supported(self, a0, wp, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, bias=None, rowvec=None, residual=None,
+                            act=nt.ACT_NONE, alpha=1.0, batch=1, split_k=0, dropout=None, ln=None, rowstat=None, colstat=None, lnf=None,
+                            lora=None, **_):
+        """Mirror of lpr_prepare (csrc/linear_pr.hip): 0 not taken, 1 taken."""
+        if mode != nt.GEMM_LINEAR or a1 is not None or batch > 1 or alpha != 1.0 or split_k > 1 or out.dtype not in (self.act_dtype, torch.bfloat16):
+            return 0
+        if any(v is not None for v in (dropout, ln, rowstat, colstat, lnf, lora, rowvec)) or act not in (nt.ACT_NONE, nt.ACT_GEGLU):
+            return 0
+        if a0.shape[1] not in (320, 640) or N % 64 or a0.stride(0) % 8 or out.stride(0) % 8:
+            return 0
+        if residual is not None and (act == nt.ACT_GEGLU or residual.stride(0) % 8 or M % 32):
+            return 0
+        return 1
+
+    def linear_pr(self, a0, wp, out, **kw):
+        self._log("linear_pr")
+        assert self.linear_pr_supported(a0, wp, out, **kw), "t2v_linear_pr would refuse this launch"
+        kw.pop("tile_cfg", None)
+        self.gemm(a0, nt.unpack_linear_pr(wp[:kw["N"]]), out, **kw)
+
     # ---- t2v_conv_halo: the same 3x3 convolution on the slab-major weight pack (csrc/conv_halo.hip) ----------------------------
     HALO_TILES = ((10, 32, 160, 4), (10, 32, 80, 4), (10, 16, 80, 8), (5, 32, 80, 8), (10, 32, 128, 4))   # (rows, columns, channels, pairs per stage pair)
 

@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "t2v-turbo_amd", "csrc")
 SOURCES = ["backward.hip", "backward_unet.hip", "train.hip", "wgrad_tn.hip"]
-GEMM_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "gemm2.hip"]   # MFMA + LDS-DMA: simulated as wave collectives (separate, slower-to-build library)
-GEMM_HEADERS = ["tile80.h", "gemm2.h"]
+GEMM_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "gemm2.hip", "linear_pr.hip"]   # MFMA + LDS-DMA: simulated as wave collectives (separate, slower-to-build library)
+GEMM_HEADERS = ["tile80.h", "gemm2.h", "gelu_poly.h"]
 OUT = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT, "libt2v_hostsim.so")
 GEMM_LIB = os.path.join(OUT, "libt2v_hostsim_gemm.so")
@@ -41,7 +41,7 @@ def patch(text):
     text = re.sub(r'asm volatile\(""\s*:::\s*"memory"\);', "hostsim::wave_rendezvous();", text)
     text = re.sub(r"__attribute__\(\(ext_vector_type\((\d+)\)\)\)", lambda m: f"__attribute__((vector_size({4 * int(m.group(1))})))", text)
     text = re.sub(r'asm volatile\("s_[^"]*"[^;]*;', ";", text)                 # s_waitcnt vmcnt / s_nop: no asynchrony on the host
-    text = re.sub(r'asm volatile\(""\s*:\s*"\+v"\([^;]*;', ";", text)          # register-pinning barriers
+    text = re.sub(r'asm volatile\(""\s*:\s*"\+[vs]"\([^;]*;', ";", text)       # register-pinning barriers
     text = text.replace('#include "gemm.hip"', '#include "gemm.cpp"')
     return text
 
@@ -72,7 +72,7 @@ def build_gemm(force=False):
     return GEMM_LIB
 
 
-FULL_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "gemm2.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "replay.hip"]
+FULL_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "gemm2.hip", "linear_pr.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "replay.hip"]
 FULL_LIB = os.path.join(OUT, "libt2v_hostsim_full.so")
 
 

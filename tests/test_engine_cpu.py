@@ -260,3 +260,36 @@ def test_train_mode_frozen_teacher_runs_natively_with_replayed_masks():
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert m._auto_route(g["x"], g["ctx"], None, None)[0] == "composite"
+
+
+def test_width_320_transformer_linears_take_the_panel_resident_route():
+    """At model_channels = 320 / 640 the engine sends the GEGLU projection and the q | k | v / q | k launches to t2v_linear_pr with the
+    fragment pack of the same matrices (engine._lpr_takes, native.pack_linear_pr); everything else stays on t2v_gemm.  A two-level UNet
+    (320 and 640 channels) against the module's own torch forward."""
+    for mc, mult in ((320, [1, 2]),):
+        cfg = tiny_unet_params(model_channels=mc, channel_mult=mult, num_res_blocks=1, attention_resolutions=[1, 2], context_dim=64)
+        torch.manual_seed(3)
+        m = UNetModel(**cfg).eval()
+        with torch.no_grad():
+            for p in m.parameters():   # (zero-initialised output projections would hide the transformer blocks)
+                if p.abs().max() == 0:
+                    p.normal_(0.0, 0.02)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(1, 4, 2, 8, 8, generator=g)
+        ts = torch.tensor([500])
+        ctx = torch.randn(1, 7, 64, generator=g)
+        ops = EmuOps()
+        eng = UNetEngine(m, ops)
+        with torch.no_grad():
+            y = eng(x, ts, ctx, 16, None, None)
+            ref = m(x, ts, context=ctx, fps=16)
+        assert rel_l2(y, ref) < 2e-5
+        n_lpr = ops.calls.count("linear_pr")
+        # per transformer pair: spatial block q|k (320 only: N = 1280 < 1920 at 640) + GEGLU, temporal block 2 x q|k|v + GEGLU
+        assert n_lpr >= 12, n_lpr
+        eng.linear_pr = False
+        eng.plans.clear()
+        ops.calls.clear()
+        with torch.no_grad():
+            y0 = eng(x, ts, ctx, 16, None, None)
+        assert "linear_pr" not in ops.calls and rel_l2(y0, y) < 1e-6

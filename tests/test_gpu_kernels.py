@@ -644,3 +644,67 @@ def test_conv_halo_unet_level_shapes_repeatable(pair):
     _halo_case(pair, n_img=2, h=40, w=64, c0=320, N=320, rowvec=True, residual=True, colstat=True, seed=10, repeat=3)
     _halo_case(pair, n_img=2, h=20, w=32, c0=1280, c1=640, N=640, colstat=True, seed=11, repeat=3)
     _halo_case(pair, n_img=2, h=10, w=16, c0=1280, N=1280, rowvec=True, residual=True, colstat=True, seed=12, repeat=3)
+
+
+# ---- t2v_linear_pr: short-K Linear with the activation panel resident in LDS (csrc/linear_pr.hip) ------------------------------------
+def _lpr_case(pair, *, M, K, N, act=0, bias=True, residual=False, ny=0, seed=0, repeat=1, lda=None, ldo=None):
+    """t2v_linear_pr on the fragment pack against the emulated Linear on the same bf16-rounded data (tests/emu_ops.py::linear_pr);
+    ``repeat`` back-to-back launches into the same output (the weight ring and the residual prefetch run ahead of the stores)."""
+    from t2v_turbo_amd import native as nt
+    n_out = N // 2 if act == nt.ACT_GEGLU else N
+    a = _rt(M, lda or K, seed=seed)
+    w = _rt(N, K, seed=seed + 1, scale=K ** -0.5)
+    b = _rt(N, seed=seed + 2) if bias else None
+    res = _rt(M, n_out, seed=seed + 3) if residual else None
+    outs = []
+    pair.hip.lib.t2v_linear_pr_force_split(ny)
+    try:
+        for side, ops in enumerate((pair.hip, pair.emu)):
+            cvt = (lambda t: None if t is None else t.cuda().bfloat16().contiguous()) if side == 0 else (lambda t: None if t is None else t.clone())
+            f32 = (lambda t: None if t is None else t.cuda().float().contiguous()) if side == 0 else (lambda t: None if t is None else t.clone())
+            dev = "cuda" if side == 0 else "cpu"
+            out_full = torch.full((M, ldo or n_out), float("nan"), device=dev, dtype=torch.bfloat16 if side == 0 else torch.float32)
+            out = out_full[:, :n_out]
+            wp = cvt(nt.pack_linear_pr(w.bfloat16()).float())
+            kw = dict(M=M, N=N, bias=f32(b), residual=cvt(res), act=act)
+            x = cvt(a)[:, :K]
+            assert ops.linear_pr_supported(x, wp, out, **kw) == 1
+            for _ in range(repeat if side == 0 else 1):
+                ops.linear_pr(x, wp, out, **kw)
+            if side == 0:
+                torch.cuda.synchronize()
+            outs.append(out.float().cpu())
+            if ldo:
+                assert torch.isnan(out_full[:, n_out:].float()).all()
+    finally:
+        pair.hip.lib.t2v_linear_pr_force_split(0)
+    y, r = outs
+    assert torch.isfinite(y).all()
+    assert rel_l2(y, r) < BF16_TOL, rel_l2(y, r)
+    assert (y - r).abs().max() < 0.05 * r.abs().max()
+
+
+def test_linear_pr_unet_shapes_repeatable(pair):
+    # the launches the engine routes here, at full size: GEGLU projections and q | k | v / q | k of the 320- and 640-channel levels
+    from t2v_turbo_amd import native as nt
+    _lpr_case(pair, M=40960, K=320, N=2560, act=nt.ACT_GEGLU, seed=1, repeat=3)
+    _lpr_case(pair, M=40960, K=320, N=960, bias=False, seed=2, repeat=2)
+    _lpr_case(pair, M=40960, K=320, N=640, bias=False, seed=3)
+    _lpr_case(pair, M=10240, K=640, N=5120, act=nt.ACT_GEGLU, seed=4, repeat=3)
+    _lpr_case(pair, M=10240, K=640, N=1920, bias=False, seed=5, repeat=2)
+
+
+def test_linear_pr_residual_and_few_chunks(pair):
+    # N = C with bias + residual (five / ten chunks: idle waves, the residual tile as the first step's C operand), without either
+    _lpr_case(pair, M=40960, K=320, N=320, residual=True, seed=6, repeat=2)
+    _lpr_case(pair, M=10240, K=640, N=640, residual=True, seed=7, repeat=2)
+    _lpr_case(pair, M=2560, K=320, N=320, bias=False, seed=8)
+    _lpr_case(pair, M=10240, K=640, N=1280, residual=True, ny=3, seed=9)
+
+
+def test_linear_pr_ragged_rows_strides_and_splits(pair):
+    from t2v_turbo_amd import native as nt
+    _lpr_case(pair, M=1000, K=320, N=1280, act=nt.ACT_GEGLU, seed=10)                 # ragged last panel
+    _lpr_case(pair, M=333, K=640, N=1024, act=nt.ACT_GEGLU, ny=2, seed=11)            # ragged, two workgroup rows
+    _lpr_case(pair, M=4000, K=320, N=960, seed=12, lda=384, ldo=1024)                 # operands as column slices of wider buffers
+    _lpr_case(pair, M=992, K=640, N=640, residual=True, seed=13)                      # residual + a last panel with one block of three
