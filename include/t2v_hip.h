@@ -197,16 +197,6 @@ int t2v_linear_pr(const t2v_gemm_desc* d, void* stream);
 int t2v_linear_pr_supported(const t2v_gemm_desc* d);
 int t2v_linear_pr_debug(int bits);         /* ablation bits; honoured by -DT2V_LPR_ABLATE tool builds only */
 int t2v_linear_pr_force_split(int ny);     /* tuning hook: column splits (workgroup rows) for every following call, 0 = library rule */
-/* The narrow Linears (N = 320 / 640 / ...: a multiple of 320) of any depth K (a multiple of 64, >= 128) with the ACCUMULATORS resident and
- * the activations streamed through LDS in 64-deep K slabs (csrc/linear_pr.hip, second kernel): the attention output projections, proj_in /
- * proj_out and the feed-forward output projection (lvdm/modules/attention.py:164, :373-389, :471-513, :537-542) — HBM-bound launches.
- * Same descriptor and the same FRAGMENT pack of the weights as t2v_linear_pr; epilogue: bias, optional residual (M % 32 == 0), optional
- * rowstat_out (the row statistics of the next LayerNorm, as t2v_gemm writes them); no activation, no column statistics.
- * t2v_linear_os_supported: 0 = not taken, 1 = taken, negative = invalid descriptor.  t2v_linear_os_force_rows: tuning hook (token blocks of
- * 32 rows per workgroup: 5 or 3; 0 = library rule). */
-int t2v_linear_os(const t2v_gemm_desc* d, void* stream);
-int t2v_linear_os_supported(const t2v_gemm_desc* d);
-int t2v_linear_os_force_rows(int blocks);
 /* tuning/test hooks: override tile id / split-K factor for every following call (0 = off) */
 int t2v_gemm_force_config(int cfg);
 /* t2v_gemm's second kernel family (csrc/gemm2.hip: static-schedule main loop, 80x80 wave tiles; tile ids 50 = 320x160, 51 = 160x160)

@@ -405,191 +405,6 @@ int lpr_launch(const LprParams& p, int tiles_m, int ny, hipStream_t s) {
     return T2V_OK;
 }
 
-
-// ======================================================================================================================================
-// t2v_linear_os — OUTPUT-STATIONARY twin for the narrow launches (N = C: to_out, proj_in / proj_out, the feed-forward output projection;
-// lvdm/modules/attention.py:164, :373-389, :471-513, :537-542).  Those are bound by HBM (M x K in, M x N in + out) and, at K = 4 C, far
-// too deep for a resident panel.  Here the ACCUMULATORS are what stays put: a workgroup owns BM token rows x 320 output channels — ten
-// waves, one 32-channel block each (acc = TB x 16 registers) — for the whole K loop; the activations stream through a three-slot LDS ring
-// in 64-deep K slabs (global -> registers two slabs ahead -> LDS one slab ahead; ONE barrier per slab), the weights go straight into
-// registers from the same fragment pack as t2v_linear_pr (block n / 32 of the pack is the wave's).  bias + residual start the
-// accumulators (requested before the first slab is written, consumed as the C operand of the first step): the epilogue is pack + store,
-// plus the row statistics of the next LayerNorm where asked for.
-// ======================================================================================================================================
-constexpr int kLosWaves = 10;     // computing waves: one 32-channel block each
-constexpr int kLosLoaders = 2;    // loader waves: the activation slabs, global -> registers -> LDS
-constexpr int kLosSlots = 3;
-constexpr int kLosAhead = 3;      // slabs a loader keeps in flight in registers
-
-// TB: 32-token blocks per workgroup (BM = 32 TB); RES: a residual operand; RST: row statistics of the output (rowstat_out).
-// Why loader WAVES: a wave's vector-memory operations retire in order (one counter), so a weight fragment requested from L2 after an
-// activation slab requested from HBM is not "there" before the slab is — with both kinds in one wave every K step waited out an HBM
-// round trip (first version of this kernel: 52.6 us at 40960 x 320 x 1280 against 45.3 for t2v_gemm).  The computing waves issue nothing
-// but their L2-resident weight fragments; the two loaders issue nothing but the slabs, three of them ahead.
-template <int TB, bool RES, bool RST>
-__global__ __launch_bounds__((kLosWaves + kLosLoaders) * 64) __attribute__((amdgpu_waves_per_eu(3, 3))) void linear_os_kernel(const LprParams p) {
-    constexpr int BM = 32 * TB, D = 4;   // weight ring: a slab is exactly one period (4 steps)
-    constexpr int SLAB_BYTES = BM * 64 * 2;                       // 64 K columns of the rows: [8 chunks of 8 K][BM][16 B]
-    constexpr int PIECES = BM / 8, PPL = (PIECES + kLosLoaders - 1) / kLosLoaders;   // 8 rows x 128 B per wave instruction
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const t2v_gemm_desc& d = p.d;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = blockIdx.x * BM;
-    const int K = d.c0, KS = K >> 4, nslab = K >> 6;              // (host-checked: K % 64 == 0, >= 128)
-
-    if (wave >= kLosWaves) {
-        // ================================= loader: slab s = K columns 64 s .. of my rows ===========================================
-        // piece pc = rows 8 pc .. + 8, all 128 bytes; lane -> row 8 pc + (lane & 7), 16-byte chunk lane >> 3 (whole cache lines per
-        // instruction; eight consecutive lanes write 128 contiguous LDS bytes of the [chunk][row] image)
-        const int lw = wave - kLosWaves;
-        const bf16_t* a = (const bf16_t*)d.a0;
-        uint4 stage[kLosAhead][PPL];
-        unsigned a_goff[PPL];   // element offset of my piece rows in A (slab 0); rows past M re-read the last row (zeros are written)
-#pragma unroll
-        for (int j = 0; j < PPL; ++j) {
-            const int row = 8 * (lw + kLosLoaders * j) + (lane & 7);
-            a_goff[j] = (unsigned)(min(m0 + row, d.M - 1) * d.lda0 + (lane >> 3) * 8);
-        }
-        static_assert(PIECES % kLosLoaders == 0, "every loader moves the same number of pieces: no guards in the loops below");
-        // (branch-free: a slab past the end re-reads the last one and is written into a slot nobody reads any more)
-        auto load_slab = [&](int sl, int which) {
-            const int off = min(sl, nslab - 1) * 64;
-#pragma unroll
-            for (int j = 0; j < PPL; ++j) stage[which][j] = *(const uint4*)(a + a_goff[j] + off);
-        };
-        auto write_slab = [&](int slot, int which) {
-#pragma unroll
-            for (int j = 0; j < PPL; ++j) {
-                const int row = 8 * (lw + kLosLoaders * j) + (lane & 7);
-                *(uint4*)(smem + slot * SLAB_BYTES + ((lane >> 3) * BM + row) * 16) = m0 + row < d.M ? stage[which][j] : make_uint4(0u, 0u, 0u, 0u);
-            }
-        };
-#pragma unroll
-        for (int q = 0; q < kLosAhead; ++q) load_slab(q, q);
-        write_slab(0, 0);
-        load_slab(kLosAhead, 0);
-        __syncthreads();
-        // iteration s: slab s + 1 (in registers) -> its slot (last read in iteration s - 2, a barrier ago); slab s + 1 + kLosAhead requested
-        // into the freed registers; the barrier.  (Unrolled over kLosAhead = kLosSlots = 3 slabs: stage and slot are constants.)
-        static_assert(kLosAhead == 3 && kLosSlots == 3, "the loop below is unrolled for three register stages and three slots");
-        for (int s0 = 0; s0 < nslab; s0 += 3) {
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int s = s0 + u;
-                if (s < nslab) {
-                    write_slab((u + 1) % 3, (u + 1) % 3);
-                    load_slab(s + 1 + kLosAhead, (u + 1) % 3);
-                    __syncthreads();
-                }
-            }
-        }
-        return;
-    }
-
-    // ===================================== computing wave: 32 TB tokens x channels 32 blk .. ===============================================
-    const int blk = blockIdx.y * kLosWaves + wave;
-    const int h = lane >> 5, l31 = lane & 31;
-    // weights: my block's fragments, D - 1 steps ahead (pack: [chunk][step][2 blocks][lane][16 B])
-    const char* wl = (const char*)d.w + ((long long)(blk >> 1) * KS * 2 + (blk & 1)) * 1024 + lane * 16;   // step s: + s * 2048
-    bf16x8_t wr[D], af[TB];
-#pragma unroll
-    for (int s = 0; s < D - 1; ++s) wr[s] = *(const bf16x8_t*)(wl + s * 2048);
-    // accumulators start at bias (+ residual): lane = 16 consecutive channels 32 blk + 16 h .. of token 32 i + l31
-    f32x16_t acc[TB];
-    {
-        f32x16_t bv;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 t = d.bias ? *(const float4*)(d.bias + blk * 32 + 16 * h + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bv[4 * q] = t.x; bv[4 * q + 1] = t.y; bv[4 * q + 2] = t.z; bv[4 * q + 3] = t.w;
-        }
-        uint4 rr[RES ? TB : 1][2];
-        if constexpr (RES) {   // (host-checked: M % 32 == 0 — a block is whole or absent; an absent one reads the workgroup's first)
-#pragma unroll
-            for (int i = 0; i < TB; ++i) {
-                const int row0 = m0 + 32 * i < d.M ? m0 + 32 * i : m0;
-                const bf16_t* rp = (const bf16_t*)d.residual + (long long)(row0 + l31) * d.ldr + blk * 32 + 16 * h;
-                rr[i][0] = *(const uint4*)rp;
-                rr[i][1] = *(const uint4*)(rp + 8);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < TB; ++i) {
-            acc[i] = bv;
-            if constexpr (RES) {
-                float r[16];
-                unpack8(rr[i][0], r);
-                unpack8(rr[i][1], r + 8);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][e] += r[e];
-            }
-        }
-    }
-    __syncthreads();
-
-    // K loop: the four steps of slab s from slot s % 3, then the one barrier
-    const unsigned a_off = (unsigned)((h * BM + l31) * 16);
-    int step = 0;
-    for (int s0 = 0; s0 < nslab; s0 += 3) {
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            if (s0 + u < nslab) {
-                const char* ab = smem + u * SLAB_BYTES + a_off;
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4) {
-                    // weights of step + D - 1 (past the end: the last step again, never used)
-                    wr[(k4 + D - 1) % D] = *(const bf16x8_t*)(wl + (long long)min(step + D - 1, KS - 1) * 2048);
-#pragma unroll
-                    for (int i = 0; i < TB; ++i) af[i] = *(const bf16x8_t*)(ab + k4 * (2 * BM * 16) + i * 512);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < TB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[k4], af[i], acc[i], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    ++step;
-                }
-                __syncthreads();
-            }
-        }
-    }
-
-    // epilogue: pack + store (+ row statistics)
-    bf16_t* const obase = (bf16_t*)d.out;
-#pragma unroll
-    for (int i = 0; i < TB; ++i) {
-        const int gm = m0 + 32 * i + l31;
-        float v[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = acc[i][e];
-        if constexpr (RST) {   // (sum, sum of squares) of the fp32 values of this row's 32-column block: my 16 + the other half's 16
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { s1 += v[e]; s2 = fmaf(v[e], v[e], s2); }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (h == 0 && gm < d.M) *(float2*)(d.rowstat_out + (long long)gm * d.ld_rowstat + 2 * blk) = make_float2(s1, s2);
-        }
-        if (gm < d.M) {
-            bf16_t* op = obase + (long long)gm * d.ldo + blk * 32 + 16 * h;
-            *(uint4*)op = pack8(v);
-            *(uint4*)(op + 8) = pack8(v + 8);
-        }
-    }
-}
-
-template <int TB, bool RES, bool RST>
-int los_launch(const LprParams& p, int tiles_m, int ny, hipStream_t s) {
-    const int smem = kLosSlots * 32 * TB * 64 * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute((const void*)linear_os_kernel<TB, RES, RST>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((linear_os_kernel<TB, RES, RST>), dim3(tiles_m, ny), dim3((kLosWaves + kLosLoaders) * 64), smem, s, p);
-    T2V_CHECK_LAUNCH();
-    return T2V_OK;
-}
-
 }  // namespace
 
 static int g_lpr_debug = 0, g_lpr_force_ny = 0;
@@ -650,57 +465,4 @@ extern "C" int t2v_linear_pr(const t2v_gemm_desc* dd, void* stream) {
     const int epi = p.d.act == T2V_ACT_GEGLU ? 1 : (p.d.residual ? 2 : 0);
     if (cfg == 1) return epi == 1 ? lpr_launch<5, 20, 1>(p, tiles_m, ny, s) : (epi == 2 ? lpr_launch<5, 20, 2>(p, tiles_m, ny, s) : lpr_launch<5, 20, 0>(p, tiles_m, ny, s));
     return epi == 1 ? lpr_launch<3, 40, 1>(p, tiles_m, ny, s) : (epi == 2 ? lpr_launch<3, 40, 2>(p, tiles_m, ny, s) : lpr_launch<3, 40, 0>(p, tiles_m, ny, s));
-}
-
-// t2v_linear_os geometry.  cfg: 0 = not taken, else the token blocks per workgroup (5: 160 rows, 3: 96 rows).
-static int g_los_force_tb = 0;
-extern "C" int t2v_linear_os_force_rows(int tb) { g_los_force_tb = tb; return T2V_OK; }
-static int los_prepare(const t2v_gemm_desc* dd, LprParams& p, int& cfg, int& tiles_m, int& ny) {
-    cfg = 0;
-    T2V_REQUIRE(dd && dd->a0 && dd->w && dd->out, T2V_EINVAL, "t2v_linear_os: null pointer");
-    p.d = *dd;
-    const t2v_gemm_desc& d = p.d;
-    if (d.mode != T2V_GEMM_LINEAR || d.a1 || d.c1 || d.batch > 1 || d.alpha != 1.0f || d.out_f32 || d.split_k > 1 || d.drop_thr || d.ln_out ||
-        d.colstat_out || d.lnf_stats || d.lora_t || d.rowvec || d.act != T2V_ACT_NONE)
-        return T2V_OK;
-    if (d.c0 < 128 || d.c0 % 64 || d.M <= 0 || d.N <= 0 || d.N % 320 || d.lda0 % 8 || d.ldo % 8) return T2V_OK;
-    if (((uintptr_t)d.a0 | (uintptr_t)d.w | (uintptr_t)d.out) % 16) return T2V_OK;
-    if (d.residual && (d.ldr % 8 || (uintptr_t)d.residual % 16 || d.M % 32)) return T2V_OK;
-    if (d.bias && (uintptr_t)d.bias % 16) return T2V_OK;
-    if (d.rowstat_out && (d.ld_rowstat % 2 || d.ld_rowstat < d.N / 16 || (uintptr_t)d.rowstat_out % 8)) return T2V_OK;
-    if ((long long)d.M * d.lda0 >= (1ll << 31)) return T2V_OK;   // 32-bit element offsets of the activation rows
-    ny = d.N / 320;
-    // rows per workgroup: 160 where that fills the chip (M >= 160 x 256 / ny), else 96
-    int tb = (long long)((d.M + 159) / 160) * ny >= 200 ? 5 : 3;
-    if (g_los_force_tb == 3 || g_los_force_tb == 5) tb = g_los_force_tb;
-    tiles_m = (d.M + 32 * tb - 1) / (32 * tb);
-    p.chunks = d.N / 64;
-    p.chunks_per_y = 5;
-    p.n_out = d.N;
-    p.debug = g_lpr_debug;
-    cfg = tb;
-    return T2V_OK;
-}
-
-extern "C" int t2v_linear_os_supported(const t2v_gemm_desc* dd) {
-    LprParams p;
-    int cfg = 0, tiles_m = 0, ny = 0;
-    const int rc = los_prepare(dd, p, cfg, tiles_m, ny);
-    return rc != T2V_OK ? rc : (cfg > 0 ? 1 : 0);
-}
-
-extern "C" int t2v_linear_os(const t2v_gemm_desc* dd, void* stream) {
-    LprParams p;
-    int cfg = 0, tiles_m = 0, ny = 0;
-    const int rc = los_prepare(dd, p, cfg, tiles_m, ny);
-    if (rc != T2V_OK) return rc;
-    T2V_REQUIRE(cfg > 0, T2V_ESHAPE, "t2v_linear_os: this launch is not taken by the output-stationary kernel (ask t2v_linear_os_supported first)");
-    hipStream_t s = (hipStream_t)stream;
-    const bool res = p.d.residual != nullptr, rst = p.d.rowstat_out != nullptr;
-    if (cfg == 5) {
-        if (res) return rst ? los_launch<5, true, true>(p, tiles_m, ny, s) : los_launch<5, true, false>(p, tiles_m, ny, s);
-        return rst ? los_launch<5, false, true>(p, tiles_m, ny, s) : los_launch<5, false, false>(p, tiles_m, ny, s);
-    }
-    if (res) return rst ? los_launch<3, true, true>(p, tiles_m, ny, s) : los_launch<3, true, false>(p, tiles_m, ny, s);
-    return rst ? los_launch<3, false, true>(p, tiles_m, ny, s) : los_launch<3, false, false>(p, tiles_m, ny, s);
 }

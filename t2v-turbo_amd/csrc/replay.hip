@@ -57,7 +57,7 @@ struct Entry { const char* name; int (*call)(const uint64_t*, int, void*); };
 #define T2V_ENTRY(f) {#f, &Thunk<&f>::call}
 // every launching entry point of include/t2v_hip.h (stream last)
 const Entry kTable[] = {
-    T2V_ENTRY(t2v_gemm), T2V_ENTRY(t2v_conv_halo), T2V_ENTRY(t2v_linear_pr), T2V_ENTRY(t2v_linear_os), T2V_ENTRY(t2v_ffn_fused), T2V_ENTRY(t2v_conv3x3_small_cin), T2V_ENTRY(t2v_gn_stats),
+    T2V_ENTRY(t2v_gemm), T2V_ENTRY(t2v_conv_halo), T2V_ENTRY(t2v_linear_pr), T2V_ENTRY(t2v_ffn_fused), T2V_ENTRY(t2v_conv3x3_small_cin), T2V_ENTRY(t2v_gn_stats),
     T2V_ENTRY(t2v_gn_apply), T2V_ENTRY(t2v_group_norm), T2V_ENTRY(t2v_group_norm_cs), T2V_ENTRY(t2v_gn_stats_cs), T2V_ENTRY(t2v_layernorm),
     T2V_ENTRY(t2v_softmax_rows), T2V_ENTRY(t2v_attn_spatial), T2V_ENTRY(t2v_attn_temporal), T2V_ENTRY(t2v_ncfhw_to_tokens),
     T2V_ENTRY(t2v_tokens_to_ncfhw), T2V_ENTRY(t2v_timestep_embedding), T2V_ENTRY(t2v_silu), T2V_ENTRY(t2v_fill_zero), T2V_ENTRY(t2v_cast),

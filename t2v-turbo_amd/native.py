@@ -143,9 +143,6 @@ _SIGS = {
     "t2v_linear_pr_supported": (C.c_int, [C.POINTER(GemmDesc)]),
     "t2v_linear_pr_debug": (C.c_int, [C.c_int]),
     "t2v_linear_pr_force_split": (C.c_int, [C.c_int]),
-    "t2v_linear_os": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
-    "t2v_linear_os_supported": (C.c_int, [C.POINTER(GemmDesc)]),
-    "t2v_linear_os_force_rows": (C.c_int, [C.c_int]),
     "t2v_replay_lookup": (C.c_int, [C.c_char_p]),
     "t2v_replay": (C.c_int, [C.c_void_p, C.c_longlong, C.c_void_p, C.POINTER(C.c_int)]),
     "t2v_gemm2_enable": (C.c_int, [C.c_int]),
@@ -542,17 +539,6 @@ class HipOps:
         rc = self.lib.t2v_linear_pr_supported(C.byref(self._gemm_desc(a0, wp, out, **dict(kw, tile_cfg=-1))))
         if rc < 0:
             _check(rc, "t2v_linear_pr_supported")
-        return rc
-
-    def linear_os(self, a0, wp, out, **kw):
-        """A narrow Linear (N a multiple of 320, any K % 64 == 0) on the output-stationary kernel (csrc/linear_pr.hip, second kernel):
-        same arguments and the same fragment pack as ``linear_pr``; bias, residual, ``rowstat``.  Ask ``linear_os_supported`` first."""
-        self._call("t2v_linear_os", C.byref(self._gemm_desc(a0, wp, out, **dict(kw, tile_cfg=-1))))
-
-    def linear_os_supported(self, a0, wp, out, **kw):
-        rc = self.lib.t2v_linear_os_supported(C.byref(self._gemm_desc(a0, wp, out, **dict(kw, tile_cfg=-1))))
-        if rc < 0:
-            _check(rc, "t2v_linear_os_supported")
         return rc
 
     def gemm_fuse_supported(self, a0, w, out, **kw):

@@ -164,39 +164,6 @@ class EmuOps:
         kw.pop("tile_cfg", None)
         self.gemm(a0, nt.unpack_linear_pr(wp[:kw["N"]]), out, **kw)
 
-    def linear_os_supported(self, a0, wp, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, bias=None, rowvec=None, residual=None,
-                            act=nt.ACT_NONE, alpha=1.0, batch=1, split_k=0, dropout=None, ln=None, rowstat=None, colstat=None, lnf=None,
-                            lora=None, **_):
-        """Mirror of los_prepare (csrc/linear_pr.hip): 0 not taken, 1 taken."""
-        if mode != nt.GEMM_LINEAR or a1 is not None or batch > 1 or alpha != 1.0 or split_k > 1 or out.dtype not in (self.act_dtype, torch.bfloat16):
-            return 0
-        if any(v is not None for v in (dropout, ln, colstat, lnf, lora, rowvec)) or act != nt.ACT_NONE:
-            return 0
-        K = a0.shape[1]
-        if K < 128 or K % 64 or N % 320 or a0.stride(0) % 8 or out.stride(0) % 8:
-            return 0
-        if residual is not None and (residual.stride(0) % 8 or M % 32):
-            return 0
-        if rowstat is not None and (rowstat.stride(0) % 2 or rowstat.stride(0) < N // 16):
-            return 0
-        return 1
-
-    def linear_os(self, a0, wp, out, **kw):
-        self._log("linear_os")
-        assert self.linear_os_supported(a0, wp, out, **kw), "t2v_linear_os would refuse this launch"
-        kw.pop("tile_cfg", None)
-        rowstat = kw.pop("rowstat", None)
-        self.gemm(a0, nt.unpack_linear_pr(wp[:kw["N"]]), out, **kw)
-        if rowstat is not None:   # (sum, sumsq) of the fp32 epilogue values per row and 32-column block — recomputed here in fp32
-            M, N = kw["M"], kw["N"]
-            y = a0[:M].float() @ nt.unpack_linear_pr(wp[:N]).float().t()
-            if kw.get("bias") is not None:
-                y = y + kw["bias"].float()[None, :N]
-            if kw.get("residual") is not None:
-                y = y + kw["residual"][:M, :N].float()
-            yb = y.reshape(M, N // 32, 32)
-            rowstat[:, :2 * (N // 32)] = torch.stack([yb.sum(dim=2), (yb * yb).sum(dim=2)], dim=2).reshape(M, -1)
-
     # ---- t2v_conv_halo: the same 3x3 convolution on the slab-major weight pack (csrc/conv_halo.hip) ----------------------------
     HALO_TILES = ((10, 32, 160, 4), (10, 32, 80, 4), (10, 16, 80, 8), (5, 32, 80, 8), (10, 32, 128, 4))   # (rows, columns, channels, pairs per stage pair)
 

@@ -111,63 +111,3 @@ def test_not_taken_cases(sim):
         assert ops.linear_pr_supported(a[:40], wp, out[:40], M=40, N=128, residual=out[:40]) == 0       # residual with M % 32 != 0
     with pytest.raises(nt.NativeError):
         sim.linear_pr(a, wp, out, M=64, N=128, alpha=0.5)
-
-
-# ---- t2v_linear_os: the output-stationary twin (N a multiple of 320, activations streamed in 64-deep K slabs) -----------------------
-def _os_case(sim, *, M, K, N, bias=True, residual=False, rowstat=False, rows=0, seed=0, lda=None, ldo=None):
-    a_full = _rt(M, lda or K, seed=seed).bfloat16()
-    a = a_full[:, :K]
-    w = _rt(N, K, seed=seed + 1, scale=K ** -0.5).bfloat16()
-    wp = nt.pack_linear_pr(w)
-    b = _rt(N, seed=seed + 2) if bias else None
-    res = _rt(M, N, seed=seed + 3).bfloat16() if residual else None
-    outs, stats = [], []
-    sim.lib.t2v_linear_os_force_rows(rows)
-    try:
-        for ops in (sim, EMU):
-            out_full = torch.full((M, ldo or N), float("nan")).bfloat16()
-            out = out_full[:, :N]
-            rs = torch.full((M, N // 16), float("nan")) if rowstat else None
-            kw = dict(M=M, N=N, bias=b, residual=res)
-            if rowstat:
-                kw["rowstat"] = rs
-            assert ops.linear_os_supported(a, wp, out, **kw) == 1, "the output-stationary kernel refuses the case"
-            ops.linear_os(a, wp, out, **kw)
-            outs.append(out.float())
-            stats.append(rs)
-            if ldo:
-                assert torch.isnan(out_full[:, N:].float()).all()
-    finally:
-        sim.lib.t2v_linear_os_force_rows(0)
-    y, r = outs
-    assert torch.isfinite(y).all()
-    assert rel_l2(y, r) < BF16_TOL, rel_l2(y, r)
-    assert (y - r).abs().max() < 0.05 * r.abs().max()
-    if rowstat:
-        assert torch.allclose(stats[0], stats[1], rtol=2e-3, atol=2e-2), (stats[0] - stats[1]).abs().max()
-
-
-def test_os_k320_and_k1280_on_160_row_workgroups(sim):
-    # K = 320: five slabs (the ring of three wraps); K = 1280: twenty; ragged rows; residual; row statistics
-    _os_case(sim, M=160 + 96, K=320, N=320, residual=True, rowstat=True, rows=5, seed=21)
-    _os_case(sim, M=200, K=1280, N=320, rows=5, seed=22)
-
-
-def test_os_96_row_workgroups_two_channel_groups(sim):
-    # N = 640: two workgroup rows of ten waves; 96-row workgroups (the library's choice at small M); no bias
-    _os_case(sim, M=96 * 2 + 64, K=640, N=640, residual=True, seed=23)
-    _os_case(sim, M=100, K=128, N=640, bias=False, rowstat=True, seed=24)          # two slabs only; ragged rows without a residual
-    _os_case(sim, M=64, K=192, N=320, seed=25, lda=256, ldo=384)                   # three slabs, strided operands
-
-
-def test_os_not_taken_cases(sim):
-    a = _rt(64, 320).bfloat16()
-    out = torch.empty(64, 320).bfloat16()
-    wp = nt.pack_linear_pr(_rt(320, 320).bfloat16())
-    for ops in (sim, EMU):
-        assert ops.linear_os_supported(a, wp, out, M=64, N=320) == 1
-        assert ops.linear_os_supported(a, wp, out[:, :256], M=64, N=256) == 0            # N % 320
-        assert ops.linear_os_supported(a[:, :64], wp, out, M=64, N=320) == 0             # K < 128
-        assert ops.linear_os_supported(a, wp, out[:, :160], M=64, N=320, act=nt.ACT_GEGLU) == 0
-        assert ops.linear_os_supported(a[:40], wp, out[:40], M=40, N=320, residual=out[:40]) == 0
-        assert ops.linear_os_supported(a, wp, out, M=64, N=320, colstat=torch.zeros(2, 320, 2)) == 0

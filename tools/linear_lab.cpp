@@ -62,12 +62,10 @@ static Lib load_lib(const std::string& path) {
     l.h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!l.h) { fprintf(stderr, "dlopen %s: %s\n", path.c_str(), dlerror()); exit(1); }
     l.gemm = (int (*)(const t2v_gemm_desc*, void*))dlsym(l.h, "t2v_gemm");
-    // LAB_OS=1: the second column is t2v_linear_os (the output-stationary kernel) instead of t2v_linear_pr; ny then = rows hook (5 / 3 / 0)
-    const bool os_mode = getenv("LAB_OS") != nullptr;
-    l.lpr = (int (*)(const t2v_gemm_desc*, void*))dlsym(l.h, os_mode ? "t2v_linear_os" : "t2v_linear_pr");
-    l.lpr_ok = (int (*)(const t2v_gemm_desc*))dlsym(l.h, os_mode ? "t2v_linear_os_supported" : "t2v_linear_pr_supported");
+    l.lpr = (int (*)(const t2v_gemm_desc*, void*))dlsym(l.h, "t2v_linear_pr");
+    l.lpr_ok = (int (*)(const t2v_gemm_desc*))dlsym(l.h, "t2v_linear_pr_supported");
     l.lpr_debug = (int (*)(int))dlsym(l.h, "t2v_linear_pr_debug");
-    l.lpr_split = (int (*)(int))dlsym(l.h, os_mode ? "t2v_linear_os_force_rows" : "t2v_linear_pr_force_split");
+    l.lpr_split = (int (*)(int))dlsym(l.h, "t2v_linear_pr_force_split");
     l.init = (int (*)())dlsym(l.h, "t2v_init");
     l.last_error = (const char* (*)())dlsym(l.h, "t2v_last_error");
     if (!l.gemm || !l.lpr || !l.init) { fprintf(stderr, "%s: missing symbols\n", path.c_str()); exit(1); }
