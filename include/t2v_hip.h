@@ -155,6 +155,13 @@ typedef struct t2v_gemm_desc {
     int ld_lora_u;
     int lora_n_leaf;
     float lora_scale;
+    /* ---- LayerNorm of the INPUT rows, applied while the activation panel is filled (t2v_linear_pr only; 0 = off) ---------------------
+     * ln_in != 0: the launch computes epilogue( LayerNorm(A)[M, K] x W^T ) with LayerNorm over the K = c0 columns of every A row
+     * (ln_gamma / ln_beta fp32 [K], ln_eps; two-pass fp32 statistics, the normalised rows rounded to bf16 exactly as a t2v_layernorm
+     * launch would have written them): norm1 / norm2 / norm3 of BasicTransformerBlock (attention.py:300-311) where their output feeds
+     * ONE Linear — no LayerNorm launch, no normalised tensor in memory.  ln_out must be NULL; not combined with a residual.
+     * t2v_gemm and t2v_conv_halo refuse a descriptor with ln_in set. */
+    int ln_in;
 } t2v_gemm_desc;
 
 int t2v_gemm(const t2v_gemm_desc* d, void* stream);

@@ -88,8 +88,8 @@ __device__ __forceinline__ void lpr_static_for(F&& f) {
 }
 
 // TB: 32-token blocks per panel; KS: 16-deep K steps; EPI: 0 = bias, 1 = bias -> GEGLU (chunk = [32 value rows | 32 gate rows] -> 32
-// output columns), 2 = bias + residual
-template <int TB, int KS, int EPI>
+// output columns), 2 = bias + residual; LNIN: the panel holds LayerNorm(A rows) (t2v_gemm_desc::ln_in), normalised as it is filled
+template <int TB, int KS, int EPI, bool LNIN>
 __global__ __launch_bounds__(kLprWaves * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_pr_kernel(const LprParams p) {
     constexpr int BM = 32 * TB, K = 16 * KS, D = kLprRing;
     // XPF: the weight ring runs on across chunk boundaries (the first D - 1 steps of the wave's next chunk are requested in this
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kLprWaves * 64) __attribute__((amdgpu_waves_per_eu(
 
     // ---- panel fill: global rows (8 rows x 128 B per wave instruction: whole cache lines) -> registers -> [K/8][BM][16 B] ----------
     // lane -> row 8 rg + (lane & 7), 16-byte column 8 cg + (lane >> 3): eight consecutive lanes write 128 contiguous LDS bytes
-    {
+    if constexpr (!LNIN) {
         constexpr int CG = K / 64, RG = BM / 8, PIECES = RG * CG, PPW = (PIECES + kLprWaves - 1) / kLprWaves;
         uint4 stage[PPW];
         const bf16_t* a = (const bf16_t*)d.a0;
@@ -179,6 +179,74 @@ __global__ __launch_bounds__(kLprWaves * 64) __attribute__((amdgpu_waves_per_eu(
             const int rg = pc / CG, cg = pc - rg * CG;
             const int row = 8 * rg + (lane & 7), c = 8 * cg + (lane >> 3);
             if (pc < PIECES) *(uint4*)(smem + (c * BM + row) * 16) = m0 + row < d.M ? stage[j] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    } else {
+        // LayerNorm of the rows on their way into the panel (attention.py:300-311: norm1 / norm2 / norm3 of BasicTransformerBlock feed
+        // exactly one Linear each where this kernel is used): the panel holds ALL K = C columns of its rows, so the statistics are the
+        // workgroup's own.  A wave takes WHOLE row groups (rg = wave, wave + 8, ...: all CG pieces of 8 rows), a row's K columns then
+        // sit in the 8 lanes with the same (lane & 7): two-pass statistics (mean, then centred variance — t2v_layernorm's arithmetic)
+        // by three butterfly stages, the normalised values rounded to bf16 as the separate launch would have written them.
+        constexpr int CG = K / 64, RG = BM / 8, RPW = (RG + kLprWaves - 1) / kLprWaves;
+        uint4 stage[RPW][CG];
+        const bf16_t* a = (const bf16_t*)d.a0;
+#pragma unroll
+        for (int jr = 0; jr < RPW; ++jr) {
+            const int rg = wave + kLprWaves * jr;
+            const int gm = m0 + 8 * rg + (lane & 7);
+            const bf16_t* ap = a + (long long)min(gm, d.M - 1) * d.lda0 + (lane >> 3) * 8;
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg)
+                if (rg < RG) stage[jr][cg] = *(const uint4*)(ap + cg * 64);
+        }
+        float* sb = (float*)(smem + PANEL_BYTES);
+        const int nb = (c_end - c_begin) * 64;
+        for (int i = tid; i < nb; i += kLprWaves * 64) sb[i] = d.bias ? d.bias[c_begin * 64 + i] : 0.f;
+        float mean[RPW], rstd[RPW];
+        constexpr float inv_k = 1.0f / (float)K;
+#pragma unroll
+        for (int jr = 0; jr < RPW; ++jr) {
+            if (wave + kLprWaves * jr < RG) {
+                float sm = 0.f;
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) {
+                    float f[8];
+                    unpack8(stage[jr][cg], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sm += f[e];
+                }
+                sm += __shfl_xor(sm, 8, 64); sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+                mean[jr] = sm * inv_k;
+                float q = 0.f;
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) {
+                    float f[8];
+                    unpack8(stage[jr][cg], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float dlt = f[e] - mean[jr]; q += dlt * dlt; }
+                }
+                q += __shfl_xor(q, 8, 64); q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+                rstd[jr] = rsqrtf(q * inv_k + d.ln_eps);
+            }
+        }
+#pragma unroll
+        for (int cg = 0; cg < CG; ++cg) {
+            const int c = 8 * cg + (lane >> 3);
+            const float4 g0 = *(const float4*)(d.ln_gamma + c * 8), g1 = *(const float4*)(d.ln_gamma + c * 8 + 4);
+            const float4 b0 = *(const float4*)(d.ln_beta + c * 8), b1 = *(const float4*)(d.ln_beta + c * 8 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int jr = 0; jr < RPW; ++jr) {
+                const int rg = wave + kLprWaves * jr;
+                if (rg < RG) {
+                    const int row = 8 * rg + (lane & 7);
+                    float f[8];
+                    unpack8(stage[jr][cg], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean[jr]) * rstd[jr] * gg[e] + bb[e];
+                    *(uint4*)(smem + (c * BM + row) * 16) = m0 + row < d.M ? pack8(f) : make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
         }
     }
     LPR_STAMP();       // 1: panel written to LDS
@@ -392,15 +460,15 @@ __global__ __launch_bounds__(kLprWaves * 64) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-template <int TB, int KS, int EPI>
+template <int TB, int KS, int EPI, bool LNIN = false>
 int lpr_launch(const LprParams& p, int tiles_m, int ny, hipStream_t s) {
     const int smem = 16 * KS * 32 * TB * 2 + p.chunks_per_y * 64 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)linear_pr_kernel<TB, KS, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)linear_pr_kernel<TB, KS, EPI, LNIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((linear_pr_kernel<TB, KS, EPI>), dim3(tiles_m, ny), dim3(kLprWaves * 64), smem, s, p);
+    hipLaunchKernelGGL((linear_pr_kernel<TB, KS, EPI, LNIN>), dim3(tiles_m, ny), dim3(kLprWaves * 64), smem, s, p);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
@@ -426,6 +494,10 @@ static int lpr_prepare(const t2v_gemm_desc* dd, LprParams& p, int& cfg, int& til
     if (((uintptr_t)d.a0 | (uintptr_t)d.w | (uintptr_t)d.out) % 16) return T2V_OK;
     if (d.residual && (d.act == T2V_ACT_GEGLU || d.ldr % 8 || (uintptr_t)d.residual % 16 || d.M % 32)) return T2V_OK;
     if (d.bias && (uintptr_t)d.bias % 16) return T2V_OK;
+    if (d.ln_in) {   // LayerNorm of the A rows in the panel fill: the affine is required, a residual epilogue is not combined with it
+        T2V_REQUIRE(d.ln_gamma && d.ln_beta, T2V_EINVAL, "t2v_linear_pr: ln_in without ln_gamma / ln_beta");
+        if (d.residual || ((uintptr_t)d.ln_gamma | (uintptr_t)d.ln_beta) % 16) return T2V_OK;
+    }
     p.chunks = d.N / 64;
     p.n_out = d.act == T2V_ACT_GEGLU ? d.N / 2 : d.N;
     const int bm = d.c0 == 320 ? 160 : 96;
@@ -463,6 +535,10 @@ extern "C" int t2v_linear_pr(const t2v_gemm_desc* dd, void* stream) {
     T2V_REQUIRE(cfg > 0, T2V_ESHAPE, "t2v_linear_pr: this launch is not taken by the panel-resident kernel (ask t2v_linear_pr_supported first)");
     hipStream_t s = (hipStream_t)stream;
     const int epi = p.d.act == T2V_ACT_GEGLU ? 1 : (p.d.residual ? 2 : 0);
+    if (p.d.ln_in) {
+        if (cfg == 1) return epi == 1 ? lpr_launch<5, 20, 1, true>(p, tiles_m, ny, s) : lpr_launch<5, 20, 0, true>(p, tiles_m, ny, s);
+        return epi == 1 ? lpr_launch<3, 40, 1, true>(p, tiles_m, ny, s) : lpr_launch<3, 40, 0, true>(p, tiles_m, ny, s);
+    }
     if (cfg == 1) return epi == 1 ? lpr_launch<5, 20, 1>(p, tiles_m, ny, s) : (epi == 2 ? lpr_launch<5, 20, 2>(p, tiles_m, ny, s) : lpr_launch<5, 20, 0>(p, tiles_m, ny, s));
     return epi == 1 ? lpr_launch<3, 40, 1>(p, tiles_m, ny, s) : (epi == 2 ? lpr_launch<3, 40, 2>(p, tiles_m, ny, s) : lpr_launch<3, 40, 0>(p, tiles_m, ny, s));
 }

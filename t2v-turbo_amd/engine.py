@@ -437,6 +437,25 @@ class _Engine:
             return False
         return self.ops.linear_pr_supported(a, w, out, **kw) == 1
 
+    # LayerNorm in the panel fill of the ONE Linear that consumes it (t2v_gemm_desc::ln_in, csrc/linear_pr.hip): the temporal blocks'
+    # norm1 / norm2 -> q | k | v and every block's norm3 -> GEGLU projection at the 320- and 640-channel levels — no t2v_layernorm launch,
+    # no normalised tensor.  T2V_LN_IN=0: the separate launch.
+    ln_in_fill = os.environ.get("T2V_LN_IN", "1") == "1"
+
+    def linear_ln_in(self, a, norm, *, w, bias, act=nt.ACT_NONE):
+        """Linear(LayerNorm(a)) as ONE t2v_linear_pr launch, or None where that kernel does not take the launch (the caller normalises first)."""
+        if not self.ln_in_fill or tuple(norm.normalized_shape) != (a.shape[1],) or not norm.elementwise_affine:
+            return None
+        N = w.shape[0]
+        out = self.buf(a.shape[0], N // 2 if act == nt.ACT_GEGLU else N)
+        kw = dict(M=a.shape[0], N=N, bias=bias, residual=None, act=act,
+                  ln_in=(self.pk.f32(norm.weight), self.pk.f32(norm.bias), norm.eps))
+        if not self._lpr_takes(a, w, out, kw):
+            self.pool.put(out)
+            return None
+        self.ops.linear_pr(a, self.pk.lpr(w), out, **kw)
+        return out
+
     # LayerNorm as a by-product of the GEMM that produces its input.  Opt-in (T2V_FUSE_LN=1): measured on MI355X it removes 30
     # launches and 0.7 ms of t2v_layernorm per UNet step but adds 0.36 ms to the producing GEMMs (a second 26 MB write in their
     # epilogue) — 23.95 vs 24.06 ms per step in a same-box A/B, i.e. the kernel time is a wash and only the boundaries are saved.
@@ -940,6 +959,8 @@ class UNetEngine(_Engine):
         def temporal_attn(attn, norm, src, stats):
             # q | k | v of LayerNorm(src) as ONE GEMM
             qkv = folded(src, norm, stats if wide else None, lambda: pk.mat_lnf([attn.to_q, attn.to_k, attn.to_v], norm, "qkv_lnf"))
+            if qkv is None and src is not box["ln"]:
+                qkv = self.linear_ln_in(src, norm, w=pk.cat_mats([attn.to_q, attn.to_k, attn.to_v], "qkv"), bias=None)
             if qkv is None:
                 qkv = self.linear(lnorm(norm, src) if src is not box["ln"] else src, None,
                                   w=pk.cat_mats([attn.to_q, attn.to_k, attn.to_v], "qkv"), bias=None)
@@ -1006,6 +1027,9 @@ class UNetEngine(_Engine):
             self.pool.put(y2, box["ln"])
             return y3
         g = folded(y2, blk.norm3, rs2 if wide else None, lambda: pk.geglu_lnf(proj.proj, blk.norm3), act=nt.ACT_GEGLU)
+        if g is None and not fuse3:
+            wg, bg = pk.geglu(proj.proj)
+            g = self.linear_ln_in(y2, blk.norm3, w=wg, bias=bg, act=nt.ACT_GEGLU)
         if g is None:
             src = box["ln"] if fuse3 else lnorm(blk.norm3, y2)
             wg, bg = pk.geglu(proj.proj)

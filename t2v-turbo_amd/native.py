@@ -50,7 +50,7 @@ class GemmDesc(C.Structure):
         ("rowstat_out", C.c_void_p), ("ld_rowstat", C.c_int), ("colstat_out", C.c_void_p),
         ("lnf_stats", C.c_void_p), ("lnf_ld", C.c_int), ("lnf_nblk", C.c_int), ("lnf_eps", C.c_float), ("lnf_s", C.c_void_p),
         ("lora_t", C.c_void_p), ("ld_lora_t", C.c_int), ("lora_u", C.c_void_p), ("ld_lora_u", C.c_int), ("lora_n_leaf", C.c_int),
-        ("lora_scale", C.c_float),
+        ("lora_scale", C.c_float), ("ln_in", C.c_int),
     ]
 
 
@@ -558,7 +558,7 @@ class HipOps:
     def _gemm_desc(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
                    rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
                    a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None, ln=None,
-                   rowstat=None, colstat=None, lnf=None, lora=None, tune_exact=False):
+                   rowstat=None, colstat=None, lnf=None, lora=None, tune_exact=False, ln_in=None):
         d = GemmDesc()
         d.a0, d.c0, d.lda0 = _p(a0), a0.shape[1], _row_stride(a0)
         if a1 is not None:
@@ -598,6 +598,11 @@ class HipOps:
         if ln is not None:  # (gamma fp32 [N], beta fp32 [N], eps, out2 bf16 [M, N]): LayerNorm(out) as a second output (N == 320)
             gamma, beta, eps, out2 = ln
             d.ln_gamma, d.ln_beta, d.ln_eps, d.ln_out, d.ld_ln_out = _p(gamma), _p(beta), float(eps), _p(out2), _row_stride(out2)
+        if ln_in is not None:   # (gamma fp32 [K], beta fp32 [K], eps): LayerNorm of the A rows in t2v_linear_pr's panel fill
+            assert ln is None, "ln (second output) and ln_in (input rows) share the ln_* fields"
+            gamma, beta, eps = ln_in
+            assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == a0.shape[1] == beta.numel()
+            d.ln_gamma, d.ln_beta, d.ln_eps, d.ln_in = _p(gamma), _p(beta), float(eps), 1
         if rowstat is not None:   # fp32 [M, ld]: (sum, sumsq) per 32-column block of every output row
             assert rowstat.dtype == torch.float32 and rowstat.shape[0] == M
             d.rowstat_out, d.ld_rowstat = _p(rowstat), _row_stride(rowstat)

@@ -146,8 +146,10 @@ class EmuOps:
     # ---- t2v_linear_pr: short-K Linear on the fragment pack (csrc/linear_pr.hip) ---------------------------------------------------
     def linear_pr_supported(self, a0, wp, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, bias=None, rowvec=None, residual=None,
                             act=nt.ACT_NONE, alpha=1.0, batch=1, split_k=0, dropout=None, ln=None, rowstat=None, colstat=None, lnf=None,
-                            lora=None, **_):
+                            lora=None, ln_in=None, **_):
         """Mirror of lpr_prepare (csrc/linear_pr.hip): 0 not taken, 1 taken."""
+        if ln_in is not None and residual is not None:
+            return 0
         if mode != nt.GEMM_LINEAR or a1 is not None or batch > 1 or alpha != 1.0 or split_k > 1 or out.dtype not in (self.act_dtype, torch.bfloat16):
             return 0
         if any(v is not None for v in (dropout, ln, rowstat, colstat, lnf, lora, rowvec)) or act not in (nt.ACT_NONE, nt.ACT_GEGLU):
@@ -162,6 +164,10 @@ class EmuOps:
         self._log("linear_pr")
         assert self.linear_pr_supported(a0, wp, out, **kw), "t2v_linear_pr would refuse this launch"
         kw.pop("tile_cfg", None)
+        ln_in = kw.pop("ln_in", None)
+        if ln_in is not None:   # LayerNorm of the rows in the panel fill: normalised rows rounded to the activation dtype, as t2v_layernorm writes them
+            gamma, beta, eps = ln_in
+            a0 = F.layer_norm(a0.float(), (a0.shape[1],), gamma.float(), beta.float(), eps).to(a0.dtype)
         self.gemm(a0, nt.unpack_linear_pr(wp[:kw["N"]]), out, **kw)
 
     # ---- t2v_conv_halo: the same 3x3 convolution on the slab-major weight pack (csrc/conv_halo.hip) ----------------------------

@@ -287,6 +287,14 @@ def test_width_320_transformer_linears_take_the_panel_resident_route():
         n_lpr = ops.calls.count("linear_pr")
         # per transformer pair: spatial block q|k (320 only: N = 1280 < 1920 at 640) + GEGLU, temporal block 2 x q|k|v + GEGLU
         assert n_lpr >= 12, n_lpr
+        # LayerNorm in the panel fill (ln_in): the temporal blocks' norm1 / norm2 and every norm3 at these widths are no launches of their own
+        n_ln = ops.calls.count("layernorm")
+        eng.ln_in_fill = False
+        eng.plans.clear()
+        ops.calls.clear()
+        with torch.no_grad():
+            y1 = eng(x, ts, ctx, 16, None, None)
+        assert ops.calls.count("layernorm") >= n_ln + 8 and ops.calls.count("linear_pr") == n_lpr and rel_l2(y1, y) < 1e-6
         eng.linear_pr = False
         eng.plans.clear()
         ops.calls.clear()

@@ -254,7 +254,9 @@ def test_unet_full_width_c2_config_vs_oracle():
     # numbers within two bf16 roundings; and the opt-in LayerNorm-as-second-output form on top of that (30 launches fewer)
     n_default = len(next(iter(eng.plans.values()))["rec"])
     outs = {}
-    for tag, flags in (("plain", dict(fuse_gn=False, fold_ln=False, fuse_ln=False)), ("ln_second_output", dict(fuse_gn=False, fold_ln=False, fuse_ln=True))):
+    # (ln_in_fill off in both: the LayerNorms t2v_linear_pr takes into its panel fill would otherwise be gone from both counts)
+    for tag, flags in (("plain", dict(fuse_gn=False, fold_ln=False, fuse_ln=False, ln_in_fill=False)),
+                       ("ln_second_output", dict(fuse_gn=False, fold_ln=False, fuse_ln=True, ln_in_fill=False))):
         for k, v in flags.items():
             setattr(eng, k, v)
         eng.plans.clear()
@@ -262,7 +264,7 @@ def test_unet_full_width_c2_config_vs_oracle():
             with torch.no_grad():
                 outs[tag] = (model(x, ts, context=ctx, fps=16, timestep_cond=tc).float().cpu(), len(next(iter(eng.plans.values()))["rec"]))
         finally:
-            eng.fuse_gn = eng.fold_ln = True
+            eng.fuse_gn = eng.fold_ln = eng.ln_in_fill = True
             eng.fuse_ln = False
             eng.plans.clear()
     n_plain = outs["plain"][1]

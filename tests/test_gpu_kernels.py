@@ -647,15 +647,18 @@ def test_conv_halo_unet_level_shapes_repeatable(pair):
 
 
 # ---- t2v_linear_pr: short-K Linear with the activation panel resident in LDS (csrc/linear_pr.hip) ------------------------------------
-def _lpr_case(pair, *, M, K, N, act=0, bias=True, residual=False, ny=0, seed=0, repeat=1, lda=None, ldo=None):
+def _lpr_case(pair, *, M, K, N, act=0, bias=True, residual=False, ny=0, seed=0, repeat=1, lda=None, ldo=None, ln_in=False):
     """t2v_linear_pr on the fragment pack against the emulated Linear on the same bf16-rounded data (tests/emu_ops.py::linear_pr);
     ``repeat`` back-to-back launches into the same output (the weight ring and the residual prefetch run ahead of the stores)."""
     from t2v_turbo_amd import native as nt
     n_out = N // 2 if act == nt.ACT_GEGLU else N
     a = _rt(M, lda or K, seed=seed)
+    if ln_in:   # rows with their own offsets and scales
+        a = (a * (0.5 + torch.arange(M)[:, None] % 7) + (torch.arange(M)[:, None] % 5 - 2.0)).bfloat16().float()
     w = _rt(N, K, seed=seed + 1, scale=K ** -0.5)
     b = _rt(N, seed=seed + 2) if bias else None
     res = _rt(M, n_out, seed=seed + 3) if residual else None
+    ln = (1.0 + 0.2 * _rt(K, seed=seed + 4), 0.3 * _rt(K, seed=seed + 5), 1e-5) if ln_in else None
     outs = []
     pair.hip.lib.t2v_linear_pr_force_split(ny)
     try:
@@ -667,6 +670,8 @@ def _lpr_case(pair, *, M, K, N, act=0, bias=True, residual=False, ny=0, seed=0, 
             out = out_full[:, :n_out]
             wp = cvt(nt.pack_linear_pr(w.bfloat16()).float())
             kw = dict(M=M, N=N, bias=f32(b), residual=cvt(res), act=act)
+            if ln_in:
+                kw["ln_in"] = (f32(ln[0]), f32(ln[1]), ln[2])
             x = cvt(a)[:, :K]
             assert ops.linear_pr_supported(x, wp, out, **kw) == 1
             for _ in range(repeat if side == 0 else 1):
@@ -700,6 +705,17 @@ def test_linear_pr_residual_and_few_chunks(pair):
     _lpr_case(pair, M=10240, K=640, N=640, residual=True, seed=7, repeat=2)
     _lpr_case(pair, M=2560, K=320, N=320, bias=False, seed=8)
     _lpr_case(pair, M=10240, K=640, N=1280, residual=True, ny=3, seed=9)
+
+
+def test_linear_pr_layernorm_in_the_panel_fill(pair):
+    # ln_in (t2v_gemm_desc): LayerNorm(x) -> q | k | v and -> GEGLU projection as one launch, at the UNet's sizes and on ragged / strided ones
+    from t2v_turbo_amd import native as nt
+    _lpr_case(pair, M=40960, K=320, N=2560, act=nt.ACT_GEGLU, ln_in=True, seed=21, repeat=2)
+    _lpr_case(pair, M=40960, K=320, N=960, bias=False, ln_in=True, seed=22)
+    _lpr_case(pair, M=10240, K=640, N=5120, act=nt.ACT_GEGLU, ln_in=True, seed=23, repeat=2)
+    _lpr_case(pair, M=10240, K=640, N=1920, bias=False, ln_in=True, seed=24)
+    _lpr_case(pair, M=1000, K=320, N=1280, act=nt.ACT_GEGLU, ln_in=True, seed=25)
+    _lpr_case(pair, M=333, K=640, N=1024, ln_in=True, ny=2, seed=26, lda=704, ldo=1152)
 
 
 def test_linear_pr_ragged_rows_strides_and_splits(pair):

@@ -38,9 +38,11 @@ def sim():
     return ops
 
 
-def _case(sim, *, M, K, N, act=nt.ACT_NONE, bias=True, residual=False, ny=0, seed=0, lda=None, ldo=None):
+def _case(sim, *, M, K, N, act=nt.ACT_NONE, bias=True, residual=False, ny=0, seed=0, lda=None, ldo=None, ln_in=False):
     n_out = N // 2 if act == nt.ACT_GEGLU else N
     a_full = _rt(M, lda or K, seed=seed).bfloat16()
+    if ln_in:   # rows with their own offsets and scales: a LayerNorm that mixed up rows or columns could not pass
+        a_full = (a_full.float() * (0.5 + torch.arange(M)[:, None] % 7) + (torch.arange(M)[:, None] % 5 - 2.0)).bfloat16()
     a = a_full[:, :K]
     w = _rt(N, K, seed=seed + 1, scale=K ** -0.5).bfloat16()
     wp = nt.pack_linear_pr(w)
@@ -48,6 +50,8 @@ def _case(sim, *, M, K, N, act=nt.ACT_NONE, bias=True, residual=False, ny=0, see
     b = _rt(N, seed=seed + 2) if bias else None
     res = _rt(M, n_out, seed=seed + 3).bfloat16() if residual else None
     kw = dict(M=M, N=N, bias=b, residual=res, act=act)
+    if ln_in:
+        kw["ln_in"] = (1.0 + 0.2 * _rt(K, seed=seed + 4), 0.3 * _rt(K, seed=seed + 5), 1e-5)
     outs = []
     sim.lib.t2v_linear_pr_force_split(ny)
     try:
@@ -96,6 +100,15 @@ def test_column_splits_over_workgroup_rows(sim):
     _case(sim, M=128, K=640, N=1280, residual=True, ny=3, seed=8)
 
 
+def test_layernorm_in_the_panel_fill(sim):
+    # ln_in: norm1 / norm2 / norm3 -> one Linear (attention.py:300-311): both geometries, both epilogues, ragged rows (the rows past M are
+    # normalised copies of the last row and written as zeros), uneven row groups per wave (20 row groups over 8 waves), column splits
+    _case(sim, M=160 + 75, K=320, N=640, act=nt.ACT_GEGLU, ln_in=True, seed=31)
+    _case(sim, M=200, K=320, N=960, ln_in=True, seed=32, lda=384, ldo=1024)
+    _case(sim, M=96 + 40, K=640, N=640, ln_in=True, bias=False, seed=33)
+    _case(sim, M=128, K=640, N=1280, act=nt.ACT_GEGLU, ln_in=True, ny=2, seed=34)
+
+
 def test_not_taken_cases(sim):
     a = _rt(64, 320).bfloat16()
     out = torch.empty(64, 128).bfloat16()
@@ -108,6 +121,7 @@ def test_not_taken_cases(sim):
         assert ops.linear_pr_supported(a[:, :256], wp, out, M=64, N=128) == 0          # K = 256
         assert ops.linear_pr_supported(a, wp, out, M=64, N=96) == 0                    # N % 64
         assert ops.linear_pr_supported(a, wp, out[:, :64], M=64, N=128, act=nt.ACT_GEGLU, residual=out[:, :64]) == 0
+        assert ops.linear_pr_supported(a, wp, out, M=64, N=128, residual=out, ln_in=(torch.ones(320), torch.zeros(320), 1e-5)) == 0   # ln_in + residual
         assert ops.linear_pr_supported(a[:40], wp, out[:40], M=40, N=128, residual=out[:40]) == 0       # residual with M % 32 != 0
     with pytest.raises(nt.NativeError):
         sim.linear_pr(a, wp, out, M=64, N=128, alpha=0.5)
