@@ -103,7 +103,7 @@ def kernel_breakdown(engine, plan, rec=None):
         a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "tflop": 0.0, "gbyte": 0.0})
         a["launches"] += 1
         a["ms"] += ms
-        if name in ("t2v_gemm", "t2v_conv_halo"):
+        if name in GEMM_FAMILY:
             d = args[0]._obj
             taps = {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(d.mode, 9)
             tf = 2.0 * d.M * d.N * taps * (d.c0 + d.c1) * max(d.batch, 1) / 1e12
@@ -150,13 +150,51 @@ def kernel_breakdown(engine, plan, rec=None):
     return agg
 
 
+GEMM_FAMILY = ("t2v_gemm", "t2v_conv_halo", "t2v_linear_pr")   # the implicit-GEMM convolutions / linears: one descriptor type, 2 M N K FLOP each
+
+
+def family_ingraph(engine, rec, names, replays=5):
+    """In-graph time (ms per step) of the launches of ``rec`` whose entry point is in ``names``: those launches, in recorded order, captured
+    into ONE hipGraph on the stream they run on and replayed — device time without the host's per-launch dispatch that an event pair
+    around every eager launch measures (rounds 4 and 5: that figure stopped responding to kernel changes).  Best of ``replays``."""
+    ops = engine.ops
+    sel = [(fn, args) for fn, args, name in rec if name in names]
+    if not sel:
+        return None
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for fn, args in sel[:4]:
+            fn(*args, ops.stream())
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            st = ops.stream()
+            for fn, args in sel:
+                fn(*args, st)
+        g.replay()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(replays):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            best = ms if best is None else min(best, ms)
+    torch.cuda.current_stream().wait_stream(side)
+    del g
+    return best
+
+
 def gemm_traffic():
     """HBM-side bytes per t2v_gemm launch from the committed PMC passes (profiles/r0N_gemm_traffic.json: rocprofv3
     --pmc FETCH_SIZE and WRITE_SIZE in separate runs of this same step, gfx950 FETCH_SIZE x2 correction;
     tools/pmc_traffic.py).  Counters cannot be read from inside the timed process, so this is the profile's number,
     labelled as such; null when the profile is absent."""
     here = os.path.dirname(os.path.abspath(__file__))
-    for name in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"):  # the newest committed PMC passes
+    for name in ("r06_gemm_traffic.json", "r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r02_gemm_traffic.json", "r01_gemm_traffic.json"):  # the newest committed PMC passes
         try:
             with open(os.path.join(here, "profiles", name)) as f:
                 g = json.load(f)["gemm"]
@@ -606,21 +644,33 @@ def main():
         if args.breakdown:
             with torch.no_grad():
                 agg = kernel_breakdown(eng, plan)
-            g0 = agg.get("t2v_gemm", {"ms": 0.0, "tflop": 0.0, "launches": 0})
-            h0 = agg.get("t2v_conv_halo", {"ms": 0.0, "tflop": 0.0, "launches": 0})
-            # the dominant kernel FAMILY: the implicit-GEMM convolutions / linears, i.e. t2v_gemm and (3x3 convs of the three upper
-            # levels since round 4) t2v_conv_halo; algorithmic FLOPs of both over the HIP-event time of both
-            gm = dict(g0, ms=g0["ms"] + h0["ms"], tflop=g0["tflop"] + h0["tflop"], launches=g0["launches"] + h0["launches"])
+            zero = {"ms": 0.0, "tflop": 0.0, "launches": 0}
+            g0, h0, l0 = agg.get("t2v_gemm", zero), agg.get("t2v_conv_halo", zero), agg.get("t2v_linear_pr", zero)
+            # the dominant kernel FAMILY: the implicit-GEMM convolutions / linears — t2v_gemm, t2v_conv_halo (3x3 convs of the three upper
+            # levels since round 4) and t2v_linear_pr (short-K GEGLU / q|k|v launches since round 6): algorithmic FLOPs of all three over
+            # their IN-GRAPH time (the family's launches captured into one hipGraph and replayed: family_ingraph); the per-launch
+            # event times of the eager replay stay in by_kernel / kernel_ms as `ms_eager`
+            gm = dict(g0, tflop=g0["tflop"] + h0["tflop"] + l0["tflop"], launches=g0["launches"] + h0["launches"] + l0["launches"],
+                      ms_eager=g0["ms"] + h0["ms"] + l0["ms"])
+            with torch.no_grad():
+                fam_ms = family_ingraph(eng, plan["rec"], GEMM_FAMILY)
+                one_ms = {n: family_ingraph(eng, plan["rec"], (n,)) for n in GEMM_FAMILY}
+            gm["ms"] = fam_ms if fam_ms else gm["ms_eager"]
             ach = gm["tflop"] / (gm["ms"] / 1e3) if gm["ms"] > 0 else 0.0
+
+            def one(n, a):
+                ms = one_ms.get(n)
+                return {"launches": a["launches"], "ms": None if ms is None else round(ms, 3), "ms_eager": round(a["ms"], 3),
+                        "tflops": round(a["tflop"] / (ms / 1e3), 1) if ms else None}
             result["roofline"] = {
-                "kernel": "gemm_kernel + conv_halo_kernel (implicit-GEMM conv / linear: v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16)",
+                "kernel": "gemm_kernel + conv_halo_kernel + linear_pr_kernel (implicit-GEMM conv / linear: v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16)",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_PEAK_TFLOPS, 4), **gemm_traffic(),
+                "timing": "in-graph: the family's launches of one step captured into one hipGraph on their stream, best of 5 replays (HIP events)",
                 "launches": gm["launches"], "tflop_per_step": round(gm["tflop"], 3), "ms_per_step": round(gm["ms"], 3),
+                "ms_per_step_eager_events": round(gm["ms_eager"], 3),
                 "whole_step_frac": round(UNET_TFLOP_PER_STEP / (ms_per_step / 1e3) / MFMA_PEAK_TFLOPS, 4),
-                "by_kernel": {"t2v_gemm": {"launches": g0["launches"], "ms": round(g0["ms"], 3), "tflops": round(g0["tflop"] / (g0["ms"] / 1e3), 1) if g0["ms"] else None},
-                              "t2v_conv_halo": {"launches": h0["launches"], "ms": round(h0["ms"], 3),
-                                                "tflops": round(h0["tflop"] / (h0["ms"] / 1e3), 1) if h0["ms"] else None}},
+                "by_kernel": {"t2v_gemm": one("t2v_gemm", g0), "t2v_conv_halo": one("t2v_conv_halo", h0), "t2v_linear_pr": one("t2v_linear_pr", l0)},
             }
             if gm.get("operand_ms"):  # the rate the kernel is actually bound by
                 result["roofline"]["operand_delivery"] = {

@@ -206,15 +206,19 @@ int t2v_linear_pr_debug(int bits);         /* ablation bits; honoured by -DT2V_L
 int t2v_linear_pr_force_split(int ny);     /* tuning hook: column splits (workgroup rows) for every following call, 0 = library rule */
 /* tuning/test hooks: override tile id / split-K factor for every following call (0 = off) */
 int t2v_gemm_force_config(int cfg);
+#ifdef T2V_EXPERIMENTAL /* measured negative results: compiled and exported by a T2V_EXPERIMENTAL=1 build (libt2v_hip_exp.so) only */
 /* t2v_gemm's second kernel family (csrc/gemm2.hip: static-schedule main loop, 80x80 wave tiles; tile ids 50 = 320x160, 51 = 160x160)
  * for LINEAR / TCONV3 launches with a plain epilogue (bias, residual, SiLU, colstat_out).  Measured slower than the tuned first-family
  * tiles on the UNet's shapes (operand-delivery bound), so it is OFF by default: t2v_gemm2_enable(1) (or T2V_GEMM2=1) lets the library
  * route long-K launches to it by its own rule, a forced tile id 50 / 51 puts an eligible launch on it whatever its K. */
 int t2v_gemm2_enable(int on);
+#endif
 int t2v_gemm_force_split(int splits);
 int t2v_gemm_num_configs(void);
 
-/* The GEGLU feed-forward of a BasicTransformerBlock, LayerNorm and residual included, in ONE launch:
+#ifdef T2V_EXPERIMENTAL
+/* The GEGLU feed-forward of a BasicTransformerBlock, LayerNorm and residual included, in ONE launch (measured slower than the three
+ * launches it replaces: profiles/r03_ffn_fused_pmc.csv):
  *     out = x + W2 . [value . gelu(gate)] + b2,   [value | gate] = W1 . LayerNorm(x) + b1
  * (lvdm/modules/attention.py:300-311 `x = self.ff(self.norm3(x)) + x`, :516-542 FeedForward / GEGLU).  The 4C-wide hidden
  * activation never reaches memory.  x, out: bf16 [M][ld] (not in place); C = 320 (and 64 for tests): t2v_ffn_fused_supported.
@@ -228,6 +232,7 @@ int t2v_gemm_num_configs(void);
 int t2v_ffn_fused_supported(int C);
 int t2v_ffn_fused(const void* x, int ldx, int M, int C, const void* w1p, const float* b1p, const void* w2p, const float* b2,
                   float ln_eps, void* out, int ldo, void* stream);
+#endif
 
 /* direct 3x3 s1 p1 conv for tiny Cin (the 4-channel latent): x bf16 [M][cin] (cin <= 8),
  * w fp32 [cout][9][cin], bias fp32 [cout], out bf16 [M][cout].
@@ -235,13 +240,15 @@ int t2v_ffn_fused(const void* x, int ldx, int M, int C, const void* w1p, const f
 int t2v_conv3x3_small_cin(const void* x, int n_img, int h, int w, int cin, const float* wgt,
                           const float* bias, int cout, void* out, void* stream);
 
-/* direct 3x3 s1 p1 conv for a tiny number of OUTPUT channels (1 <= cout <= 4): x bf16 [M][cin] (row stride ldx, cin % 8 == 0),
+#ifdef T2V_EXPERIMENTAL
+/* direct 3x3 s1 p1 conv for a tiny number of OUTPUT channels (1 <= cout <= 4; measured 4x slower than the MFMA tile): x bf16 [M][cin] (row stride ldx, cin % 8 == 0),
  * w fp32 [cout][9][cin] (tap-major), bias fp32 [cout] or NULL, out [M][cout] fp32 (out_f32 != 0) or bf16 at row stride ldo; the image
  * width must be a multiple of 4 (a thread owns four pixels of a row).  Replaces Decoder.conv_out (ae_modules.py:641: 128 -> 3 channels
  * at 320x512) — on the MFMA tiles that conv multiplies a 64-/128-wide tile of padding.  t2v_conv3x3_small_cout_supported: 1 / 0. */
 int t2v_conv3x3_small_cout_supported(int w, int cin, int cout);
 int t2v_conv3x3_small_cout(const void* x, int ldx, int n_img, int h, int w, int cin, const float* wgt, const float* bias, int cout,
                            void* out, int ldo, int out_f32, void* stream);
+#endif
 
 /* ---------------------------------------------------------------- normalisation
  * GroupNorm(32) in two phases over token-major data with optional virtual concat.
@@ -349,10 +356,12 @@ int t2v_lcm_step(const float* x, const void* eps, int eps_dt, const float* noise
  * compiles them out and these calls just store the value). */
 int t2v_gemm_debug(int bits);
 int t2v_attn_debug(int bits);
+#ifdef T2V_EXPERIMENTAL
 /* which form of the spatial forward t2v_attn_spatial launches (tools / tests; the product default is 0 and the others are measured no
  * faster): 0 = 4 waves x 32 queries per workgroup, 8 = 8 waves x 32, 64 = 4 waves x 64 queries (two query sets per wave, phases offset)
  * on launches with >= 512 queries and keys, 65 = that form always.  Same arithmetic per query in every form: bit-identical outputs. */
 int t2v_attn_spatial_form(int form);
+#endif
 /* t2v_group_norm has a ONE-launch form (registers hold the tensor, per-unit inter-workgroup barrier) for tensors that fit:
  * t2v_gn_coop_enable(1) / environment T2V_GN_COOP=1 selects it (default off: measured slower than the three-launch form on
  * MI355X for cache-resident tensors); t2v_gn_coop_error() returns 1 if a
@@ -458,6 +467,28 @@ typedef struct t2v_wgrad_problem {
     float alpha;
 } t2v_wgrad_problem;
 int t2v_wgrad_tn_group(const t2v_wgrad_problem* problems, int n, float* ws, long long ws_bytes, void* stream);
+/* ---- base-weight gradients for FULL fine-tuning (csrc/full_grad.hip; train_latent_t2v_turbo_v2.py:798-816,1262) ----------------------
+ * t2v_im2col_bf16: the shifted-row matrix of a conv leaf in the K order of the forward's tap-major pack,
+ *     out[m][tap * C + c] = x[src(m, tap)][c]   (0 outside the grid; x = virtual concat [x0 | x1], C = c0 + c1, channels % 8 == 0)
+ * for mode = T2V_GEMM_CONV3X3 / _S2 / _S2_PAD01 / _UP2 (9 taps, (ky, kx) row-major) or T2V_GEMM_TCONV3 (3 taps = frame offsets; n_img =
+ * clips x frames) on the (n_img, h, w) INPUT grid; out: bf16 [t2v_im2col_rows(mode, n_img, h, w)][ldo], ldo >= taps * C.  With it the
+ * weight gradient of a conv leaf, dW[n][tap][c] = sum_m dy[m][n] out[m][tap * C + c], is one t2v_wgrad_tn(dy, out) product. */
+long long t2v_im2col_rows(int mode, int n_img, int h, int w);
+int t2v_im2col_bf16(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int mode, int n_img, int h, int w, int frames, void* out,
+                    int ldo, void* stream);
+/* t2v_norm_affine_grad: per-channel sums over token rows, `sum_rows` consecutive rows per output row u (rows % sum_rows == 0):
+ *     dgamma[u][c] = sum dz[m][c] xhat[m][c],   dbeta[u][c] = sum dz[m][c]
+ * kind 0: xhat from GroupNorm statistics stats[row / rows_per_unit][group][2] = (mean, rstd) of the forward (lvdm/basics.py:78-89);
+ * kind 1: xhat = LayerNorm's (x - mean_row) * rstd_row, recomputed per row with ln_eps (attention.py:300-311);
+ * kind 2: no norm — dbeta = plain column sums of dy (bias gradients; per-clip sums = d(loss)/d(time embedding row); c0 = columns of dy).
+ * silu != 0 (kinds 0, 1): the forward applied SiLU behind the norm (openaimodel3d.py:223-254), dz = dy * silu'(xhat gamma + beta); else
+ * dz = dy.  x = [x0 | x1] bf16 (the norm's INPUT), dy bf16 [rows][ldy] over the C = c0 + c1 channels (C % 8 == 0, C <= 2048); dgamma /
+ * dbeta fp32 with row strides ld_dgamma / ld_dbeta (either may be NULL for kind 2 / when not wanted).  ws: fp32 workspace of
+ * t2v_norm_affine_grad_ws_floats(rows, sum_rows, C) floats.  Two launches, fixed summation order (no float atomics). */
+long long t2v_norm_affine_grad_ws_floats(long long rows, long long sum_rows, int channels);
+int t2v_norm_affine_grad(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, long long rows, long long sum_rows, int kind,
+                         int rows_per_unit, int groups, const float* stats, float ln_eps, const float* gamma, const float* beta, int silu,
+                         const void* dy, int ldy, float* dgamma, int ld_dgamma, float* dbeta, int ld_dbeta, float* ws, void* stream);
 /* t2v_transpose_pad_bf16: out[b][c][r] = in[b][r][c] for r < rows and 0 for rows <= r < roundup(rows, 64) — the K-contiguous,
  * K-padded operand of the token-contracted weight-gradient GEMMs (dU = dy^T t, dD = G^T x) in one pass; 16-byte accesses on both
  * sides: cols % 8 == 0, ld_in % 8 == 0, ld_out % 8 == 0 and >= roundup(rows, 64), 16-byte aligned bases, batch strides % 8. */

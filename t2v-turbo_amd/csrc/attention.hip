@@ -264,6 +264,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(T2V_ATT
     }
 }
 
+#ifdef T2V_EXPERIMENTAL   // (measured no faster: in the T2V_EXPERIMENTAL=1 library only)
 // ------------------------------------------------------------------------------------------------
 // attn_spatial_q64_kernel (round 5): the same arithmetic with SIXTY-FOUR queries per wave — two 32-query sets A and B that share every K / V^T
 // fragment read — and the two sets' phases offset by one in program order, so that one set's softmax VALU work is issued in the gaps of the
@@ -481,6 +482,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+#endif   // T2V_EXPERIMENTAL
+
 // ------------------------------------------------------------------------------------------------
 // Temporal attention: the sequence is the F frames of one pixel.  One wave per (clip, pixel, head), matrix cores for
 // both products (the VALU form of this kernel was instruction-bound at a third of the HBM rate):
@@ -636,8 +639,10 @@ extern "C" int t2v_attn_debug(int bits) { g_attn_debug = bits; return T2V_OK; }
 // Which form of the spatial forward t2v_attn_spatial launches: 0 = the product kernel (4 waves x 32 queries), 8 = eight waves per workgroup,
 // 64 = 64 queries per wave on launches with >= 512 queries and keys, 65 = 64 queries per wave always.  The last three are MEASURED NO FASTER
 // (profiles/r05_attn_issue_order_variants.txt) and exist for tools and tests; -1 (initial) = from T2V_ATTN_NW / T2V_ATTN_Q64 in the environment.
+#ifdef T2V_EXPERIMENTAL
 static int g_attn_form = -1;
 extern "C" int t2v_attn_spatial_form(int form) { g_attn_form = form; return T2V_OK; }
+#endif
 
 extern "C" int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, const void* vt, int ld_vt,
                                 long long vt_img_stride, void* out, int ldo, int n_img, int seq_q, int seq_kv, int heads,
@@ -649,6 +654,7 @@ extern "C" int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, 
     T2V_REQUIRE(heads <= 65535 && n_img <= 65535, T2V_ESHAPE, "t2v_attn_spatial: grid");
     if (vt_img_stride <= 0) vt_img_stride = (long long)heads * 64 * ld_vt;
     T2V_REQUIRE(vt_img_stride % 8 == 0, T2V_ESHAPE, "t2v_attn_spatial: vt_img_stride");
+#ifdef T2V_EXPERIMENTAL
     if (g_attn_form < 0) {   // T2V_ATTN_NW=8 / T2V_ATTN_Q64=1 (long launches) / 2 (always): tools switches, see t2v_attn_spatial_form
         const int nw = getenv("T2V_ATTN_NW") ? atoi(getenv("T2V_ATTN_NW")) : 0, q = getenv("T2V_ATTN_Q64") ? atoi(getenv("T2V_ATTN_Q64")) : 0;
         g_attn_form = q == 2 ? 65 : (q == 1 ? 64 : (nw == 8 ? 8 : 0));
@@ -664,7 +670,9 @@ extern "C" int t2v_attn_spatial(const void* q, int ldq, const void* k, int ldk, 
         hipLaunchKernelGGL(attn_spatial_kernel<8>, grid, dim3(512), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
                            (const bf16_t*)k, ldk, (const bf16_t*)vt, ld_vt, vt_img_stride, (bf16_t*)out, ldo, seq_q, seq_kv, heads,
                            kv_div, scale, (const bf16_t*)t2v_zero_page(), g_attn_debug);
-    } else {
+    } else
+#endif
+    {
         dim3 grid((seq_q + 127) / 128, heads, n_img);
         hipLaunchKernelGGL(attn_spatial_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, ldq,
                            (const bf16_t*)k, ldk, (const bf16_t*)vt, ld_vt, vt_img_stride, (bf16_t*)out, ldo, seq_q, seq_kv, heads,

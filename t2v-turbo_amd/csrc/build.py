@@ -7,11 +7,17 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
-SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "linear_pr.hip", "gemm2.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "replay.hip"]
+SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "linear_pr.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "full_grad.hip", "replay.hip"]
+# T2V_EXPERIMENTAL=1: the library WITH the measured negative results (the second t2v_gemm kernel family, the one-launch feed-forward, the
+# alternative flash-attention forms, the direct small-Cout conv: -DT2V_EXPERIMENTAL) as libt2v_hip_exp.so next to the product library —
+# tools and tests load it through T2V_HIP_LIB; the product library and include/t2v_hip.h's default view do not carry them.
+EXPERIMENTAL = os.environ.get("T2V_EXPERIMENTAL") == "1"
+if EXPERIMENTAL:
+    SOURCES = SOURCES + ["gemm2.hip", "ffn.hip"]
 # T2V_HIP_LIB_OUT: build a variant (e.g. with ablation switches) next to the product library instead of over it
-LIB = os.path.abspath(os.environ["T2V_HIP_LIB_OUT"]) if os.environ.get("T2V_HIP_LIB_OUT") else os.path.join(PKG, "libt2v_hip.so")
+LIB = os.path.abspath(os.environ["T2V_HIP_LIB_OUT"]) if os.environ.get("T2V_HIP_LIB_OUT") else os.path.join(PKG, "libt2v_hip_exp.so" if EXPERIMENTAL else "libt2v_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value",
-         "-I", os.path.join(ROOT, "include"), "-I", HERE] + os.environ.get("T2V_EXTRA_HIPCC_FLAGS", "").split()
+         "-I", os.path.join(ROOT, "include"), "-I", HERE] + (["-DT2V_EXPERIMENTAL"] if EXPERIMENTAL else []) + os.environ.get("T2V_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc():
@@ -55,7 +61,7 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         # a build with its own output path OR its own flags is a variant: its objects never share a name with the product's (a
         # flagged object left behind as foo.o would look fresh to the next plain build and be linked into libt2v_hip.so)
-        variant = bool(os.environ.get("T2V_HIP_LIB_OUT") or os.environ.get("T2V_EXTRA_HIPCC_FLAGS"))
+        variant = bool(os.environ.get("T2V_HIP_LIB_OUT") or os.environ.get("T2V_EXTRA_HIPCC_FLAGS") or EXPERIMENTAL)
         o = os.path.join(HERE, s.replace(".hip", ".variant.o" if variant else ".o"))
         objs.append(o)
         # (variant builds are always recompiled; the product build only recompiles what changed)

@@ -227,6 +227,7 @@ extern "C" int t2v_lcm_step(const float* x, const void* eps, int eps_dt, const f
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
+#ifdef T2V_EXPERIMENTAL   // (4x slower than the MFMA tile on MI355X: in the T2V_EXPERIMENTAL=1 library only)
 // ---- direct 3x3 s1 p1 conv for a tiny number of OUTPUT channels (the VAE decoder's conv_out: 128 -> 3 at 320x512, ae_modules.py:641) ------
 // An MFMA tile is at least 64 channels wide: at cout = 3 the implicit-GEMM kernels multiply 0.77 TFLOP of padding per 16-frame decode
 // (0.75 ms).  Here a thread owns FOUR consecutive output pixels of an image row and all COUT channels: per filter row and 8-channel
@@ -332,6 +333,7 @@ extern "C" int t2v_conv3x3_small_cout(const void* x, int ldx, int n_img, int h, 
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
+#endif   // T2V_EXPERIMENTAL
 
 extern "C" int t2v_conv3x3_small_cin(const void* x, int n_img, int h, int w, int cin, const float* wgt, const float* bias,
                                      int cout, void* out, void* stream) {

@@ -1,0 +1,266 @@
+// Parameter gradients of the base weights for FULL fine-tuning of the student UNet (train_latent_t2v_turbo_v2.py:798-816 param
+// groups, :1262 accelerator.backward: every UNet parameter is trainable there, not only LoRA tensors).  Two pieces that the
+// token-contracted weight-gradient kernel (wgrad_tn.hip: dW = dy^T x) does not cover by itself:
+//
+//  * t2v_im2col_bf16 — the shifted-row matrix of a conv leaf, xcol[m][tap * C + c] = x[src(m, tap)][c] (zero outside the grid), in the
+//    K order of the forward's tap-major weight pack, for every gather mode of t2v_gemm (3x3 stride 1 / stride 2 / stride 2 padded
+//    right-bottom / over the nearest-x2 upsampled input, (3,1,1) temporal).  dW[n][tap][c] = sum_m dy[m][n] xcol[m][tap * C + c] is then
+//    ONE t2v_wgrad_tn product (openaimodel3d.py:155-159,179-184 ResBlock convs, :63-79 Down/Upsample, :257-309 TemporalConvBlock under
+//    autograd).  HBM-bound copy: 2 C bytes in, 2 taps C bytes out per output row.
+//  * t2v_norm_affine_grad — the per-channel reductions over token rows that the normalisation layers' affine parameters, every bias
+//    and the time-embedding row vector need:
+//        dgamma[u][c] = sum_{rows of u} dz[m][c] xhat[m][c],   dbeta[u][c] = sum_{rows of u} dz[m][c]
+//    with xhat from GroupNorm statistics ((mean, rstd) per (unit, group): lvdm/basics.py:78-89 GroupNormSpecific) or recomputed per row
+//    (LayerNorm: attention.py:300-311), dz = dy, or dy * silu'(xhat gamma + beta) where the forward applied SiLU after the norm
+//    (openaimodel3d.py:223-254 in_layers / out_layers), or plain column sums of dy (kind 2: biases; per-clip sums = d(loss)/d(emb)).
+//    `sum_rows` consecutive rows make one output row u.  Two launches: per-block partial sums in a fixed order, then their sum in block
+//    order — deterministic, no float atomics.  HBM-bound: reads x and dy once.
+#include "common.h"
+
+namespace {
+
+constexpr int IM_KIND_S1 = T2V_GEMM_CONV3X3, IM_KIND_S2 = T2V_GEMM_CONV3X3_S2, IM_KIND_UP2 = T2V_GEMM_CONV3X3_UP2, IM_KIND_T = T2V_GEMM_TCONV3,
+              IM_KIND_S2P = T2V_GEMM_CONV3X3_S2_PAD01;
+
+// one thread per 16-byte chunk (8 channels) of one (output row, tap)
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ x0, int c0, int ld0, const bf16_t* __restrict__ x1, int c1, int ld1,
+                                                     int mode, int n_img, int h, int w, int ho, int wo, int frames, int taps,
+                                                     bf16_t* __restrict__ out, int ldo, long long total) {
+    const int C = c0 + c1, cpr = C >> 3;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ci = (int)(i % cpr);
+        const long long mt = i / cpr;
+        const int tap = (int)(mt % taps);
+        const long long m = mt / taps;
+        long long src = -1;
+        if (mode == IM_KIND_T) {
+            const int hw = h * w;
+            const long long img = m / hw;            // (clip, frame)
+            const int f = (int)(img % frames), sf = f + tap - 1;
+            if (sf >= 0 && sf < frames) src = m + (long long)(tap - 1) * hw;
+        } else {
+            const int xo = (int)(m % wo), yo = (int)((m / wo) % ho);
+            const long long img = m / ((long long)wo * ho);
+            const int ty = tap / 3, tx = tap - 3 * ty;
+            int sy, sx;
+            bool ok;
+            if (mode == IM_KIND_S1) { sy = yo + ty - 1; sx = xo + tx - 1; ok = sy >= 0 && sy < h && sx >= 0 && sx < w; }
+            else if (mode == IM_KIND_S2) { sy = 2 * yo + ty - 1; sx = 2 * xo + tx - 1; ok = sy >= 0 && sy < h && sx >= 0 && sx < w; }
+            else if (mode == IM_KIND_S2P) { sy = 2 * yo + ty; sx = 2 * xo + tx; ok = sy < h && sx < w; }
+            else { const int uy = yo + ty - 1, ux = xo + tx - 1; ok = uy >= 0 && uy < 2 * h && ux >= 0 && ux < 2 * w; sy = uy >> 1; sx = ux >> 1; }
+            if (ok) src = (img * h + sy) * (long long)w + sx;
+        }
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (src >= 0) {
+            const int c = ci * 8;
+            v = c < c0 ? *(const uint4*)(x0 + src * ld0 + c) : *(const uint4*)(x1 + src * ld1 + (c - c0));
+        }
+        *(uint4*)(out + m * ldo + (long long)tap * C + ci * 8) = v;
+    }
+}
+
+// ---- per-channel row reductions ------------------------------------------------------------------------------------------------------
+// Block = 4 waves; a wave owns whole rows (lane l holds the 16-byte chunks l, l + 64, ... of the row: NJ of them), so a LayerNorm's row
+// statistics are two butterflies.  Block (bx, u) walks rows [bx * rows_per_blk, ...) of output row u; its four waves' register sums meet
+// in LDS in wave order; partial[(u * nblk + bx)][2][C].
+constexpr int AG_MAXJ = 4;   // C <= 64 * 8 * 4 = 2048
+template <int KIND>   // 0: GroupNorm statistics given, 1: LayerNorm (row statistics recomputed), 2: column sums of dy only
+__global__ __launch_bounds__(256) void affine_grad_partial_kernel(const bf16_t* __restrict__ x0, int c0, int ld0, const bf16_t* __restrict__ x1,
+                                                                  int c1, int ld1, long long sum_rows, int rows_per_blk, int rows_per_unit,
+                                                                  int groups, const float* __restrict__ stats, float ln_eps,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+                                                                  const bf16_t* __restrict__ dy, int ldy, float* __restrict__ partial) {
+    const int C = c0 + c1, cpr = C >> 3;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = blockIdx.y, bx = blockIdx.x, nblk = gridDim.x;
+    const long long r_begin = (long long)u * sum_rows + (long long)bx * rows_per_blk;
+    const long long r_end = min((long long)(u + 1) * sum_rows, r_begin + rows_per_blk);
+    float ag[AG_MAXJ][8], ab[AG_MAXJ][8], gm[AG_MAXJ][8], bt[AG_MAXJ][8];
+#pragma unroll
+    for (int j = 0; j < AG_MAXJ; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; gm[j][e] = 1.f; bt[j][e] = 0.f; }
+        const int ci = lane + 64 * j;
+        if (KIND != 2 && silu && ci < cpr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gm[j][e] = gamma[ci * 8 + e]; bt[j][e] = beta[ci * 8 + e]; }
+        }
+    }
+    const int cpg = KIND == 0 ? C / groups : 1;
+    const float inv_c = 1.0f / (float)C;
+    for (long long r = r_begin + wave; r < r_end; r += 4) {
+        float xv[AG_MAXJ][8], dv[AG_MAXJ][8];
+#pragma unroll
+        for (int j = 0; j < AG_MAXJ; ++j) {
+            const int ci = lane + 64 * j;
+            if (ci < cpr) {
+                unpack8(*(const uint4*)(dy + r * ldy + ci * 8), dv[j]);
+                if (KIND != 2) {
+                    const int c = ci * 8;
+                    unpack8(c < c0 ? *(const uint4*)(x0 + r * ld0 + c) : *(const uint4*)(x1 + r * ld1 + (c - c0)), xv[j]);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { dv[j][e] = 0.f; xv[j][e] = 0.f; }
+            }
+        }
+        float mean = 0.f, rstd = 1.f;
+        if (KIND == 1) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < AG_MAXJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += xv[j][e];
+            mean = wave_sum(s) * inv_c;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < AG_MAXJ; ++j)
+                if (lane + 64 * j < cpr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { const float dlt = xv[j][e] - mean; q += dlt * dlt; }
+                }
+            rstd = rsqrtf(wave_sum(q) * inv_c + ln_eps);
+        }
+        const long long unit = KIND == 0 ? r / rows_per_unit : 0;
+#pragma unroll
+        for (int j = 0; j < AG_MAXJ; ++j) {
+            const int ci = lane + 64 * j;
+            if (ci < cpr) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xh = 0.f, dz = dv[j][e];
+                    if (KIND == 0) {
+                        const float* st = stats + (unit * groups + (ci * 8 + e) / cpg) * 2;
+                        xh = (xv[j][e] - st[0]) * st[1];
+                    } else if (KIND == 1) {
+                        xh = (xv[j][e] - mean) * rstd;
+                    }
+                    if (KIND != 2 && silu) {   // y = silu(z), z = xhat gamma + beta: dz = dy * sigma(z) (1 + z (1 - sigma(z)))
+                        const float z = xh * gm[j][e] + bt[j][e];
+                        const float sg = 1.0f / (1.0f + __expf(-z));
+                        dz *= sg * (1.0f + z * (1.0f - sg));
+                    }
+                    ag[j][e] += dz * xh;
+                    ab[j][e] += dz;
+                }
+            }
+        }
+    }
+    // the four waves' sums, added in wave order
+    extern __shared__ float red[];   // [4][2][C]
+#pragma unroll
+    for (int j = 0; j < AG_MAXJ; ++j) {
+        const int ci = lane + 64 * j;
+        if (ci < cpr) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(wave * 2 + 0) * C + ci * 8 + e] = ag[j][e];
+                red[(wave * 2 + 1) * C + ci * 8 + e] = ab[j][e];
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = partial + ((long long)u * nblk + bx) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = ((red[i] + red[2 * C + i]) + red[4 * C + i]) + red[6 * C + i];
+}
+
+// out[u][c] = sum over the unit's blocks, in block order
+__global__ __launch_bounds__(256) void affine_grad_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dgamma,
+                                                                int ld_g, float* __restrict__ dbeta, int ld_b) {
+    const int u = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 2 * C) return;
+    const float* src = partial + (long long)u * nblk * 2 * C + i;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += src[(long long)b * 2 * C];
+    if (i < C) { if (dgamma) dgamma[(long long)u * ld_g + i] = s; }
+    else if (dbeta) dbeta[(long long)u * ld_b + (i - C)] = s;
+}
+
+}  // namespace
+
+extern "C" long long t2v_im2col_rows(int mode, int n_img, int h, int w) {
+    if (mode == T2V_GEMM_CONV3X3 || mode == T2V_GEMM_TCONV3) return (long long)n_img * h * w;
+    if (mode == T2V_GEMM_CONV3X3_S2) return (long long)n_img * ((h - 1) / 2 + 1) * ((w - 1) / 2 + 1);
+    if (mode == T2V_GEMM_CONV3X3_S2_PAD01) return (long long)n_img * ((h - 2) / 2 + 1) * ((w - 2) / 2 + 1);
+    if (mode == T2V_GEMM_CONV3X3_UP2) return (long long)n_img * 4 * h * w;
+    return -1;
+}
+
+extern "C" int t2v_im2col_bf16(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, int mode, int n_img, int h, int w, int frames,
+                               void* out, int ldo, void* stream) {
+    T2V_REQUIRE(x0 && out && n_img > 0 && h > 0 && w > 0 && c0 > 0 && c1 >= 0 && (c1 == 0 || x1), T2V_EINVAL, "t2v_im2col_bf16: bad argument");
+    const long long rows = t2v_im2col_rows(mode, n_img, h, w);
+    T2V_REQUIRE(rows > 0, T2V_EINVAL, "t2v_im2col_bf16: mode must be one of the conv gather modes of t2v_gemm");
+    const int taps = mode == T2V_GEMM_TCONV3 ? 3 : 9, C = c0 + c1;
+    T2V_REQUIRE(c0 % 8 == 0 && c1 % 8 == 0 && ld0 % 8 == 0 && (c1 == 0 || ld1 % 8 == 0) && ldo % 8 == 0 && ldo >= taps * C &&
+                    (uintptr_t)x0 % 16 == 0 && (uintptr_t)x1 % 16 == 0 && (uintptr_t)out % 16 == 0,
+                T2V_ESHAPE, "t2v_im2col_bf16: channels / row strides in multiples of 8, 16-byte aligned rows, ldo >= taps * C");
+    T2V_REQUIRE(mode != T2V_GEMM_TCONV3 || (frames > 0 && n_img % frames == 0), T2V_ESHAPE, "t2v_im2col_bf16: n_img must be clips x frames");
+    int ho = h, wo = w;
+    if (mode == T2V_GEMM_CONV3X3_S2) { ho = (h - 1) / 2 + 1; wo = (w - 1) / 2 + 1; }
+    else if (mode == T2V_GEMM_CONV3X3_S2_PAD01) { ho = (h - 2) / 2 + 1; wo = (w - 2) / 2 + 1; }
+    else if (mode == T2V_GEMM_CONV3X3_UP2) { ho = 2 * h; wo = 2 * w; }
+    const long long total = rows * taps * (C / 8);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256LL * 16) blocks = 256LL * 16;
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1,
+                       ld1, mode, n_img, h, w, ho, wo, frames, taps, (bf16_t*)out, ldo, total);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+
+static int affine_grad_blocks(long long sum_rows, long long n_out) {
+    // about 1024 blocks over the whole launch, at least 16 rows (four per wave) each
+    long long nblk = (1024 + n_out - 1) / n_out;
+    const long long max_blk = (sum_rows + 15) / 16;
+    if (nblk > max_blk) nblk = max_blk;
+    if (nblk < 1) nblk = 1;
+    return (int)nblk;
+}
+
+extern "C" long long t2v_norm_affine_grad_ws_floats(long long rows, long long sum_rows, int channels) {
+    if (rows <= 0 || sum_rows <= 0 || rows % sum_rows || channels <= 0) return -1;
+    const long long n_out = rows / sum_rows;
+    return n_out * affine_grad_blocks(sum_rows, n_out) * 2 * channels;
+}
+
+extern "C" int t2v_norm_affine_grad(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, long long rows, long long sum_rows, int kind,
+                                    int rows_per_unit, int groups, const float* stats, float ln_eps, const float* gamma, const float* beta,
+                                    int silu, const void* dy, int ldy, float* dgamma, int ld_dgamma, float* dbeta, int ld_dbeta, float* ws,
+                                    void* stream) {
+    T2V_REQUIRE(dy && ws && rows > 0 && sum_rows > 0 && rows % sum_rows == 0 && kind >= 0 && kind <= 2 && (dgamma || dbeta), T2V_EINVAL,
+                "t2v_norm_affine_grad: bad argument");
+    if (kind == 2) { c1 = 0; x1 = nullptr; silu = 0; }
+    const int C = c0 + c1;
+    T2V_REQUIRE(C > 0 && C % 8 == 0 && C <= 64 * 8 * AG_MAXJ && c0 % 8 == 0 && ldy % 8 == 0 && (uintptr_t)dy % 16 == 0, T2V_ESHAPE,
+                "t2v_norm_affine_grad: channels a multiple of 8 (<= 2048), 16-byte aligned rows");
+    if (kind != 2) {
+        T2V_REQUIRE(x0 && ld0 % 8 == 0 && (uintptr_t)x0 % 16 == 0 && (c1 == 0 || (x1 && ld1 % 8 == 0 && (uintptr_t)x1 % 16 == 0)), T2V_ESHAPE,
+                    "t2v_norm_affine_grad: the normalised tensor's rows must be 16-byte aligned");
+        T2V_REQUIRE(!silu || (gamma && beta), T2V_EINVAL, "t2v_norm_affine_grad: SiLU behind the norm needs gamma and beta");
+        T2V_REQUIRE(dgamma, T2V_EINVAL, "t2v_norm_affine_grad: dgamma");
+    }
+    if (kind == 0)
+        T2V_REQUIRE(stats && groups > 0 && C % groups == 0 && rows_per_unit > 0 && rows % rows_per_unit == 0, T2V_ESHAPE,
+                    "t2v_norm_affine_grad: GroupNorm statistics [rows / rows_per_unit][groups][2]");
+    const long long n_out = rows / sum_rows;
+    T2V_REQUIRE(n_out <= 65535, T2V_ESHAPE, "t2v_norm_affine_grad: grid");
+    const int nblk = affine_grad_blocks(sum_rows, n_out);
+    const int rows_per_blk = (int)((sum_rows + nblk - 1) / nblk);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t smem = (size_t)8 * C * sizeof(float);
+    dim3 grid(nblk, (unsigned)n_out);
+#define T2V_AG_LAUNCH(K)                                                                                                                      \
+    hipLaunchKernelGGL(affine_grad_partial_kernel<K>, grid, dim3(256), smem, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, sum_rows, \
+                       rows_per_blk, rows_per_unit, groups, stats, ln_eps, gamma, beta, silu, (const bf16_t*)dy, ldy, ws)
+    if (kind == 0) T2V_AG_LAUNCH(0);
+    else if (kind == 1) T2V_AG_LAUNCH(1);
+    else T2V_AG_LAUNCH(2);
+#undef T2V_AG_LAUNCH
+    T2V_CHECK_LAUNCH();
+    hipLaunchKernelGGL(affine_grad_final_kernel, dim3((2 * C + 255) / 256, (unsigned)n_out), dim3(256), 0, s, (const float*)ws, nblk, C, dgamma,
+                       ld_dgamma, dbeta, ld_dbeta);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}

@@ -25,7 +25,9 @@
 //  * workgroup id -> tile mapping is XCD-aware: each of the 8 XCDs (private L2s) gets a contiguous
 //    run of tiles, N-tile fastest, so the tiles that share an A panel hit the same L2.
 #include "common.h"
+#ifdef T2V_EXPERIMENTAL
 #include "gemm2.h"
+#endif
 #include "gelu_poly.h"
 #include <cstdlib>
 #include <type_traits>
@@ -1485,6 +1487,7 @@ static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, in
 // 3.75 LDS-DMA pieces per wave per 25 MFMAs (conv_halo: 1.25) and 64-byte row pieces fetch every cache line twice — the loop is
 // bound by DMA issue and L2 -> LDS bytes, not by its schedule.  Kept as a tested, measured negative result: OFF unless asked for
 // (t2v_gemm2_enable(1) / T2V_GEMM2=1: the library's own routing rule; tile id 50 / 51 forced: that tile).
+#ifdef T2V_EXPERIMENTAL
 static int g_gemm2 = -1;
 extern "C" int t2v_gemm2_enable(int on) { g_gemm2 = on ? 1 : 0; return T2V_OK; }
 // c2 > 0: the second family takes this launch.  It implements the column statistics (fuse == 2) itself; every other fused request
@@ -1497,6 +1500,7 @@ static int gemm2_route(const t2v_gemm_desc* dd, int fuse, Gemm2Params& p2, int& 
     if ((fuse & ~2) || dd->ln_out || !(forced || (g_gemm2 && !g_force_cfg))) return T2V_OK;
     return t2v_gemm2_prepare(dd, p2, forced, c2);
 }
+#endif   // T2V_EXPERIMENTAL
 
 extern "C" int t2v_gemm_fuse_supported(const t2v_gemm_desc* dd) {
     GemmParams p;
@@ -1504,6 +1508,7 @@ extern "C" int t2v_gemm_fuse_supported(const t2v_gemm_desc* dd) {
     bool ok = false;
     const int rc = gemm_prepare(dd, p, cfg, fuse, fuse_cfg, ok);
     if (rc != T2V_OK) return rc;
+#ifdef T2V_EXPERIMENTAL
     if (fuse == 2) {   // column statistics: the second kernel family carries them on the launches it takes
         Gemm2Params p2;
         int c2 = 0;
@@ -1511,6 +1516,7 @@ extern "C" int t2v_gemm_fuse_supported(const t2v_gemm_desc* dd) {
         if (rc2 != T2V_OK) return rc2;
         if (c2) return 1;
     }
+#endif
     return ((fuse & ~8) && ok) ? 1 : 0;   // (bit 8 is the library's own choice for dropout launches, not a request)
 }
 
@@ -1536,6 +1542,7 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
     if (rc != T2V_OK) return rc;
     t2v_gemm_desc& d = p.d;
     hipStream_t s = (hipStream_t)stream;
+#ifdef T2V_EXPERIMENTAL
     {
         Gemm2Params p2;
         int c2 = 0;
@@ -1543,6 +1550,7 @@ extern "C" int t2v_gemm(const t2v_gemm_desc* dd, void* stream) {
         if (rc2 != T2V_OK) return rc2;
         if (c2) return t2v_gemm2_dispatch(c2, p2, s);
     }
+#endif
     if (fuse) {
         T2V_REQUIRE(fuse_ok, T2V_ESHAPE, "t2v_gemm: this launch cannot carry fused statistics (ask t2v_gemm_fuse_supported first)");
         return t2v_gemm_launch_fused(fuse_cfg, fuse, p, s);

@@ -57,7 +57,11 @@ struct Entry { const char* name; int (*call)(const uint64_t*, int, void*); };
 #define T2V_ENTRY(f) {#f, &Thunk<&f>::call}
 // every launching entry point of include/t2v_hip.h (stream last)
 const Entry kTable[] = {
-    T2V_ENTRY(t2v_gemm), T2V_ENTRY(t2v_conv_halo), T2V_ENTRY(t2v_linear_pr), T2V_ENTRY(t2v_ffn_fused), T2V_ENTRY(t2v_conv3x3_small_cin), T2V_ENTRY(t2v_gn_stats),
+    T2V_ENTRY(t2v_gemm), T2V_ENTRY(t2v_conv_halo), T2V_ENTRY(t2v_linear_pr),
+#ifdef T2V_EXPERIMENTAL
+    T2V_ENTRY(t2v_ffn_fused),
+#endif
+    T2V_ENTRY(t2v_conv3x3_small_cin), T2V_ENTRY(t2v_gn_stats),
     T2V_ENTRY(t2v_gn_apply), T2V_ENTRY(t2v_group_norm), T2V_ENTRY(t2v_group_norm_cs), T2V_ENTRY(t2v_gn_stats_cs), T2V_ENTRY(t2v_layernorm),
     T2V_ENTRY(t2v_softmax_rows), T2V_ENTRY(t2v_attn_spatial), T2V_ENTRY(t2v_attn_temporal), T2V_ENTRY(t2v_ncfhw_to_tokens),
     T2V_ENTRY(t2v_tokens_to_ncfhw), T2V_ENTRY(t2v_timestep_embedding), T2V_ENTRY(t2v_silu), T2V_ENTRY(t2v_fill_zero), T2V_ENTRY(t2v_cast),
@@ -65,7 +69,7 @@ const Entry kTable[] = {
     T2V_ENTRY(t2v_sumpool2x2), T2V_ENTRY(t2v_gn_bwd2), T2V_ENTRY(t2v_layernorm_bwd), T2V_ENTRY(t2v_geglu_fwd), T2V_ENTRY(t2v_geglu_bwd),
     T2V_ENTRY(t2v_scatter2x), T2V_ENTRY(t2v_add_bf16), T2V_ENTRY(t2v_attn_temporal_bwd), T2V_ENTRY(t2v_adamw_step), T2V_ENTRY(t2v_ema_update),
     T2V_ENTRY(t2v_sumsq), T2V_ENTRY(t2v_gather_f32), T2V_ENTRY(t2v_attn_spatial_bwd), T2V_ENTRY(t2v_wgrad_tn), T2V_ENTRY(t2v_wgrad_tn_group),
-    T2V_ENTRY(t2v_transpose_pad_bf16), T2V_ENTRY(t2v_dropout_bf16),
+    T2V_ENTRY(t2v_transpose_pad_bf16), T2V_ENTRY(t2v_dropout_bf16), T2V_ENTRY(t2v_im2col_bf16), T2V_ENTRY(t2v_norm_affine_grad),
 };
 constexpr int kEntries = (int)(sizeof(kTable) / sizeof(kTable[0]));
 

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__
 extern "C" int t2v_dropout_bf16(const void* x, int ldx, const void* resid, int ldr, void* out, int ldo, long long rows, int ncols,
                                 float p, const void* seed, unsigned site, void* stream) {
     T2V_REQUIRE(x && out && seed && rows > 0 && ncols > 0, T2V_EINVAL, "t2v_dropout_bf16: null pointer / empty");
-    T2V_REQUIRE(p >= 0.f && p < 1.f, T2V_EINVAL, "t2v_dropout_bf16: p must be in [0, 1)");
+    // (p >= 1 - 2^-16 would quantise to "one element in 65536 survives at scale 65536": refused, torch's p = 1 is all zeros)
+    T2V_REQUIRE(p >= 0.f && p < 1.f - 1.f / 65536.f, T2V_EINVAL, "t2v_dropout_bf16: p must be in [0, 1 - 2^-16)");
     T2V_REQUIRE(ncols % 2 == 0 && ldx % 2 == 0 && ldo % 2 == 0 && (!resid || ldr % 2 == 0) && ldx >= ncols && ldo >= ncols, T2V_ESHAPE,
                 "t2v_dropout_bf16: even column count / row strides");
     T2V_REQUIRE((uintptr_t)x % 4 == 0 && (uintptr_t)out % 4 == 0 && (!resid || (uintptr_t)resid % 4 == 0), T2V_ESHAPE,

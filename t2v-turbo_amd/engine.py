@@ -138,6 +138,7 @@ class Packer:
         self.wdtype, self.device = wdtype, device
         self.merge_lora = merge_lora
         self.cache = {}
+        self.makers = {}
 
     def wb(self, mod):
         return effective_weight_bias(mod, self.merge_lora)
@@ -145,7 +146,24 @@ class Packer:
     def _memo(self, key, fn):
         if key not in self.cache:
             self.cache[key] = fn()
+            self.makers[key] = fn
         return self.cache[key]
+
+    def refresh(self):
+        """Re-make every pack from the CURRENT parameters into the tensors that are already there (full fine-tuning: the weights move
+        every optimizer step, the recorded launch lists keep pointing at the same packs).  Entries are re-made in the order they were
+        first made, so a pack derived from another cached pack (transposes, fragment packs) sees its refreshed source."""
+        def put(old, new):
+            if isinstance(old, torch.Tensor):
+                if old.data_ptr() != new.data_ptr():
+                    old.copy_(new)
+            elif isinstance(old, (tuple, list)):
+                for o, n in zip(old, new):
+                    put(o, n)
+        for key, fn in list(self.makers.items()):
+            if key[0] == "full_idx":   # (index tables: no weights inside)
+                continue
+            put(self.cache[key], fn())
 
     def f32(self, p):
         return None if p is None else self._memo(("f32", id(p)), lambda: p.detach().to(self.device, torch.float32).contiguous())
@@ -665,11 +683,15 @@ class UNetEngine(_Engine):
     # The inference dataflow applies them with the counter-based masks of t2v_dropout_bf16 between the GroupNorm + SiLU and the
     # (3,1,1) conv, exactly where the gradient engine puts them for the student; any other active Dropout still refuses.
     def _any_live_dropout(self):
+        # every nn.Dropout is listed (not only p > 0: p can be raised in place with no parameter change); the list is rebuilt per weight
+        # version and on every 64th call (a Dropout swapped into the tree without touching a parameter is then seen within 64 calls at
+        # 1 ms per walk, instead of never)
+        from .nn_util import walk_modules
         cache = getattr(self, "_dropout_mods", None)
-        if cache is None or cache[0] != self.fingerprint:
-            from .nn_util import walk_modules
-            cache = self._dropout_mods = (self.fingerprint, [mod for mod in walk_modules(self.model) if isinstance(mod, nn.Dropout) and mod.p > 0])
-        return any(mod.training for mod in cache[1])
+        if cache is None or cache[0] != self.fingerprint or cache[2] >= 64:
+            cache = self._dropout_mods = [self.fingerprint, [mod for mod in walk_modules(self.model) if isinstance(mod, nn.Dropout)], 0]
+        cache[2] += 1
+        return any(mod.training and mod.p > 0 for mod in cache[1])
 
     def _active_tconv_dropouts(self):
         from .nn_util import walk_modules

@@ -34,11 +34,12 @@ import torch.nn as nn
 from . import native as nt
 from .native import on_tensor_device
 from .engine import Act, Packer, UNetEngine, effective_weight_bias, is_lora_leaf, leaf_out_channels
+from .engine_full import FullTrainMixin
 from .engine_lora import LoraTrainMixin, _pad
 from .unet3d import Downsample, ResBlock, SpatialTransformer, TemporalTransformer, TimestepEmbedSequential, Upsample
 
 
-class UNetGradEngine(LoraTrainMixin, UNetEngine):
+class UNetGradEngine(FullTrainMixin, LoraTrainMixin, UNetEngine):
     # spatial self-attention backward by the flash-style kernels of csrc/attention_bwd.hip (probabilities never in memory);
     # T2V_FLASH_ATTN_BWD=0 selects the GEMM-formulated one (both validated on MI355X; 342 -> 320 ms per distillation step)
     flash_attn_bwd = os.environ.get("T2V_FLASH_ATTN_BWD", "1") == "1"
@@ -84,7 +85,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         from .nn_util import walk_modules
         mods = walk_modules(self.model)  # (one cheap walk per call: order does not matter here)
         active = [mod for mod in mods if isinstance(mod, nn.Dropout) and mod.p > 0 and mod.training]
-        if active and self.training_lora:
+        if active and self.trains:
             from .unet3d import TemporalConvBlock
             known = {id(mod.dropout) for mod in mods if is_lora_leaf(mod)}
             for blk in mods:
@@ -92,7 +93,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                     known.update(id(l) for st in (blk.conv1, blk.conv2, blk.conv3, blk.conv4) for l in st if isinstance(l, nn.Dropout))
             other = [mod for mod in active if id(mod) not in known]
             if other:
-                raise RuntimeError(f"native LoRA training: {len(other)} active Dropout module(s) the engine does not apply")
+                raise RuntimeError(f"native training: {len(other)} active Dropout module(s) the engine does not apply")
         return len(active)
 
     @on_tensor_device
@@ -101,14 +102,16 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         the caller in torch (``conditioning_torch``) so that autograd owns that branch's 27 tiny leaves."""
         m = self.model
         assert x.dim() == 5 and context is not None
-        assert (emb_all is not None) == self.training_lora, "emb_all is given exactly when LoRA tensors are bound"
-        self._check_weights(m, self.lora_ids if self.training_lora else ())
+        assert (emb_all is not None) == self.trains, "emb_all is given exactly when LoRA tensors / the base weights are bound for training"
+        # (full fine-tuning: every parameter moves every step — the packs are re-filled in place instead of dropping the plans)
+        if not self.training_full:
+            self._check_weights(m, self.lora_ids if self.training_lora else ())
         dropping = self._active_dropouts()
-        if dropping and not self.training_lora:
+        if dropping and not self.trains:
             raise RuntimeError("native UNet gradient path: a Dropout(p>0) is in training mode; call .eval() first")
         key = ("grad", dropping, tuple(x.shape), x.dtype, tuple(context.shape), context.dtype, isinstance(fps, int),
                None if timestep_cond is None else tuple(timestep_cond.shape),
-               None if motion_cond is None else tuple(motion_cond.shape), x.device, self.training_lora)
+               None if motion_cond is None else tuple(motion_cond.shape), x.device, self.training_lora, self.training_full)
         plan = self.plans.get(key)
         if dropping:  # one seed per forward; the backward regenerates the same masks from it
             self._seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
@@ -134,7 +137,11 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
                 st["mc"].copy_(motion_cond)
             if emb_all is not None:
                 st["emb_all"].copy_(emb_all.detach())
-                self.refresh_lora_packs()
+                if self.training_lora:
+                    self.refresh_lora_packs()
+                else:
+                    self.plan = plan
+                    self.full_refresh_packs()
             if dropping:
                 st["seed"].fill_(self._seed)
             if "seed" in st:
@@ -179,8 +186,9 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             self._replay(plan, "rec_bwd")
         finally:
             self._overlap = None
-        if self.training_lora:
+        if self.trains:
             self.d_emb_all = plan["d_emb"]
+        if self.training_lora:
             if flat_grad is not None:
                 assert flat_grad.dtype == torch.float32 and flat_grad.numel() == self.lora_numel and flat_grad.is_contiguous()
                 if world:
@@ -283,12 +291,24 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             plan["d_emb"] = torch.zeros_like(st["emb_all"])
             st["seed"] = torch.full((1,), getattr(self, "_seed", 0), dtype=torch.int64, device=x.device)
             self.seed_t = st["seed"]
+        if self.training_full:
+            # plain leaves on packs of the current weights (re-filled in place per step: Packer.refresh); one fp32 gradient per parameter
+            self.pk = Packer(self.adt, x.device)
+            st["emb_all"] = emb_all.detach().to(x.device, torch.float32).clone().contiguous()
+            plan["d_emb"] = torch.zeros_like(st["emb_all"])
+            plan["fgrads"] = {}
+            st["seed"] = torch.full((1,), getattr(self, "_seed", 0), dtype=torch.int64, device=x.device)
+            self.seed_t = st["seed"]
+            self._full_fp = None
+            self.full_refresh_packs()
         self.plan = plan
         self.tape, self.refs = [], {}
+        self._fsaved = {}
 
         def fwd():
             self.tape.clear()
             self.refs.clear()
+            self._fsaved.clear()
             self.drop_sites = []
             plan["probs"].clear()
             self._forward_tape(st, out)
@@ -351,6 +371,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         """-> dx [M, C] (one buffer even when x is a virtual concat: the consumer takes column slices)."""
         ops = self.ops
         G = norm.num_groups
+        if self.training_full:
+            self.full_norm_grads(norm, x, dy, kind=0, silu=silu, rows_per_unit=rows, stats=stats)
         ws = self.buf(1, max(ops.gn_bwd_ws_floats(units, rows, G), 1), torch.float32)
         dx = self.buf(x.M, x.C)
         ops.gn_bwd(x.parts[0], units, rows, stats, self.pk.f32(norm.weight), self.pk.f32(norm.bias), silu, dy, resid, ws, dx, G,
@@ -379,7 +401,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         p = ps.pop()
         if p <= 0:
             return None
-        assert self.training_lora, "dropout is only applied on the LoRA training path"
+        assert self.trains, "dropout is only applied on the training paths"
         self.drop_sites.append((drops, kind, meta))
         return float(p), len(self.drop_sites) - 1
 
@@ -397,6 +419,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         x = a if isinstance(a, Act) else Act(a, 0, 0, 0)
         mods = lora if lora is not None else ([mod] if mod is not None else None)
         zf = grp = None
+        if self.training_full and mods:
+            self.full_save(mods, x, perm=perm)
         if self.training_lora and mods and all(is_lora_leaf(mm) for mm in mods):
             assert act == nt.ACT_NONE
             meta = (self.B, self.F, x.M // (self.B * self.F)) if self.row_kind == "temporal" else (self.B, self.F, self.ctx_len)
@@ -430,6 +454,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
 
     def conv(self, x, mod, mode, *, frames=0, rowvec=None, rowvec_div=0, residual=None, out_dtype=None, w=None, bias="auto", frozen_pack=False):
         zf = extra = None
+        if w is None and self.training_full and mod is not None:
+            self.full_save([mod], x, frames=frames)
         if w is None and self.training_lora and is_lora_leaf(mod):
             if mode == nt.GEMM_CONV3X3_S2:
                 ho, wo = (x.h - 1) // 2 + 1, (x.w - 1) // 2 + 1
@@ -452,6 +478,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
     def lin_b(self, dy, w_t, residual=None, lora=None, need_dx=True, colsum=None):
         """dx = dy @ W for a [K, N]-transposed pack w_t (rows = input features); ``lora``: the leaves behind w_t — in
         training their weight gradients are taken here and their branch's data gradient joins dx."""
+        if self.training_full and lora:
+            self.full_linear_grads(lora, dy)
         grp = self.saved_group(lora, nt.GEMM_LINEAR)
         dl = None
         if grp is not None:
@@ -500,6 +528,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             return self.conv(Act(src, n, h, w), None, inner_mode, frames=frames, w=wpack, bias=None, residual=residual,
                              out_dtype=odt, frozen_pack=frozen).t
 
+        if self.training_full and dy_pad is None:
+            self.full_conv_grads(mod, mode, dy.t)
         grp = self.saved_group([mod], mode)
         dl = None
         if grp is not None:
@@ -540,6 +570,11 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         h0 = self.buf(B * F * H * W, c_first)
         ops.conv_small(xt, B * F, H, W, pk.small_conv(conv_in), pk.bias(conv_in), h0)
         self.pool.put(xt)
+        if self.training_full:   # the entry conv's weight gradient contracts against the latent rows, zero-padded to one 16-byte chunk
+            x8 = self.buf(B * F * H * W, 8)
+            ops.fill_zero(x8)
+            ops.ncfhw_to_tokens(x, x8)
+            self.full_save([conv_in], Act(x8, B * F, H, W), frames=0)
         if self.training_lora and is_lora_leaf(conv_in):
             # LoRA branch of the entry conv: the 4-channel latent zero-padded to one 64-channel K slab of the implicit GEMM
             x64 = self.buf(B * F * H * W, 64)
@@ -587,6 +622,12 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             dt = self.buf(n_img * H * W, xin.C)
             ops.conv_small(d4, n_img, H, W, pk.small_conv_dgrad(m.out[2], cin_pad=cpad), None, dt)
             self.pool.put(d4)
+            if self.training_full:   # the exit conv's own weight / bias gradient: dy zero-padded to one 16-byte chunk of columns
+                d8 = self.buf(n_img * H * W, 8)
+                ops.fill_zero(d8)
+                ops.ncfhw_to_tokens(dout, d8)
+                self.full_conv_grads(m.out[2], nt.GEMM_CONV3X3, d8)
+                self.pool.put(d8)
             grp = self.saved_group([m.out[2]], nt.GEMM_CONV3X3)
             if grp is not None:  # LoRA of the exit conv: dy zero-padded to 64 columns (K of  g = s dy U)
                 d64 = self.buf(n_img * H * W, 64)
@@ -630,7 +671,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         self.ctx_len = L
         self.ctx_kv = {}
         self._ctx_f = None
-        if self.training_lora:  # the M = B-row branch belongs to torch autograd (engine_lora.py); its result is an input
+        if self.trains:  # the M = B-row branch belongs to torch autograd (engine_lora.py / engine_full.py); its result is an input
             assert st["emb_all"].shape == (B, off)
             self.emb_all = st["emb_all"]
             return
@@ -845,6 +886,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             self.pool.put(d_t2.t, h1.t, st2)
             # training: the per-clip column sums of d_h1 are d(loss)/d(emb_all) of this block (rowvec of the forward conv)
             colsum = self.plan["d_emb"][:, off:off + cout] if self.training_lora else None
+            if self.training_full:
+                self.full_colsum(d_h1, self.plan["d_emb"][:, off:off + cout], F * hw)
             d_t1 = self.conv_b(Act(d_h1, *geom), rb.in_layers[2], nt.GEMM_CONV3X3, geom, colsum=colsum)
             self.pool.put(d_h1)
             d_skip = d_h2 if identity else self.lin_b(d_h2, self.pk.mat_t(rb.skip_connection), lora=[rb.skip_connection])
@@ -977,6 +1020,8 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             return ln
 
         def ln_b(norm, src, d_ln, resid):
+            if self.training_full:
+                self.full_norm_grads(norm, src, d_ln, kind=1)
             dx = self.buf(M, C)
             ops.layernorm_bwd(src, pk.f32(norm.weight), norm.eps, d_ln, resid, dx)
             return dx
@@ -1010,7 +1055,7 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
             vt = self.buf(n_img * inner, kp)
             if kp != hw:
                 ops.fill_zero(vt)
-            if self.training_lora and is_lora_leaf(attn.to_v):
+            if (self.training_lora and is_lora_leaf(attn.to_v)) or self.training_full:
                 # training: V token-major through the injected leaf, then transposed per image (inference: V^T straight
                 # out of a GEMM with the weight as the row operand)
                 v = self.linear(src, attn.to_v, bias=None)
@@ -1109,11 +1154,11 @@ class UNetGradEngine(LoraTrainMixin, UNetEngine):
         def cross_attn(attn, src):
             heads, L = attn.heads, self.ctx_len
             q = self.linear(src, attn.to_q, bias=None)
-            own_kv = self.training_lora and is_lora_leaf(attn.to_k) and is_lora_leaf(attn.to_v)
+            own_kv = (self.training_lora and is_lora_leaf(attn.to_k) and is_lora_leaf(attn.to_v)) or self.training_full
             # The frames of a clip share the text K / V (one attention of F*hw queries over L keys per clip and head) — unless
             # the train-mode student's dropout sits on the to_k / to_v LoRA branches: the reference projects the context
             # REPEATED per frame (openaimodel3d.py:710), so every frame draws its own masks and has its own K / V.
-            per_frame = own_kv and any(d.training and d.p > 0 for d in (attn.to_k.dropout, attn.to_v.dropout))
+            per_frame = own_kv and self.training_lora and any(d.training and d.p > 0 for d in (attn.to_k.dropout, attn.to_v.dropout))
             nf = F if per_frame else 1           # K / V sets per clip
             mq = hw if per_frame else F * hw     # queries per K / V set
             if own_kv:

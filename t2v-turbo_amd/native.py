@@ -74,7 +74,10 @@ def dropout_thr16(p):
 
 def dropout_inv_keep(p):
     """1 / (1 - p') with p' = thr16 / 65536, the drop probability the 16-bit mask really has (p = 0.1 -> 6553 / 65536): the scale
-    that keeps E[dropout(x)] = x exactly.  p < 2^-16 quantises to 'keep everything' at scale 1."""
+    that keeps E[dropout(x)] = x exactly.  p < 2^-16 quantises to 'keep everything' at scale 1; p must be < 1 - 2^-16 (the library
+    refuses more: one element in 65536 would survive at scale 65536 where torch gives all zeros)."""
+    if dropout_thr16(p) >= 0xFFFF:
+        raise NativeError(f"dropout p = {p}: the 16-bit mask cannot represent p >= 1 - 2^-16")
     return 65536.0 / (65536.0 - dropout_thr16(p))
 
 
@@ -228,6 +231,13 @@ _SIGS = {
     "t2v_wgrad_tn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int,
                                C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
     "t2v_wgrad_tn_group": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "t2v_im2col_rows": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "t2v_im2col_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_int, C.c_void_p]),
+    "t2v_norm_affine_grad_ws_floats": (C.c_longlong, [C.c_longlong, C.c_longlong, C.c_int]),
+    "t2v_norm_affine_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_int,
+                                       C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "t2v_transpose_pad_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
                                          C.c_longlong, C.c_void_p]),
     "t2v_dropout_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_float,
@@ -235,7 +245,17 @@ _SIGS = {
     "t2v_lcm_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_float, C.c_float, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
-EXPORTED = sorted(_SIGS)
+# Entry points of a T2V_EXPERIMENTAL=1 build only (libt2v_hip_exp.so: the measured negative results — the second t2v_gemm kernel family, the
+# one-launch feed-forward, the alternative flash-attention forms, the direct small-Cout conv): bound when the loaded library has them.
+EXPERIMENTAL = ("t2v_gemm2_enable", "t2v_ffn_fused_supported", "t2v_ffn_fused", "t2v_conv3x3_small_cout_supported", "t2v_conv3x3_small_cout",
+                "t2v_attn_spatial_form")
+EXPORTED = sorted(n for n in _SIGS if n not in EXPERIMENTAL)
+
+
+def has_experimental(lib=None):
+    """True if the loaded library is a T2V_EXPERIMENTAL=1 build (csrc/build.py)."""
+    lib = lib if lib is not None else load()
+    return hasattr(lib, "t2v_ffn_fused")
 
 
 def load(path=None):
@@ -253,6 +273,8 @@ def load(path=None):
     except OSError as e:  # e.g. libamdhip64 missing
         raise NativeError(f"cannot load {path}: {e}") from e
     for name, (res, args) in _SIGS.items():
+        if name in EXPERIMENTAL and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
@@ -465,7 +487,9 @@ class HipOps:
         flush(len(recording))
         return segs
 
-    max_progs = 16   # compiled launch lists kept (least recently used beyond this are dropped, one at a time)
+    # compiled launch lists kept (least recently used beyond this are dropped, one at a time).  A service that rotates through more
+    # live plans than this recompiles a list per replay: T2V_MAX_PROGS sizes it (every engine keeps T2V_MAX_PLANS plans, default 4).
+    max_progs = int(os.environ.get("T2V_MAX_PROGS", "16"))
 
     def replay(self, recording, stream, cache=True):
         """Issue a recorded launch list.  ``cache=False``: a one-shot list (the sub-lists an engine cuts for hipGraph capture) —
@@ -592,7 +616,8 @@ class HipOps:
         if tile_cfg == 0:
             key = (mode, M, N, taps * (d.c0 + d.c1), batch)
             tuned = self.tune.lookup(key) if (hasattr(self.tune, "lookup") and not tune_exact) else self.tune.get(key)
-        d.tile_cfg, d.split_k = tuned if tuned else (tile_cfg, split_k)
+        # (a nearest-shape hit whose K-split plan is not trusted comes back with split 0: the caller's hint then stands)
+        d.tile_cfg, d.split_k = (tuned[0], tuned[1] or split_k) if tuned else (tile_cfg, split_k)
         if d.drop_thr:
             d.split_k = 1
         if ln is not None:  # (gamma fp32 [N], beta fp32 [N], eps, out2 bf16 [M, N]): LayerNorm(out) as a second output (N == 320)
@@ -623,7 +648,7 @@ class HipOps:
         return d
 
     def ffn_fused_supported(self, C_):
-        return bool(self.lib.t2v_ffn_fused_supported(int(C_)))
+        return hasattr(self.lib, "t2v_ffn_fused_supported") and bool(self.lib.t2v_ffn_fused_supported(int(C_)))
 
     def ffn_fused(self, x, w1p, b1p, w2p, b2, eps, out):
         """out = x + FF(LayerNorm(x)) (GEGLU feed-forward) in one launch; packed weights: ``ffn_pack`` (include/t2v_hip.h)."""
@@ -634,7 +659,7 @@ class HipOps:
         self._call("t2v_conv3x3_small_cin", _p(x), n_img, h, w, x.shape[1], _p(wgt), _p(bias), out.shape[1], _p(out))
 
     def conv_small_cout_supported(self, w, cin, cout):
-        return self.lib.t2v_conv3x3_small_cout_supported(int(w), int(cin), int(cout)) == 1
+        return hasattr(self.lib, "t2v_conv3x3_small_cout_supported") and self.lib.t2v_conv3x3_small_cout_supported(int(w), int(cin), int(cout)) == 1
 
     def conv_small_cout(self, x, n_img, h, w, wgt, bias, out):
         """Direct 3x3 conv to 1..4 output channels: x bf16 [M, cin], wgt fp32 [cout, 9 * cin] (tap-major), out [M, cout] fp32 or bf16."""
@@ -801,6 +826,29 @@ class HipOps:
                    v_head_stride, _p(kt), _row_stride(kt), _p(qt), _p(dot), _row_stride(qt), _p(dout), _row_stride(dout), _p(o),
                    _row_stride(o), _p(l2), _p(dsum), _row_stride(l2), _p(dq), _row_stride(dq), _p(dk), _row_stride(dk), _p(dv),
                    _row_stride(dv), n_img, seq, seq, heads, scale)
+
+    # ---- base-weight gradients for full fine-tuning (csrc/full_grad.hip) -----------------------------------------------------------
+    def im2col_rows(self, mode, n_img, h, w):
+        return int(self.lib.t2v_im2col_rows(int(mode), int(n_img), int(h), int(w)))
+
+    def im2col(self, x0, x1, mode, n_img, h, w, frames, out):
+        """out[m][tap * C + c] = x[src(m, tap)][c] (bf16; x = [x0 | x1] on the (n_img, h, w) input grid) for a conv gather mode of ``gemm``."""
+        self._call("t2v_im2col_bf16", _p(x0), x0.shape[1], _row_stride(x0), _p(x1), 0 if x1 is None else x1.shape[1],
+                   0 if x1 is None else _row_stride(x1), int(mode), n_img, h, w, frames, _p(out), _row_stride(out))
+
+    def norm_affine_grad_ws_floats(self, rows, sum_rows, channels):
+        return int(self.lib.t2v_norm_affine_grad_ws_floats(int(rows), int(sum_rows), int(channels)))
+
+    def norm_affine_grad(self, x0, x1, dy, *, kind, sum_rows, ws, dgamma=None, dbeta=None, rows_per_unit=0, groups=0, stats=None, eps=0.0,
+                         gamma=None, beta=None, silu=False):
+        """Per-channel row sums (include/t2v_hip.h): ``kind`` 0 GroupNorm (``stats``), 1 LayerNorm (``eps``), 2 column sums of ``dy``;
+        ``dgamma`` / ``dbeta``: fp32 [rows / sum_rows, C] (row slices of wider buffers allowed)."""
+        rows = dy.shape[0]
+        c0 = dy.shape[1] if kind == 2 else x0.shape[1]
+        self._call("t2v_norm_affine_grad", _p(x0) if kind != 2 else None, c0, _row_stride(x0) if kind != 2 else 0, _p(x1),
+                   0 if x1 is None else x1.shape[1], 0 if x1 is None else _row_stride(x1), rows, int(sum_rows), int(kind), int(rows_per_unit),
+                   int(groups), _p(stats), float(eps), _p(gamma), _p(beta), 1 if silu else 0, _p(dy), _row_stride(dy), _p(dgamma),
+                   0 if dgamma is None else _row_stride(dgamma), _p(dbeta), 0 if dbeta is None else _row_stride(dbeta), _p(ws))
 
     def wgrad_tn(self, a, b, out, alpha=1.0, splits=0):
         """out[R, C] (fp32) = alpha * a^T b for token-major bf16 a [M, R], b [M, C] (column slices allowed)."""

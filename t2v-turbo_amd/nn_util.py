@@ -13,6 +13,7 @@ class EngineBox:
         self.engine = None
         self.enc = None
         self.grad = None
+        self.full = None
 
     def __deepcopy__(self, memo):
         return EngineBox()

@@ -13,6 +13,7 @@ Two execution paths, selected by where the input lives:
   * CPU tensor (or autograd)  -> each module's ``forward`` below: plain torch ops with the
     reference's semantics ("plumbing" configuration C1 and the autograd path of training).
 """
+import os
 from functools import partial
 
 import torch
@@ -423,6 +424,33 @@ class _NativeStudent(torch.autograd.Function):
         return (dx.to(ctx.x_dtype), eng.d_emb_all.to(ctx.e_dtype).clone(), None, None, *grads)
 
 
+class _NativeStudentFull(torch.autograd.Function):
+    """UNet forward of the FULL fine-tuning student (train_latent_t2v_turbo_v2.py:669,798-816,1262: every parameter trainable, no LoRA):
+    d/d(latents), d/d(emb_all) and the gradient of every parameter outside the B-row conditioning branch come from the native gradient
+    engine (engine_full.py); torch keeps differentiating the conditioning branch behind ``emb_all``."""
+
+    @staticmethod
+    def forward(ctx, x, emb_all, model, args, *params):
+        eng = model.native_full_engine()
+        timesteps, context, fps, tc, mc = args
+        y = eng.forward_tape(x.detach(), timesteps, context.detach(), fps, tc, mc, emb_all=emb_all.detach())
+        ctx.model, ctx.plan, ctx.fwd_id = model, eng._last, eng._last["fwd_id"]
+        ctx.params = params
+        ctx.x_dtype, ctx.e_dtype = x.dtype, emb_all.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.model.native_full_engine()
+        if ctx.plan["fwd_id"] != ctx.fwd_id:
+            raise RuntimeError("native student: another grad-mode forward of the same shape ran before this backward "
+                               "(the engine keeps one outstanding tape per input shape)")
+        eng._last = ctx.plan
+        dx = eng.backward(dout)
+        grads = [None if (g is None or not p.requires_grad) else g.to(p.dtype) for p, g in zip(ctx.params, eng.full_grads(ctx.params))]
+        return (dx.to(ctx.x_dtype), eng.d_emb_all.to(ctx.e_dtype).clone(), None, None, *grads)
+
+
 class UNetModel(nn.Module):
     """Same constructor signature as the reference (openaimodel3d.py:340-374)."""
 
@@ -540,6 +568,10 @@ class UNetModel(nn.Module):
             assert timestep_cond is not None
         mode = getattr(self, "native_mode", "auto")
         if mode == "train":  # force the native gradient engine (raises where it cannot run)
+            from .nn_util import walk_modules
+            from .engine import is_lora_leaf
+            if not any(is_lora_leaf(mod) for mod in walk_modules(self)) and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                return self._forward_native_full(x, timesteps, context, fps, timestep_cond, motion_cond)
             return self._forward_native_train(x, timesteps, context, fps, timestep_cond, motion_cond)
         if mode != "off" and x.is_cuda:  # "off": always the torch path
             route, why = self._auto_route(x, context, timestep_cond, features_adapter)
@@ -547,6 +579,8 @@ class UNetModel(nn.Module):
                 return self.native_engine()(x, timesteps, context, fps, timestep_cond, motion_cond)
             if route == "train":
                 return self._forward_native_train(x, timesteps, context, fps, timestep_cond, motion_cond)
+            if route == "train_full":
+                return self._forward_native_full(x, timesteps, context, fps, timestep_cond, motion_cond)
             _warn_aten_route(why)
         return self._forward_composite(x, timesteps, context, features_adapter, fps, timestep_cond, motion_cond)
 
@@ -558,8 +592,11 @@ class UNetModel(nn.Module):
                                                              -> "train": gradient engine (un-merged LoRA branch, counter-based dropout);
           * no gradient wanted, no LoRA, train mode with only the TemporalConvBlock dropouts live (the v1 teacher, which the
             reference never puts in eval mode)               -> "infer": inference engine + counter-based dropout masks;
-          * anything else (full fine-tuning, gradients w.r.t. the context, adapters, other live dropouts)
-                                                             -> the torch composite path, with a one-time warning."""
+          * no LoRA, gradients wanted and at least one parameter trainable — FULL fine-tuning, the student of
+            train_latent_t2v_turbo_v2.py:669,798-816,1262 (train mode with the TemporalConvBlock dropouts live, or eval)
+                                                             -> "train_full": gradient engine with base-weight gradients (engine_full.py);
+          * anything else (gradients w.r.t. the context, input gradients of a frozen network through this route, adapters, other live
+            dropouts)                                        -> the torch composite path, with a one-time warning."""
         from .nn_util import walk_modules, walk_parameters
         grad = torch.is_grad_enabled() and self._needs_grad(x, context, timestep_cond)
         mods = walk_modules(self) if (self.training or grad) else ()
@@ -578,8 +615,13 @@ class UNetModel(nn.Module):
             return "infer", None
         lora_ids = {id(w) for mod in mods if is_lora_leaf(mod) for w in (mod.lora_up.weight, mod.lora_down.weight)}
         if not lora_ids:
+            if (grad and self.native_full and context is not None and any(p.requires_grad for p in walk_parameters(self))
+                    and not (context.requires_grad or (timestep_cond is not None and timestep_cond.requires_grad))
+                    and (not self.training or self._only_tconv_dropouts(mods))):
+                return "train_full", None
             return "composite", ("a train-mode network with active Dropout and no LoRA" if not grad else
-                                 "gradients without LoRA injection (full fine-tuning / input gradients)")
+                                 "gradients without LoRA injection that the native full fine-tuning route does not take (input gradients only, "
+                                 "gradients w.r.t. the context, other live dropouts, T2V_NATIVE_FULL=0)")
         if context is None:
             return "composite", "no text context"
         if any(p.requires_grad and id(p) not in lora_ids for p in walk_parameters(self)):
@@ -609,6 +651,32 @@ class UNetModel(nn.Module):
             from .native import HipOps
             self._engine_box.engine = UNetEngine(self, HipOps())
         return self._engine_box.engine
+
+    # ---- native FULL fine-tuning (every parameter trainable, no LoRA: train_latent_t2v_turbo_v2.py) ---------------------------------
+    native_full = os.environ.get("T2V_NATIVE_FULL", "1") == "1"
+
+    def native_full_engine(self):
+        if getattr(self._engine_box, "full", None) is None:
+            from .engine_unet_bwd import UNetGradEngine
+            make_ops = getattr(self, "_native_ops_factory", None)  # tests substitute the emulated backend
+            if make_ops is None:
+                from .native import HipOps as make_ops
+            eng = UNetGradEngine(self, make_ops())
+            eng.bind_full(eng.engine_parameters(self))
+            self._engine_box.full = eng
+        return self._engine_box.full
+
+    def _forward_native_full(self, x, timesteps, context, fps, timestep_cond, motion_cond):
+        if not (x.is_cuda or getattr(self, "_native_ops_factory", None) is not None):
+            raise RuntimeError("native full fine-tuning needs CUDA tensors")
+        if context is None:
+            raise ValueError("native full fine-tuning needs the text context")
+        if context.requires_grad or (timestep_cond is not None and timestep_cond.requires_grad):
+            raise RuntimeError("native full fine-tuning: gradients flow to the latents and the parameters only")
+        eng = self.native_full_engine()
+        emb_all = self.conditioning_emb_all(timesteps, fps, timestep_cond, motion_cond)
+        args = (timesteps, context, fps, timestep_cond, motion_cond)
+        return _NativeStudentFull.apply(x, emb_all, self, args, *eng.full_params)
 
     # ---- native LoRA training (native_mode = "train") ---------------------------------------------------------------------
     def native_train_engine(self, forward_only=False):

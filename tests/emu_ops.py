@@ -500,6 +500,75 @@ class EmuOps:
                 dk[r, c] = (dS.t() @ Q * scale).to(dk.dtype)
                 dv[r, c] = (P.t() @ dO).to(dv.dtype)
 
+    # ---- base-weight gradients for full fine-tuning (csrc/full_grad.hip) -----------------------------------------------------------
+    @staticmethod
+    def im2col_rows(mode, n_img, h, w):
+        if mode in (nt.GEMM_CONV3X3, nt.GEMM_TCONV3):
+            return n_img * h * w
+        if mode == nt.GEMM_CONV3X3_S2:
+            return n_img * ((h - 1) // 2 + 1) * ((w - 1) // 2 + 1)
+        if mode == nt.GEMM_CONV3X3_S2_PAD01:
+            return n_img * ((h - 2) // 2 + 1) * ((w - 2) // 2 + 1)
+        if mode == nt.GEMM_CONV3X3_UP2:
+            return n_img * 4 * h * w
+        return -1
+
+    def im2col(self, x0, x1, mode, n_img, h, w, frames, out):
+        """out[m][tap * C + c] = x[src(m, tap)][c]: F.unfold of the (padded / upsampled) image, re-ordered tap-major."""
+        self._log("im2col")
+        x = self._cat(x0, x1).float()
+        C = x.shape[1]
+        if mode == nt.GEMM_TCONV3:
+            b = n_img // frames
+            x5 = F.pad(x.reshape(b, frames, h * w, C), (0, 0, 0, 0, 1, 1))            # frames padded by one on both sides
+            cols = torch.stack([x5[:, t:t + frames] for t in range(3)], dim=3)        # b f p tap c
+            out[:, :3 * C].copy_(cols.reshape(-1, 3 * C).to(out.dtype))
+            return
+        x4 = x.reshape(n_img, h, w, C).permute(0, 3, 1, 2)
+        if mode == nt.GEMM_CONV3X3:
+            u = F.unfold(x4, 3, padding=1)
+        elif mode == nt.GEMM_CONV3X3_S2:
+            u = F.unfold(x4, 3, padding=1, stride=2)
+        elif mode == nt.GEMM_CONV3X3_S2_PAD01:
+            u = F.unfold(F.pad(x4, (0, 1, 0, 1)), 3, stride=2)
+        elif mode == nt.GEMM_CONV3X3_UP2:
+            u = F.unfold(F.interpolate(x4, scale_factor=2, mode="nearest"), 3, padding=1)
+        else:
+            raise ValueError(mode)
+        # unfold: [n, C * 9, L] with the channel the slow index -> [n * L, 9, C]
+        u = u.reshape(n_img, C, 9, -1).permute(0, 3, 2, 1).reshape(-1, 9 * C)
+        out[:, :9 * C].copy_(u.to(out.dtype))
+
+    def norm_affine_grad_ws_floats(self, rows, sum_rows, channels):
+        return 8
+
+    def norm_affine_grad(self, x0, x1, dy, *, kind, sum_rows, ws, dgamma=None, dbeta=None, rows_per_unit=0, groups=0, stats=None, eps=0.0,
+                         gamma=None, beta=None, silu=False):
+        self._log("norm_affine_grad")
+        rows = dy.shape[0]
+        g = dy.float()
+        C = g.shape[1]
+        xh = None
+        if kind == 0:
+            x = self._cat(x0, x1).float()
+            units, cpg = rows // rows_per_unit, C // groups
+            st = stats.reshape(units, groups, 2).float()
+            mean = st[:, :, 0].repeat_interleave(cpg, dim=1)[:, None, :]
+            rstd = st[:, :, 1].repeat_interleave(cpg, dim=1)[:, None, :]
+            xh = ((x.reshape(units, rows_per_unit, C) - mean) * rstd).reshape(rows, C)
+        elif kind == 1:
+            x = self._cat(x0, x1).float()
+            xh = (x - x.mean(dim=1, keepdim=True)) / torch.sqrt(x.var(dim=1, unbiased=False, keepdim=True) + eps)
+        if silu and kind != 2:
+            z = xh * gamma.float() + beta.float()
+            sig = torch.sigmoid(z)
+            g = g * sig * (1 + z * (1 - sig))
+        n_out = rows // sum_rows
+        if dgamma is not None:
+            dgamma.copy_((g * xh).reshape(n_out, sum_rows, C).sum(dim=1) if xh is not None else torch.zeros(n_out, C))
+        if dbeta is not None:
+            dbeta.copy_(g.reshape(n_out, sum_rows, C).sum(dim=1))
+
     def wgrad_tn(self, a, b, out, alpha=1.0, splits=0):
         self._log("wgrad_tn")
         if self.strict:

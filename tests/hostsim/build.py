@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "t2v-turbo_amd", "csrc")
-SOURCES = ["backward.hip", "backward_unet.hip", "train.hip", "wgrad_tn.hip"]
+SOURCES = ["backward.hip", "backward_unet.hip", "train.hip", "wgrad_tn.hip", "full_grad.hip"]
 GEMM_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "gemm2.hip", "linear_pr.hip"]   # MFMA + LDS-DMA: simulated as wave collectives (separate, slower-to-build library)
 GEMM_HEADERS = ["tile80.h", "gemm2.h", "gelu_poly.h"]
 OUT = os.path.join(HERE, "_build")
@@ -47,7 +47,7 @@ def patch(text):
 
 
 def build_gemm(force=False):
-    """t2v_gemm (+ the experimental tile ids) on the simulator.  Minutes of g++ time: built on demand by its own test module."""
+    """t2v_gemm (+ the experimental tile ids; -DT2V_EXPERIMENTAL: the simulator keeps testing the kernels the product library leaves out) on the simulator.  Minutes of g++ time: built on demand by its own test module."""
     deps = [os.path.join(CSRC, s) for s in GEMM_SOURCES + GEMM_HEADERS] + [os.path.join(HERE, "common.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
                                                            os.path.abspath(__file__), os.path.join(ROOT, "include", "t2v_hip.h")]
     if not force and os.path.exists(GEMM_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(GEMM_LIB) for d in deps):
@@ -62,7 +62,7 @@ def build_gemm(force=False):
     for src in GEMM_SOURCES:
         cpp = os.path.join(OUT, src.replace(".hip", ".cpp"))
         obj = cpp.replace(".cpp", ".o")
-        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-w", "-fno-strict-aliasing", "-I", HERE, "-I", OUT, "-I", os.path.join(ROOT, "include"), "-c", cpp, "-o", obj]
+        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-w", "-fno-strict-aliasing", "-DT2V_EXPERIMENTAL", "-I", HERE, "-I", OUT, "-I", os.path.join(ROOT, "include"), "-c", cpp, "-o", obj]
         procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
     for cmd, pr in procs:
@@ -72,7 +72,7 @@ def build_gemm(force=False):
     return GEMM_LIB
 
 
-FULL_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "gemm2.hip", "linear_pr.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "replay.hip"]
+FULL_SOURCES = ["gemm.hip", "gemm_exp.hip", "gemm_fuse.hip", "conv_halo.hip", "gemm2.hip", "linear_pr.hip", "ffn.hip", "norm.hip", "attention.hip", "elementwise.hip", "backward.hip", "backward_unet.hip", "train.hip", "attention_bwd.hip", "wgrad_tn.hip", "full_grad.hip", "replay.hip"]
 FULL_LIB = os.path.join(OUT, "libt2v_hostsim_full.so")
 
 
@@ -91,7 +91,7 @@ def build_full(force=False):
     for src in FULL_SOURCES:
         cpp = os.path.join(full, src.replace(".hip", ".cpp"))
         obj = cpp.replace(".cpp", ".o")
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-w", "-fno-strict-aliasing", "-DHOSTSIM_FULL", "-I", HERE, "-I", full, "-I", os.path.join(ROOT, "include"),
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-w", "-fno-strict-aliasing", "-DHOSTSIM_FULL", "-DT2V_EXPERIMENTAL", "-I", HERE, "-I", full, "-I", os.path.join(ROOT, "include"),
                "-c", cpp, "-o", obj]
         procs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)

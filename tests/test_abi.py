@@ -9,9 +9,12 @@ from t2v_turbo_amd import native
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
+def _declared(experimental=False):
+    """Function names the header declares: the product view (the T2V_EXPERIMENTAL blocks dropped) or those blocks alone."""
     text = open(os.path.join(ROOT, "include", "t2v_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    blocks = re.findall(r"#ifdef T2V_EXPERIMENTAL(.*?)#endif", text, flags=re.S)
+    text = "\n".join(blocks) if experimental else re.sub(r"#ifdef T2V_EXPERIMENTAL.*?#endif", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(t2v_[a-z0-9_]+)\s*\(", text)))
 
 
@@ -23,6 +26,10 @@ def test_header_symbols_exported_and_bound():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/t2v_hip.h but not exported"
     assert sorted(native.EXPORTED) == names, set(native.EXPORTED) ^ set(names)
+    # the measured negative results live behind T2V_EXPERIMENTAL: declared there, bound when present, NOT in the product library
+    exp = _declared(experimental=True)
+    assert exp == sorted(native.EXPERIMENTAL), set(exp) ^ set(native.EXPERIMENTAL)
+    assert not any(hasattr(lib, n) for n in exp), "the product library exports T2V_EXPERIMENTAL entry points"
 
 
 def test_struct_layout_matches_header():
@@ -77,3 +84,28 @@ def test_tune_table_nearest_shape_fallback():
     t.nearest = False
     assert t.lookup((0, 8192, 320, 320, 1)) is None
     assert TuneTable({}).lookup((0, 1, 1, 64, 1)) is None
+
+
+def test_split_hint_survives_a_nearest_shape_hit_without_a_trusted_split():
+    """A tile-table miss used to keep the caller's split_k hint; the nearest-shape fallback returns (tile, 0) when the tuned M is not
+    within a third of the asked one, and that 0 must not overwrite the hint (the training engine's token-contracted weight gradients
+    pass one).  Descriptor construction only: no launch, no GPU."""
+    import torch
+    ops = native.HipOps()
+    M_t, N, K = 1024, 128, 256
+    ops.tune = native.TuneTable({(native.GEMM_LINEAR, M_t, N, K, 1): (6, 3)}, nearest=True)
+    w = torch.zeros(N, K, dtype=torch.bfloat16)
+
+    def desc(M, **kw):
+        return ops._gemm_desc(torch.zeros(M, K, dtype=torch.bfloat16), w, torch.zeros(M, N, dtype=torch.bfloat16), M=M, N=N, **kw)
+
+    d = desc(M_t, split_k=5)
+    assert (d.tile_cfg, d.split_k) == (6, 3)            # exact hit: the tuned entry wins over the hint
+    d = desc(1100, split_k=5)
+    assert (d.tile_cfg, d.split_k) == (6, 3)            # nearest, M within a third: tile and split of the tuned entry
+    d = desc(2200, split_k=5)
+    assert (d.tile_cfg, d.split_k) == (6, 5)            # nearest tile, split not trusted: the caller's hint stands
+    d = desc(2200)
+    assert (d.tile_cfg, d.split_k) == (6, 0)            # ... and without a hint the library's own rule
+    d = desc(8000, split_k=5)
+    assert (d.tile_cfg, d.split_k) == (0, 5)            # miss: as before

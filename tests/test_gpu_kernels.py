@@ -260,6 +260,10 @@ def test_attn_spatial_forms_are_bit_identical(pair, n_img, seq_q, seq_kv, heads,
     """t2v_attn_spatial_form: eight waves per workgroup (8) and 64 queries per wave with the two query sets' phases offset (65) do the SAME
     arithmetic per query as the product kernel (0) — outputs must be bit-identical: ragged query blocks of 128 / 256, the last tile's
     padding keys, per-clip text keys (kv_div), a running max that moves.  (Both are measured no faster: tools / tests only.)"""
+    from t2v_turbo_amd import native as _nt
+    if not _nt.has_experimental():
+        pytest.skip("entry point of a T2V_EXPERIMENTAL=1 build (python t2v-turbo_amd/csrc/build.py with T2V_EXPERIMENTAL=1, then T2V_HIP_LIB=.../libt2v_hip_exp.so)")
+
     inner = heads * 64
     n_kv = n_img // kv_div
     kp = ((seq_kv + 63) // 64) * 64
@@ -543,6 +547,10 @@ def test_gemm_layernorm_second_output(pair, M, K, res):
 
 def test_conv3x3_small_cout_direct(pair):
     """t2v_conv3x3_small_cout at the VAE decoder's conv_out size (one 320x512 frame, 128 -> 3 channels, fp32 out) and small corner cases."""
+    from t2v_turbo_amd import native as _nt
+    if not _nt.has_experimental():
+        pytest.skip("entry point of a T2V_EXPERIMENTAL=1 build (python t2v-turbo_amd/csrc/build.py with T2V_EXPERIMENTAL=1, then T2V_HIP_LIB=.../libt2v_hip_exp.so)")
+
     for n_img, h, w, cin, cout, f32 in [(1, 320, 512, 128, 3, True), (2, 6, 8, 16, 3, False), (1, 5, 12, 64, 4, True), (3, 3, 4, 8, 1, True)]:
         M = n_img * h * w
         x = _rt(M, cin, seed=cin + h)

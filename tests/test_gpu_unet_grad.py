@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from tests.emu_ops import EmuOps
+from t2v_turbo_amd import native as nt
 from tests.util import rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -234,7 +235,7 @@ def test_dropout_mask_is_the_emulated_one(ops, rows, ncols, ld, p, resid):
     o_h = _dev(x)
     hip.dropout(o_h, _dev(r) if resid else None, o_h, ncols, p, seed.cuda(), 7)
     torch.cuda.synchronize()
-    ref = torch.where(keep, x[:, :ncols] / (1 - p), torch.zeros(())) + (r[:, :ncols] if resid else 0)
+    ref = torch.where(keep, x[:, :ncols] * nt.dropout_inv_keep(p), torch.zeros(())) + (r[:, :ncols] if resid else 0)   # (the scale of the quantised drop probability)
     got = o_h.float().cpu()
     assert torch.equal(got[:, ncols:], x[:, ncols:])   # columns beyond ncols untouched
     assert rel_l2(got[:, :ncols], ref) < 5e-3

@@ -228,7 +228,7 @@ def test_dropout_mask_is_the_emulated_one(ops, rows, ncols, ld, p, resid):
     keep = emu.dropout_keep(int(seed[0]), 7, rows, ncols, p)
     o_s = _bf(x)
     sim.dropout(o_s, _bf(r) if resid else None, o_s, ncols, p, seed, 7)
-    ref = torch.where(keep, x[:, :ncols] / (1 - p), torch.zeros(())) + (r[:, :ncols] if resid else 0)
+    ref = torch.where(keep, x[:, :ncols] * nt.dropout_inv_keep(p), torch.zeros(())) + (r[:, :ncols] if resid else 0)   # (the scale of the quantised drop probability)
     got = o_s.float()
     assert torch.equal(got[:, ncols:], x[:, ncols:])   # columns beyond ncols untouched
     assert rel_l2(got[:, :ncols], ref) < 5e-3
@@ -307,3 +307,85 @@ def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
     sim.wgrad_tn(_bf(a)[:, :R], _bf(b)[:, :C], o_s[:, :C], alpha=0.5, splits=splits)
     assert rel_l2(o_s[:, :C], o_e) < 1e-5 and float(o_s[:, C:].min()) == 7.0
 
+
+
+# ---------------------------------------------------------------------------------- base-weight gradients (csrc/full_grad.hip)
+@pytest.mark.parametrize("mode,n_img,h,w,frames,c0,c1", [
+    (nt.GEMM_CONV3X3, 2, 5, 6, 0, 16, 0), (nt.GEMM_CONV3X3, 1, 4, 4, 0, 8, 24), (nt.GEMM_CONV3X3_S2, 2, 6, 8, 0, 16, 0),
+    (nt.GEMM_CONV3X3_S2, 1, 5, 7, 0, 8, 0), (nt.GEMM_CONV3X3_S2_PAD01, 2, 6, 8, 0, 16, 0), (nt.GEMM_CONV3X3_UP2, 2, 3, 4, 0, 16, 0),
+    (nt.GEMM_TCONV3, 6, 2, 3, 3, 16, 8), (nt.GEMM_TCONV3, 4, 3, 3, 4, 8, 0)])
+def test_im2col_matches_unfold(ops, mode, n_img, h, w, frames, c0, c1):
+    """t2v_im2col_bf16 in every gather mode of t2v_gemm against F.unfold on the padded / strided / upsampled image (the emulation): exact
+    (a copy), and consistent with the forward conv: xcol @ W_tapmajor^T == the emulated conv."""
+    sim, emu = ops
+    x0, x1 = _rt(n_img * h * w, c0, seed=1), (_rt(n_img * h * w, c1, seed=2) if c1 else None)
+    taps, Cc = (3 if mode == nt.GEMM_TCONV3 else 9), c0 + c1
+    rows = sim.im2col_rows(mode, n_img, h, w)
+    assert rows == emu.im2col_rows(mode, n_img, h, w) and rows > 0
+    ld = taps * Cc + 8
+    o_s = torch.full((rows, ld), 7.0, dtype=torch.bfloat16)
+    o_e = torch.full((rows, ld), 7.0)
+    sim.im2col(_bf(x0), None if x1 is None else _bf(x1), mode, n_img, h, w, frames, o_s)
+    emu.im2col(x0, x1, mode, n_img, h, w, frames, o_e)
+    assert torch.equal(o_s.float(), o_e)                 # (the columns past taps * C are untouched on both sides)
+    if c0 % 64 == 0 and c1 % 64 == 0:
+        return
+    # against the forward conv of the emulation (channel counts here are not multiples of 64: compare with torch directly)
+    wk = _rt(5, taps * Cc, seed=3)
+    y = o_e[:, :taps * Cc] @ wk.t()
+    xin = torch.cat([x0] + ([x1] if x1 is not None else []), dim=1)
+    if mode == nt.GEMM_TCONV3:
+        x5 = xin.reshape(n_img // frames, frames, h * w, Cc).permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(x5, wk.reshape(5, 3, Cc).permute(0, 2, 1)[..., None], padding=(1, 0)).permute(0, 2, 3, 1).reshape(-1, 5)
+    else:
+        x4 = xin.reshape(n_img, h, w, Cc).permute(0, 3, 1, 2)
+        w4 = wk.reshape(5, 3, 3, Cc).permute(0, 3, 1, 2)
+        Fn = torch.nn.functional
+        ref = {nt.GEMM_CONV3X3: lambda: Fn.conv2d(x4, w4, padding=1), nt.GEMM_CONV3X3_S2: lambda: Fn.conv2d(x4, w4, stride=2, padding=1),
+               nt.GEMM_CONV3X3_S2_PAD01: lambda: Fn.conv2d(Fn.pad(x4, (0, 1, 0, 1)), w4, stride=2),
+               nt.GEMM_CONV3X3_UP2: lambda: Fn.conv2d(Fn.interpolate(x4, scale_factor=2, mode="nearest"), w4, padding=1)}[mode]()
+        ref = ref.permute(0, 2, 3, 1).reshape(-1, 5)
+    assert torch.allclose(y, ref, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("kind,c0,c1,units,rows,silu,sum_rows", [
+    (0, 64, 0, 2, 48, True, 96), (0, 32, 64, 3, 40, False, 120), (0, 320, 0, 1, 70, True, 70), (1, 64, 0, 1, 50, False, 50),
+    (1, 320, 0, 1, 33, False, 33), (1, 1280, 0, 1, 9, False, 9), (2, 96, 0, 1, 60, False, 60), (2, 64, 0, 1, 60, False, 20)])
+def test_norm_affine_grad_against_autograd_style_sums(ops, kind, c0, c1, units, rows, silu, sum_rows):
+    """t2v_norm_affine_grad: dgamma / dbeta of GroupNorm(+SiLU) (two-part input), of LayerNorm, plain column sums (bias gradients) and
+    per-clip column sums (sum_rows < rows: d(loss)/d(time-embedding row)), against the emulation — and the emulation against torch autograd."""
+    sim, emu = ops
+    M, Cc, G = units * rows, c0 + c1, 32
+    x0, x1 = _rt(M, c0, seed=1), (_rt(M, c1, seed=2) if c1 else None)
+    dy = _rt(M, Cc, seed=3)
+    gamma, beta = _rt(Cc, seed=5) * 0.2 + 1.0, _rt(Cc, seed=6) * 0.1
+    n_out = M // sum_rows
+    kw = dict(kind=kind, sum_rows=sum_rows, silu=silu)
+    if kind == 0:
+        stats = torch.zeros(units, 2 * G)
+        emu.gn_stats(x0, x1, units, rows, 1e-5, None, stats, G)
+        kw.update(rows_per_unit=rows, groups=G, stats=stats, gamma=gamma, beta=beta)
+    elif kind == 1:
+        kw.update(eps=1e-5)
+    outs = []
+    for o, cvt in ((sim, _bf), (emu, lambda t: t)):
+        wide = torch.full((n_out, Cc + 4), 3.0)   # the destinations are column slices of wider rows (a gradient arena)
+        dg, db = (wide[:, :Cc].clone() if kind != 2 else None), torch.full((n_out, Cc + 4), 3.0)[:, :Cc]
+        ws = torch.zeros(max(o.norm_affine_grad_ws_floats(M, sum_rows, Cc), 1))
+        o.norm_affine_grad(None if kind == 2 else cvt(x0), None if x1 is None else cvt(x1), cvt(dy), ws=ws, dgamma=dg, dbeta=db, **kw)
+        outs.append((dg, db.clone()))
+    (dg_s, db_s), (dg_e, db_e) = outs
+    assert rel_l2(db_s, db_e) < 1e-4
+    if kind != 2:
+        assert rel_l2(dg_s, dg_e) < 1e-4
+        # the emulation itself against autograd
+        xin = torch.cat([x0] + ([x1] if x1 is not None else []), dim=1)
+        gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        if kind == 0:
+            z = torch.nn.functional.group_norm(xin.reshape(units, rows, Cc).permute(0, 2, 1), G, gm, bt, 1e-5).permute(0, 2, 1).reshape(M, Cc)
+        else:
+            z = torch.nn.functional.layer_norm(xin, (Cc,), gm, bt, 1e-5)
+        if silu:
+            z = torch.nn.functional.silu(z)
+        (z * dy).sum().backward()
+        assert rel_l2(dg_e.sum(dim=0), gm.grad) < 1e-4 and rel_l2(db_e.sum(dim=0), bt.grad) < 1e-4

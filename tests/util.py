@@ -70,5 +70,10 @@ def run_isolated(module, func, timeout=900):
     if "BODY_OK" not in (p.stdout or ""):
         raise AssertionError(f"{module}.{func} failed in the child (rc {p.returncode}):\n{out[-6000:]}")
     if p.returncode != 0:
+        # a teardown fault AFTER the verified body fails the test too, unless the known-bad box is named explicitly
+        # (T2V_ALLOW_TEARDOWN_FAULT=1: round 5's box whose destroy_process_group aborted the interpreter)
+        if os.environ.get("T2V_ALLOW_TEARDOWN_FAULT") != "1":
+            raise AssertionError(f"{module}.{func}: body verified, but the child exited with rc {p.returncode} during teardown "
+                                 f"(T2V_ALLOW_TEARDOWN_FAULT=1 accepts that):\n{out[-3000:]}")
         import warnings
         warnings.warn(f"{module}.{func}: body verified, but the child exited with rc {p.returncode} during teardown")

@@ -64,12 +64,12 @@ def main():
     rec = next(iter(model.native_engine().plans.values()))["rec"]
     seen = {}
     for fn, a, name in rec:
-        if name != "t2v_gemm":
+        if name not in bench.GEMM_FAMILY:   # t2v_gemm, t2v_conv_halo, t2v_linear_pr: one descriptor type
             continue
         d = a[0]._obj
         taps = {nt.GEMM_LINEAR: 1, nt.GEMM_TCONV3: 3}.get(d.mode, 9)
         K = taps * (d.c0 + d.c1)
-        key = (d.mode, d.M, d.N, K, max(d.batch, 1), d.act, bool(d.residual), bool(d.rowvec))
+        key = (d.mode, d.M, d.N, K, max(d.batch, 1), d.act, bool(d.residual), bool(d.rowvec), name, int(d.ln_in))
         if key in seen:
             seen[key][0] += 1
         else:
@@ -82,7 +82,7 @@ def main():
         items.sort(key=lambda kv: -kv[1][0] * (kv[0][1] * kv[0][2] * (kv[0][3] + 2000.0)))
         items = items[:args.top]
     for key, (count, fn, a, d) in items:
-        mode, M, N, K, batch, act, has_res, has_rv = key
+        mode, M, N, K, batch, act, has_res, has_rv, kname, ln_in = key
         s = torch.cuda.current_stream().cuda_stream
         us = graph_time(lambda: fn(*a, torch.cuda.current_stream().cuda_stream))
         n_out = N // 2 if act == nt.ACT_GEGLU else N
@@ -104,7 +104,7 @@ def main():
             except Exception as e:  # noqa
                 us_blas = None
             del A, B, Cc
-        rows.append(dict(mode=mode, M=M, N=N, K=K, batch=batch, act=act, res=int(has_res), rv=int(has_rv), count=count,
+        rows.append(dict(kernel=kname.replace("t2v_", ""), ln_in=ln_in, mode=mode, M=M, N=N, K=K, batch=batch, act=act, res=int(has_res), rv=int(has_rv), count=count,
                          cfg=d.tile_cfg, split=d.split_k,
                          us=round(us, 2), total_ms=round(us * count / 1e3, 3), tflops=round(flops / us / 1e6, 1),
                          us_blas=None if us_blas is None else round(us_blas, 2),
@@ -126,6 +126,10 @@ def main():
     floor = sum(max(r["us_mfma_floor"], r["us_hbm_floor"]) * r["count"] for r in rows) / 1e3
     blas = sum((r["us_blas"] or r["us"]) * r["count"] for r in rows) / 1e3
     blas_txt = f"; plain hipBLASLt GEMMs of the same MNK {blas:.2f} ms" if args.blas else ""
+    lin = sum(r["total_ms"] for r in rows if r["mode"] == nt.GEMM_LINEAR)
+    by_k = {k: round(sum(r["total_ms"] for r in rows if r["kernel"] == k), 3) for k in sorted({r["kernel"] for r in rows})}
+    tf = sum(2.0 * r["M"] * r["N"] * r["K"] * r["batch"] * r["count"] for r in rows) / 1e12
+    blas_txt += f"; LINEAR-mode launches {lin:.2f} ms; by kernel {by_k}; {tf:.2f} TFLOP -> {tf / tot * 1e3:.0f} TFLOP/s = {tf / tot * 1e3 / 2500:.3f} of 2.5 PF"
     print(f"GEMM per UNet step: {tot:.2f} ms in-graph; roofline floor {floor:.2f} ms{blas_txt}")
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
