@@ -482,7 +482,7 @@ int t2v_im2col_bf16(const void* x0, int c0, int ld0, const void* x1, int c1, int
  * kind 1: xhat = LayerNorm's (x - mean_row) * rstd_row, recomputed per row with ln_eps (attention.py:300-311);
  * kind 2: no norm — dbeta = plain column sums of dy (bias gradients; per-clip sums = d(loss)/d(time embedding row); c0 = columns of dy).
  * silu != 0 (kinds 0, 1): the forward applied SiLU behind the norm (openaimodel3d.py:223-254), dz = dy * silu'(xhat gamma + beta); else
- * dz = dy.  x = [x0 | x1] bf16 (the norm's INPUT), dy bf16 [rows][ldy] over the C = c0 + c1 channels (C % 8 == 0, C <= 2048); dgamma /
+ * dz = dy.  x = [x0 | x1] bf16 (the norm's INPUT), dy bf16 [rows][ldy] over the C = c0 + c1 channels (C % 8 == 0; C <= 2560 for kinds 0 / 1); dgamma /
  * dbeta fp32 with row strides ld_dgamma / ld_dbeta (either may be NULL for kind 2 / when not wanted).  ws: fp32 workspace of
  * t2v_norm_affine_grad_ws_floats(rows, sum_rows, C) floats.  Two launches, fixed summation order (no float atomics). */
 long long t2v_norm_affine_grad_ws_floats(long long rows, long long sum_rows, int channels);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ 
 // Block = 4 waves; a wave owns whole rows (lane l holds the 16-byte chunks l, l + 64, ... of the row: NJ of them), so a LayerNorm's row
 // statistics are two butterflies.  Block (bx, u) walks rows [bx * rows_per_blk, ...) of output row u; its four waves' register sums meet
 // in LDS in wave order; partial[(u * nblk + bx)][2][C].
-constexpr int AG_MAXJ = 4;   // C <= 64 * 8 * 4 = 2048
+constexpr int AG_MAXJ = 5;   // C <= 64 * 8 * 5 = 2560 per launch (the widest GroupNorm: a 1280 + 1280 concat); plain column sums go out in column chunks
 template <int KIND>   // 0: GroupNorm statistics given, 1: LayerNorm (row statistics recomputed), 2: column sums of dy only
 __global__ __launch_bounds__(256) void affine_grad_partial_kernel(const bf16_t* __restrict__ x0, int c0, int ld0, const bf16_t* __restrict__ x1,
                                                                   int c1, int ld1, long long sum_rows, int rows_per_blk, int rows_per_unit,
@@ -75,17 +75,11 @@ __global__ __launch_bounds__(256) void affine_grad_partial_kernel(const bf16_t* 
     const int u = blockIdx.y, bx = blockIdx.x, nblk = gridDim.x;
     const long long r_begin = (long long)u * sum_rows + (long long)bx * rows_per_blk;
     const long long r_end = min((long long)(u + 1) * sum_rows, r_begin + rows_per_blk);
-    float ag[AG_MAXJ][8], ab[AG_MAXJ][8], gm[AG_MAXJ][8], bt[AG_MAXJ][8];
+    float ag[AG_MAXJ][8], ab[AG_MAXJ][8];
 #pragma unroll
-    for (int j = 0; j < AG_MAXJ; ++j) {
+    for (int j = 0; j < AG_MAXJ; ++j)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; gm[j][e] = 1.f; bt[j][e] = 0.f; }
-        const int ci = lane + 64 * j;
-        if (KIND != 2 && silu && ci < cpr) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { gm[j][e] = gamma[ci * 8 + e]; bt[j][e] = beta[ci * 8 + e]; }
-        }
-    }
+        for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; }
     const int cpg = KIND == 0 ? C / groups : 1;
     const float inv_c = 1.0f / (float)C;
     for (long long r = r_begin + wave; r < r_end; r += 4) {
@@ -126,6 +120,13 @@ __global__ __launch_bounds__(256) void affine_grad_partial_kernel(const bf16_t* 
         for (int j = 0; j < AG_MAXJ; ++j) {
             const int ci = lane + 64 * j;
             if (ci < cpr) {
+                float gm[8], bt[8];   // (re-read per row from L1: kept in registers beside the sums they would not fit at 2560 channels)
+                if (KIND != 2 && silu) {
+                    const float4 g0 = *(const float4*)(gamma + ci * 8), g1 = *(const float4*)(gamma + ci * 8 + 4);
+                    const float4 b0 = *(const float4*)(beta + ci * 8), b1 = *(const float4*)(beta + ci * 8 + 4);
+                    gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
+                    bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1.x; bt[5] = b1.y; bt[6] = b1.z; bt[7] = b1.w;
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float xh = 0.f, dz = dv[j][e];
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void affine_grad_partial_kernel(const bf16_t* 
                         xh = (xv[j][e] - mean) * rstd;
                     }
                     if (KIND != 2 && silu) {   // y = silu(z), z = xhat gamma + beta: dz = dy * sigma(z) (1 + z (1 - sigma(z)))
-                        const float z = xh * gm[j][e] + bt[j][e];
+                        const float z = xh * gm[e] + bt[e];
                         const float sg = 1.0f / (1.0f + __expf(-z));
                         dz *= sg * (1.0f + z * (1.0f - sg));
                     }
@@ -231,10 +232,25 @@ extern "C" int t2v_norm_affine_grad(const void* x0, int c0, int ld0, const void*
                                     void* stream) {
     T2V_REQUIRE(dy && ws && rows > 0 && sum_rows > 0 && rows % sum_rows == 0 && kind >= 0 && kind <= 2 && (dgamma || dbeta), T2V_EINVAL,
                 "t2v_norm_affine_grad: bad argument");
-    if (kind == 2) { c1 = 0; x1 = nullptr; silu = 0; }
+    if (kind == 2) {
+        c1 = 0; x1 = nullptr; silu = 0;
+        constexpr int CHUNK = 2048;
+        if (c0 > CHUNK) {   // plain column sums are independent per column: wider matrices (the 8 C-wide GEGLU pre-activation) go out in chunks
+            for (int c = 0; c < c0; c += CHUNK) {
+                const int n = c0 - c < CHUNK ? c0 - c : CHUNK;
+                const int rc = t2v_norm_affine_grad(nullptr, n, 0, nullptr, 0, 0, rows, sum_rows, 2, 0, 0, nullptr, 0.f, nullptr, nullptr, 0,
+                                                    (const bf16_t*)dy + c, ldy, dgamma ? dgamma + c : nullptr, ld_dgamma, dbeta ? dbeta + c : nullptr,
+                                                    ld_dbeta, ws, stream);
+                if (rc != T2V_OK) return rc;
+            }
+            return T2V_OK;
+        }
+    }
     const int C = c0 + c1;
     T2V_REQUIRE(C > 0 && C % 8 == 0 && C <= 64 * 8 * AG_MAXJ && c0 % 8 == 0 && ldy % 8 == 0 && (uintptr_t)dy % 16 == 0, T2V_ESHAPE,
-                "t2v_norm_affine_grad: channels a multiple of 8 (<= 2048), 16-byte aligned rows");
+                "t2v_norm_affine_grad: channels a multiple of 8 (<= 2560 behind a norm), 16-byte aligned rows");
+    if (kind != 2 && silu)
+        T2V_REQUIRE(((uintptr_t)gamma | (uintptr_t)beta) % 16 == 0, T2V_ESHAPE, "t2v_norm_affine_grad: gamma / beta 16-byte aligned");
     if (kind != 2) {
         T2V_REQUIRE(x0 && ld0 % 8 == 0 && (uintptr_t)x0 % 16 == 0 && (c1 == 0 || (x1 && ld1 % 8 == 0 && (uintptr_t)x1 % 16 == 0)), T2V_ESHAPE,
                     "t2v_norm_affine_grad: the normalised tensor's rows must be 16-byte aligned");
@@ -252,8 +268,12 @@ extern "C" int t2v_norm_affine_grad(const void* x0, int c0, int ld0, const void*
     const size_t smem = (size_t)8 * C * sizeof(float);
     dim3 grid(nblk, (unsigned)n_out);
 #define T2V_AG_LAUNCH(K)                                                                                                                      \
-    hipLaunchKernelGGL(affine_grad_partial_kernel<K>, grid, dim3(256), smem, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, sum_rows, \
-                       rows_per_blk, rows_per_unit, groups, stats, ln_eps, gamma, beta, silu, (const bf16_t*)dy, ldy, ws)
+    do {                                                                                                                                      \
+        static bool attr_set = false;   /* (8 C floats of LDS: 80 KB at 2560 channels, above the 64 KB a launch gets unasked) */             \
+        if (!attr_set) { hipFuncSetAttribute((const void*)affine_grad_partial_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
+        hipLaunchKernelGGL(affine_grad_partial_kernel<K>, grid, dim3(256), smem, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, sum_rows, \
+                           rows_per_blk, rows_per_unit, groups, stats, ln_eps, gamma, beta, silu, (const bf16_t*)dy, ldy, ws);               \
+    } while (0)
     if (kind == 0) T2V_AG_LAUNCH(0);
     else if (kind == 1) T2V_AG_LAUNCH(1);
     else T2V_AG_LAUNCH(2);

@@ -732,3 +732,52 @@ def test_linear_pr_ragged_rows_strides_and_splits(pair):
     _lpr_case(pair, M=333, K=640, N=1024, act=nt.ACT_GEGLU, ny=2, seed=11)            # ragged, two workgroup rows
     _lpr_case(pair, M=4000, K=320, N=960, seed=12, lda=384, ldo=1024)                 # operands as column slices of wider buffers
     _lpr_case(pair, M=992, K=640, N=640, residual=True, seed=13)                      # residual + a last panel with one block of three
+
+
+# ---- base-weight gradients for full fine-tuning (csrc/full_grad.hip) ------------------------------------------------------------------
+@pytest.mark.parametrize("mode,n_img,h,w,frames,c0,c1", [
+    (1, 16, 40, 64, 0, 320, 0), (1, 2, 10, 16, 0, 640, 640), (2, 16, 40, 64, 0, 320, 0), (3, 16, 20, 32, 0, 640, 0), (4, 16, 10, 16, 16, 1280, 0),
+    (4, 16, 40, 64, 16, 320, 0), (5, 2, 64, 64, 0, 128, 0), (1, 2, 8, 8, 0, 8, 0)])
+def test_im2col_on_device(pair, mode, n_img, h, w, frames, c0, c1):
+    """t2v_im2col_bf16 at the UNet's conv shapes (3x3, stride 2, nearest-x2, temporal, the VAE encoder's padded stride 2, the 8-channel
+    entry conv) against the emulation (F.unfold): a copy — exact."""
+    x0, x1 = pair.act(_rt(n_img * h * w, c0, seed=1)), (pair.act(_rt(n_img * h * w, c1, seed=2)) if c1 else (None, None))
+    taps = 3 if mode == 4 else 9
+    rows = pair.hip.im2col_rows(mode, n_img, h, w)
+    assert rows == pair.emu.im2col_rows(mode, n_img, h, w)
+    o_h = torch.full((rows, taps * (c0 + c1)), float("nan"), dtype=torch.bfloat16, device="cuda")
+    o_e = torch.zeros(rows, taps * (c0 + c1))
+    pair.run("im2col", (x0[0], x1[0], mode, n_img, h, w, frames, o_h), (x0[1], x1[1], mode, n_img, h, w, frames, o_e))
+    assert torch.equal(o_h.float().cpu(), o_e)
+
+
+@pytest.mark.parametrize("kind,c0,c1,units,rows,silu,sum_rows", [
+    (0, 320, 0, 16, 2560, True, 40960), (0, 640, 320, 1, 10240, True, 10240), (0, 1280, 0, 16, 160, False, 2560), (1, 320, 0, 1, 40960, False, 40960),
+    (1, 1280, 0, 1, 2560, False, 2560), (2, 320, 0, 1, 40960, False, 40960), (2, 2560, 0, 1, 4096, False, 4096), (2, 640, 0, 1, 20480, False, 10240)])
+def test_norm_affine_grad_on_device(pair, kind, c0, c1, units, rows, silu, sum_rows):
+    """t2v_norm_affine_grad at the UNet's sizes: GroupNorm(+SiLU) with a two-part input, LayerNorm, bias column sums, per-clip sums."""
+    M, Cc, G = units * rows, c0 + c1, 32
+    x0, x1 = pair.act(_rt(M, c0, seed=1)), (pair.act(_rt(M, c1, seed=2)) if c1 else (None, None))
+    dy = pair.act(_rt(M, Cc, seed=3))
+    gamma, beta = pair.f32(_rt(Cc, seed=5) * 0.2 + 1.0), pair.f32(_rt(Cc, seed=6) * 0.1)
+    n_out = M // sum_rows
+    outs = []
+    for side, ops in enumerate((pair.hip, pair.emu)):
+        dev = "cuda" if side == 0 else "cpu"
+        kw = dict(kind=kind, sum_rows=sum_rows, silu=silu)
+        if kind == 0:
+            stats = torch.zeros(units, 2 * G)
+            pair.emu.gn_stats(x0[1], x1[1], units, rows, 1e-5, None, stats, G)
+            kw.update(rows_per_unit=rows, groups=G, stats=stats.to(dev), gamma=gamma[side], beta=beta[side])
+        elif kind == 1:
+            kw.update(eps=1e-5)
+        dg = torch.full((n_out, Cc), 3.0, device=dev) if kind != 2 else None
+        db = torch.full((n_out, Cc), 3.0, device=dev)
+        ws = torch.zeros(max(ops.norm_affine_grad_ws_floats(M, sum_rows, Cc), 1), device=dev)
+        ops.norm_affine_grad(None if kind == 2 else x0[side], x1[side], dy[side], ws=ws, dgamma=dg, dbeta=db, **kw)
+        outs.append((None if dg is None else dg.cpu(), db.cpu()))
+    torch.cuda.synchronize()
+    (dg_h, db_h), (dg_e, db_e) = outs
+    assert rel_l2(db_h, db_e) < 2e-3      # (bf16 inputs on the device against fp32 copies of the same values: summation order only)
+    if kind != 2:
+        assert rel_l2(dg_h, dg_e) < 2e-3

@@ -350,7 +350,8 @@ def test_im2col_matches_unfold(ops, mode, n_img, h, w, frames, c0, c1):
 
 @pytest.mark.parametrize("kind,c0,c1,units,rows,silu,sum_rows", [
     (0, 64, 0, 2, 48, True, 96), (0, 32, 64, 3, 40, False, 120), (0, 320, 0, 1, 70, True, 70), (1, 64, 0, 1, 50, False, 50),
-    (1, 320, 0, 1, 33, False, 33), (1, 1280, 0, 1, 9, False, 9), (2, 96, 0, 1, 60, False, 60), (2, 64, 0, 1, 60, False, 20)])
+    (1, 320, 0, 1, 33, False, 33), (1, 1280, 0, 1, 9, False, 9), (2, 96, 0, 1, 60, False, 60), (2, 64, 0, 1, 60, False, 20),
+    (0, 1280, 1280, 1, 20, True, 20), (2, 5120, 0, 1, 24, False, 24)])   # the widest GroupNorm (a 1280 + 1280 concat); column sums in 2048-column chunks
 def test_norm_affine_grad_against_autograd_style_sums(ops, kind, c0, c1, units, rows, silu, sum_rows):
     """t2v_norm_affine_grad: dgamma / dbeta of GroupNorm(+SiLU) (two-part input), of LayerNorm, plain column sums (bias gradients) and
     per-clip column sums (sum_rows < rows: d(loss)/d(time-embedding row)), against the emulation — and the emulation against torch autograd."""

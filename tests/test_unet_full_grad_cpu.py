@@ -102,3 +102,41 @@ def test_partially_frozen_network_and_auto_route():
     _compare(got, ref)
     m.requires_grad_(False)
     assert m._auto_route(x.clone().requires_grad_(True), ctx, tc, None)[0] == "composite"   # input gradients only: not this route
+
+
+def _fixture_step(m, x, ts, ctx, tc, r_out, route):
+    """(output, d/d latents, gradients in named_parameters order) through ``route``."""
+    y, dx, grads = _grads(m, route, x, ts, ctx, tc, r_out)
+    return y, dx, [grads[n] for n, _ in m.named_parameters()]
+
+
+def check_against_reference_fixture(y, dx, grads, names, gg, out_tol, dx_tol, norm_tol, proj_tol, full_tol):
+    """Compare one step with tests/golden/unet_tiny_full_grad.npz (made by the imported reference: make_golden_full_grad.py)."""
+    from tests.golden.make_golden_full_grad import KEEP_FULL, digests
+    assert [str(n) for n in gg["names"]] == names, "parameter registration order differs from the reference's"
+    e_out, e_dx = rel_l2(y, gg["out"]), rel_l2(dx, gg["dx"])
+    d, ref = torch.from_numpy(digests(grads)), gg["digests"]
+    norm_err = (d[:, 0] - ref[:, 0]).abs() / ref[:, 0]
+    proj_err = ((d[:, 1:] - ref[:, 1:]).abs() / ref[:, :1]).max(dim=1).values
+    print(f"[full fine-tuning fixture] out {e_out:.3e} dx {e_dx:.3e}; per-parameter norm err max {float(norm_err.max()):.4f} median "
+          f"{float(norm_err.median()):.5f}; projection err / norm max {float(proj_err.max()):.4f} median {float(proj_err.median()):.5f}", flush=True)
+    assert e_out < out_tol and e_dx < dx_tol
+    assert float(norm_err.max()) < norm_tol, names[int(norm_err.argmax())]
+    assert float(proj_err.max()) < proj_tol[0] and float(proj_err.median()) < proj_tol[1], names[int(proj_err.argmax())]
+    for n in KEEP_FULL:
+        assert rel_l2(grads[names.index(n)], gg["g_" + n.replace(".", "__")]) < full_tol, n
+
+
+def test_module_autograd_reproduces_the_reference_full_gradient_fixture():
+    """The checker of the engine tests — autograd through this repository's torch module — against the REFERENCE's own parameter
+    gradients (tests/golden/unet_tiny_full_grad.npz): same registration order, every gradient to fp32 round-off."""
+    from tests.golden.make_golden_full_grad import SEED_R
+    g, gg = load("unet_tiny"), load("unet_tiny_full_grad")
+    m = UNetModel(**tiny_unet_params())
+    m.load_state_dict(synth_state_dict(manifest("unet_tiny")), strict=True)
+    m.requires_grad_(True)
+    m.eval()
+    r_out = torch.randn(g["x"].shape, generator=torch.Generator().manual_seed(SEED_R))
+    assert torch.equal(r_out, gg["r_out"])
+    y, dx, grads = _fixture_step(m, g["x"], g["ts"], g["ctx"], g["tc"], r_out, "off")
+    check_against_reference_fixture(y, dx, grads, [n for n, _ in m.named_parameters()], gg, 1e-5, 1e-4, 1e-4, (1e-3, 1e-4), 1e-4)

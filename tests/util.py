@@ -34,7 +34,8 @@ VAE_FULL_DD = dict(double_z=True, z_channels=4, resolution=512, in_channels=3, o
 
 def load(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
-    return {k: torch.from_numpy(z[k]) for k in z.files}
+    # (string arrays — parameter names of a fixture — stay numpy)
+    return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind not in "USO" else z[k]) for k in z.files}
 
 
 _MAN = None
