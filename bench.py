@@ -652,9 +652,13 @@ def main():
             # event times of the eager replay stay in by_kernel / kernel_ms as `ms_eager`
             gm = dict(g0, tflop=g0["tflop"] + h0["tflop"] + l0["tflop"], launches=g0["launches"] + h0["launches"] + l0["launches"],
                       ms_eager=g0["ms"] + h0["ms"] + l0["ms"])
-            with torch.no_grad():
-                fam_ms = family_ingraph(eng, plan["rec"], GEMM_FAMILY)
-                one_ms = {n: family_ingraph(eng, plan["rec"], (n,)) for n in GEMM_FAMILY}
+            try:   # (a derived figure must never cost the bench line: a failed capture falls back to the eager event times, labelled)
+                with torch.no_grad():
+                    fam_ms = family_ingraph(eng, plan["rec"], GEMM_FAMILY)
+                    one_ms = {n: family_ingraph(eng, plan["rec"], (n,)) for n in GEMM_FAMILY}
+            except Exception as e:  # noqa: BLE001
+                log(f"in-graph family timing failed ({e!r}): roofline from the eager per-launch events")
+                fam_ms, one_ms = None, {}
             gm["ms"] = fam_ms if fam_ms else gm["ms_eager"]
             ach = gm["tflop"] / (gm["ms"] / 1e3) if gm["ms"] > 0 else 0.0
 
@@ -666,7 +670,8 @@ def main():
                 "kernel": "gemm_kernel + conv_halo_kernel + linear_pr_kernel (implicit-GEMM conv / linear: v_mfma_f32_32x32x16_bf16 / 16x16x32_bf16)",
                 "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / MFMA_PEAK_TFLOPS, 4), **gemm_traffic(),
-                "timing": "in-graph: the family's launches of one step captured into one hipGraph on their stream, best of 5 replays (HIP events)",
+                "timing": ("in-graph: the family's launches of one step captured into one hipGraph on their stream, best of 5 replays (HIP events)"
+                           if fam_ms else "eager replay, one HIP event pair per launch (the in-graph capture failed on this box)"),
                 "launches": gm["launches"], "tflop_per_step": round(gm["tflop"], 3), "ms_per_step": round(gm["ms"], 3),
                 "ms_per_step_eager_events": round(gm["ms_eager"], 3),
                 "whole_step_frac": round(UNET_TFLOP_PER_STEP / (ms_per_step / 1e3) / MFMA_PEAK_TFLOPS, 4),
