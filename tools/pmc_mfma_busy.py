@@ -12,7 +12,7 @@ import csv
 import re
 import sys
 
-CLASSES = [("conv_halo_kernel", "t2v_conv_halo (3x3 conv, halo slab)"), ("gemm_kernel", "t2v_gemm (implicit-GEMM conv / linear)"),
+CLASSES = [("conv_halo_kernel", "t2v_conv_halo (3x3 conv, halo slab)"), ("linear_pr_kernel", "t2v_linear_pr (short-K linear, resident panel)"), ("gemm_kernel", "t2v_gemm (implicit-GEMM conv / linear)"),
            ("splitk_reduce", "t2v_gemm split-K reduce"), ("attn_spatial", "flash attention (spatial / text)"), ("attn_temporal", "temporal attention"),
            ("gn_", "GroupNorm"), ("group_norm", "GroupNorm"), ("layernorm", "LayerNorm"), ("ffn", "fused FFN")]
 

@@ -17,7 +17,7 @@ def collect(path, counter):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"]
-        fam = ("gemm" if ("gemm_kernel" in name or "splitk_reduce" in name or "conv_halo_kernel" in name or "gemm2_kernel" in name) else
+        fam = ("gemm" if ("gemm_kernel" in name or "splitk_reduce" in name or "conv_halo_kernel" in name or "gemm2_kernel" in name or "linear_pr_kernel" in name) else
                "other_t2v" if "anonymous namespace" in name and "at::" not in name else None)
         if fam is None:
             continue
