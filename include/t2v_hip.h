@@ -162,6 +162,15 @@ typedef struct t2v_gemm_desc {
      * ONE Linear — no LayerNorm launch, no normalised tensor in memory.  ln_out must be NULL; not combined with a residual.
      * t2v_gemm and t2v_conv_halo refuse a descriptor with ln_in set. */
     int ln_in;
+    /* ---- GroupNorm applied to the INPUT rows while the activation panel is filled (t2v_linear_pr only; NULL = off) -----------------------
+     * gn_coef fp32 [units][2][K]: the per-channel affine t2v_gn_coef_cs made of the producers' column statistics (coef[u][0][c] = rstd
+     * gamma[c], coef[u][1][c] = beta[c] - mean rstd gamma[c]); unit of row m = m / gn_rows_per_unit.  The launch computes
+     * epilogue( (A * coef[u][0] + coef[u][1]) x W^T ), the normalised rows rounded to bf16 as t2v_group_norm_cs would have written them —
+     * SpatialTransformer / TemporalTransformer: x = proj_in(norm(x)) (attention.py:373-389,471-513) without the normalised tensor in
+     * memory.  gn_rows_per_unit a multiple of the panel height (160 rows at K = 320, 96 at K = 640: ask t2v_linear_pr_supported), no
+     * SiLU, plain epilogue (bias only), not combined with ln_in.  t2v_gemm and t2v_conv_halo refuse a descriptor with gn_coef set. */
+    const float* gn_coef;
+    int gn_rows_per_unit;
 } t2v_gemm_desc;
 
 int t2v_gemm(const t2v_gemm_desc* d, void* stream);
@@ -467,6 +476,12 @@ typedef struct t2v_wgrad_problem {
     float alpha;
 } t2v_wgrad_problem;
 int t2v_wgrad_tn_group(const t2v_wgrad_problem* problems, int n, float* ws, long long ws_bytes, void* stream);
+/* t2v_gn_coef_cs: the per-channel affine of a GroupNorm alone, from the producers' column statistics (t2v_gemm_desc::colstat_out layout,
+ * one array per part of a virtual concat): coef fp32 [n_units][2][c0 + c1] — for consumers that normalise in their own load phase
+ * (t2v_gemm_desc::gn_coef).  t2v_gn_coef_cs_supported: 1 / 0 (else t2v_group_norm_cs, which writes the normalised tensor). */
+int t2v_gn_coef_cs_supported(const float* cs0, int c0, const float* cs1, int c1, int n_units, int rows_per_unit, int groups);
+int t2v_gn_coef_cs(const float* cs0, int c0, const float* cs1, int c1, int n_units, int rows_per_unit, int groups, float eps,
+                   const float* gamma, const float* beta, float* coef, void* stream);
 /* ---- base-weight gradients for FULL fine-tuning (csrc/full_grad.hip; train_latent_t2v_turbo_v2.py:798-816,1262) ----------------------
  * t2v_im2col_bf16: the shifted-row matrix of a conv leaf in the K order of the forward's tap-major pack,
  *     out[m][tap * C + c] = x[src(m, tap)][c]   (0 outside the grid; x = virtual concat [x0 | x1], C = c0 + c1, channels % 8 == 0)

@@ -442,7 +442,7 @@ extern "C" int t2v_conv_halo_pack_cols(int channels) { return ((channels / 32 * 
 static int halo_prepare(const t2v_gemm_desc* dd, HaloParams& p, int& cfg) {
     cfg = 0;
     T2V_REQUIRE(dd && dd->a0 && dd->w && dd->out, T2V_EINVAL, "t2v_conv_halo: null pointer");
-    T2V_REQUIRE(!dd->ln_in, T2V_EINVAL, "t2v_conv_halo: ln_in is t2v_linear_pr's");
+    T2V_REQUIRE(!dd->ln_in && !dd->gn_coef, T2V_EINVAL, "t2v_conv_halo: ln_in / gn_coef are t2v_linear_pr's");
     p.d = *dd;
     t2v_gemm_desc& d = p.d;
     if (!d.a1) { d.c1 = 0; d.lda1 = 0; }

@@ -1340,7 +1340,7 @@ extern "C" int t2v_gemm_num_configs(void) { return kNumCfg; }
 // fuse_ok = false: the caller has to use the standalone kernels).  Shared by t2v_gemm and t2v_gemm_fuse_supported.
 static int gemm_prepare(const t2v_gemm_desc* dd, GemmParams& p, int& cfg_out, int& fuse, int& fuse_cfg, bool& fuse_ok) {
     T2V_REQUIRE(dd && dd->a0 && dd->w && dd->out, T2V_EINVAL, "t2v_gemm: null pointer");
-    T2V_REQUIRE(!dd->ln_in, T2V_EINVAL, "t2v_gemm: ln_in (LayerNorm of the input rows) is t2v_linear_pr's; normalise first or ask t2v_linear_pr_supported");
+    T2V_REQUIRE(!dd->ln_in && !dd->gn_coef, T2V_EINVAL, "t2v_gemm: ln_in / gn_coef (a norm of the input rows) are t2v_linear_pr's; normalise first or ask t2v_linear_pr_supported");
     p.d = *dd;
     t2v_gemm_desc& d = p.d;
     if (!d.a1) { d.c1 = 0; d.lda1 = 0; }

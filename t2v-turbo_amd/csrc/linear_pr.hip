@@ -88,8 +88,9 @@ __device__ __forceinline__ void lpr_static_for(F&& f) {
 }
 
 // TB: 32-token blocks per panel; KS: 16-deep K steps; EPI: 0 = bias, 1 = bias -> GEGLU (chunk = [32 value rows | 32 gate rows] -> 32
-// output columns), 2 = bias + residual; LNIN: the panel holds LayerNorm(A rows) (t2v_gemm_desc::ln_in), normalised as it is filled
-template <int TB, int KS, int EPI, bool LNIN>
+// output columns), 2 = bias + residual; PRE: what the panel fill does to the A rows on their way into LDS — 0 nothing, 1 LayerNorm
+// (t2v_gemm_desc::ln_in), 2 the per-(unit, channel) affine of a GroupNorm whose statistics are known (t2v_gemm_desc::gn_coef)
+template <int TB, int KS, int EPI, int PRE>
 __global__ __launch_bounds__(kLprWaves * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_pr_kernel(const LprParams p) {
     constexpr int BM = 32 * TB, K = 16 * KS, D = kLprRing;
     // XPF: the weight ring runs on across chunk boundaries (the first D - 1 steps of the wave's next chunk are requested in this
@@ -155,7 +156,8 @@ __global__ __launch_bounds__(kLprWaves * 64) __attribute__((amdgpu_waves_per_eu(
 
     // ---- panel fill: global rows (8 rows x 128 B per wave instruction: whole cache lines) -> registers -> [K/8][BM][16 B] ----------
     // lane -> row 8 rg + (lane & 7), 16-byte column 8 cg + (lane >> 3): eight consecutive lanes write 128 contiguous LDS bytes
-    if constexpr (!LNIN) {
+    constexpr bool LNIN = PRE == 1, GNIN = PRE == 2;
+    if constexpr (PRE == 0) {
         constexpr int CG = K / 64, RG = BM / 8, PIECES = RG * CG, PPW = (PIECES + kLprWaves - 1) / kLprWaves;
         uint4 stage[PPW];
         const bf16_t* a = (const bf16_t*)d.a0;
@@ -203,36 +205,42 @@ __global__ __launch_bounds__(kLprWaves * 64) __attribute__((amdgpu_waves_per_eu(
         for (int i = tid; i < nb; i += kLprWaves * 64) sb[i] = d.bias ? d.bias[c_begin * 64 + i] : 0.f;
         float mean[RPW], rstd[RPW];
         constexpr float inv_k = 1.0f / (float)K;
+        if constexpr (LNIN) {
 #pragma unroll
-        for (int jr = 0; jr < RPW; ++jr) {
-            if (wave + kLprWaves * jr < RG) {
-                float sm = 0.f;
+            for (int jr = 0; jr < RPW; ++jr) {
+                if (wave + kLprWaves * jr < RG) {
+                    float sm = 0.f;
 #pragma unroll
-                for (int cg = 0; cg < CG; ++cg) {
-                    float f[8];
-                    unpack8(stage[jr][cg], f);
+                    for (int cg = 0; cg < CG; ++cg) {
+                        float f[8];
+                        unpack8(stage[jr][cg], f);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) sm += f[e];
+                        for (int e = 0; e < 8; ++e) sm += f[e];
+                    }
+                    sm += __shfl_xor(sm, 8, 64); sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
+                    mean[jr] = sm * inv_k;
+                    float q = 0.f;
+#pragma unroll
+                    for (int cg = 0; cg < CG; ++cg) {
+                        float f[8];
+                        unpack8(stage[jr][cg], f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float dlt = f[e] - mean[jr]; q += dlt * dlt; }
+                    }
+                    q += __shfl_xor(q, 8, 64); q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+                    rstd[jr] = rsqrtf(q * inv_k + d.ln_eps);
                 }
-                sm += __shfl_xor(sm, 8, 64); sm += __shfl_xor(sm, 16, 64); sm += __shfl_xor(sm, 32, 64);
-                mean[jr] = sm * inv_k;
-                float q = 0.f;
-#pragma unroll
-                for (int cg = 0; cg < CG; ++cg) {
-                    float f[8];
-                    unpack8(stage[jr][cg], f);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float dlt = f[e] - mean[jr]; q += dlt * dlt; }
-                }
-                q += __shfl_xor(q, 8, 64); q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-                rstd[jr] = rsqrtf(q * inv_k + d.ln_eps);
             }
         }
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
             const int c = 8 * cg + (lane >> 3);
-            const float4 g0 = *(const float4*)(d.ln_gamma + c * 8), g1 = *(const float4*)(d.ln_gamma + c * 8 + 4);
-            const float4 b0 = *(const float4*)(d.ln_beta + c * 8), b1 = *(const float4*)(d.ln_beta + c * 8 + 4);
+            // LayerNorm: the layer's affine; GroupNorm: rstd gamma / beta - mean rstd gamma per channel of the panel's statistics unit
+            // (host-checked: a panel lies inside one unit), coef [unit][2][K] as t2v_gn_coef_cs wrote it
+            const float* ga = LNIN ? d.ln_gamma : d.gn_coef + (long long)(m0 / d.gn_rows_per_unit) * 2 * K;
+            const float* gb = LNIN ? d.ln_beta : ga + K;
+            const float4 g0 = *(const float4*)(ga + c * 8), g1 = *(const float4*)(ga + c * 8 + 4);
+            const float4 b0 = *(const float4*)(gb + c * 8), b1 = *(const float4*)(gb + c * 8 + 4);
             const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
             const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(kLprWaves * 64) __attribute__((amdgpu_waves_per_eu(
                     float f[8];
                     unpack8(stage[jr][cg], f);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean[jr]) * rstd[jr] * gg[e] + bb[e];
+                    for (int e = 0; e < 8; ++e) f[e] = LNIN ? (f[e] - mean[jr]) * rstd[jr] * gg[e] + bb[e] : f[e] * gg[e] + bb[e];
                     *(uint4*)(smem + (c * BM + row) * 16) = m0 + row < d.M ? pack8(f) : make_uint4(0u, 0u, 0u, 0u);
                 }
             }
@@ -460,15 +468,15 @@ __global__ __launch_bounds__(kLprWaves * 64) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-template <int TB, int KS, int EPI, bool LNIN = false>
+template <int TB, int KS, int EPI, int PRE = 0>
 int lpr_launch(const LprParams& p, int tiles_m, int ny, hipStream_t s) {
     const int smem = 16 * KS * 32 * TB * 2 + p.chunks_per_y * 64 * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)linear_pr_kernel<TB, KS, EPI, LNIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)linear_pr_kernel<TB, KS, EPI, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((linear_pr_kernel<TB, KS, EPI, LNIN>), dim3(tiles_m, ny), dim3(kLprWaves * 64), smem, s, p);
+    hipLaunchKernelGGL((linear_pr_kernel<TB, KS, EPI, PRE>), dim3(tiles_m, ny), dim3(kLprWaves * 64), smem, s, p);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
@@ -498,9 +506,13 @@ static int lpr_prepare(const t2v_gemm_desc* dd, LprParams& p, int& cfg, int& til
         T2V_REQUIRE(d.ln_gamma && d.ln_beta, T2V_EINVAL, "t2v_linear_pr: ln_in without ln_gamma / ln_beta");
         if (d.residual || ((uintptr_t)d.ln_gamma | (uintptr_t)d.ln_beta) % 16) return T2V_OK;
     }
+    const int bm = d.c0 == 320 ? 160 : 96;
+    if (d.gn_coef) {   // GroupNorm affine in the panel fill: every panel inside one statistics unit, not combined with ln_in / a residual
+        T2V_REQUIRE(!d.ln_in && d.gn_rows_per_unit > 0, T2V_EINVAL, "t2v_linear_pr: gn_coef with ln_in, or without gn_rows_per_unit");
+        if (d.residual || (uintptr_t)d.gn_coef % 16 || d.gn_rows_per_unit % bm || d.M % d.gn_rows_per_unit) return T2V_OK;
+    }
     p.chunks = d.N / 64;
     p.n_out = d.act == T2V_ACT_GEGLU ? d.N / 2 : d.N;
-    const int bm = d.c0 == 320 ? 160 : 96;
     tiles_m = (d.M + bm - 1) / bm;
     // column split: as many workgroups as fill the 256 CUs once, each with at least one chunk per wave
     ny = 1;
@@ -536,8 +548,12 @@ extern "C" int t2v_linear_pr(const t2v_gemm_desc* dd, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int epi = p.d.act == T2V_ACT_GEGLU ? 1 : (p.d.residual ? 2 : 0);
     if (p.d.ln_in) {
-        if (cfg == 1) return epi == 1 ? lpr_launch<5, 20, 1, true>(p, tiles_m, ny, s) : lpr_launch<5, 20, 0, true>(p, tiles_m, ny, s);
-        return epi == 1 ? lpr_launch<3, 40, 1, true>(p, tiles_m, ny, s) : lpr_launch<3, 40, 0, true>(p, tiles_m, ny, s);
+        if (cfg == 1) return epi == 1 ? lpr_launch<5, 20, 1, 1>(p, tiles_m, ny, s) : lpr_launch<5, 20, 0, 1>(p, tiles_m, ny, s);
+        return epi == 1 ? lpr_launch<3, 40, 1, 1>(p, tiles_m, ny, s) : lpr_launch<3, 40, 0, 1>(p, tiles_m, ny, s);
+    }
+    if (p.d.gn_coef) {   // (the transformers' proj_in: plain epilogue)
+        T2V_REQUIRE(epi == 0, T2V_ESHAPE, "t2v_linear_pr: gn_coef goes with the plain epilogue");
+        return cfg == 1 ? lpr_launch<5, 20, 0, 2>(p, tiles_m, ny, s) : lpr_launch<3, 40, 0, 2>(p, tiles_m, ny, s);
     }
     if (cfg == 1) return epi == 1 ? lpr_launch<5, 20, 1>(p, tiles_m, ny, s) : (epi == 2 ? lpr_launch<5, 20, 2>(p, tiles_m, ny, s) : lpr_launch<5, 20, 0>(p, tiles_m, ny, s));
     return epi == 1 ? lpr_launch<3, 40, 1>(p, tiles_m, ny, s) : (epi == 2 ? lpr_launch<3, 40, 2>(p, tiles_m, ny, s) : lpr_launch<3, 40, 0>(p, tiles_m, ny, s));

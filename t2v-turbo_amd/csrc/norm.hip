@@ -1077,6 +1077,32 @@ extern "C" int t2v_group_norm_cs(const float* cs0, const float* cs1, const void*
     return T2V_OK;
 }
 
+// The per-channel affine of a GroupNorm by itself — coef[unit][0][c] = rstd gamma[c], coef[unit][1][c] = beta[c] - mean rstd gamma[c] — from
+// the producers' column statistics (the statistics launch of t2v_group_norm_cs's direct form, alone): for a consumer that applies the
+// norm in its own load phase (t2v_linear_pr with t2v_gemm_desc::gn_coef: the transformers' proj_in).  _supported: 1 where the direct
+// form takes the shape (even channels per group and part widths, <= GN_CSD_LOADS slabs per thread), else 0: use t2v_group_norm_cs.
+extern "C" int t2v_gn_coef_cs_supported(const float* cs0, int c0, const float* cs1, int c1, int n_units, int rows_per_unit, int groups) {
+    if (!cs0 || n_units <= 0 || rows_per_unit <= 0 || rows_per_unit % 32 || groups <= 0 || c0 <= 0) return 0;
+    if (!cs1) c1 = 0;
+    if ((c0 + c1) % groups) return 0;
+    return gn_csd_threads(c0, c1, groups, rows_per_unit / 32, n_units, cs0, cs1) ? 1 : 0;
+}
+extern "C" int t2v_gn_coef_cs(const float* cs0, int c0, const float* cs1, int c1, int n_units, int rows_per_unit, int groups, float eps,
+                              const float* gamma, const float* beta, float* coef, void* stream) {
+    T2V_REQUIRE(cs0 && gamma && beta && coef && n_units > 0 && rows_per_unit > 0 && groups > 0 && groups <= 128 && c0 > 0, T2V_EINVAL,
+                "t2v_gn_coef_cs: bad argument");
+    if (!cs1) c1 = 0;
+    const int C = c0 + c1;
+    T2V_REQUIRE(rows_per_unit % 32 == 0 && C % groups == 0, T2V_ESHAPE, "t2v_gn_coef_cs: rows_per_unit a multiple of 32, channels of the groups");
+    const int slabs_per_unit = rows_per_unit / 32;
+    const int nt = gn_csd_threads(c0, c1, groups, slabs_per_unit, n_units, cs0, cs1);
+    T2V_REQUIRE(nt, T2V_ESHAPE, "t2v_gn_coef_cs: the direct statistics form does not take this shape (ask t2v_gn_coef_cs_supported)");
+    const float inv_count = 1.0f / ((float)rows_per_unit * (float)(C / groups));
+    gn_csd_launch(nt, cs0, c0, cs1, c1, n_units, slabs_per_unit, groups, inv_count, eps, gamma, beta, coef, nullptr, (hipStream_t)stream);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+
 // (mean, rstd) per (unit, group) from the column statistics of the producing GEMMs — t2v_gn_stats without reading the tensor
 // (the training engine keeps the statistics for the backward and normalises with t2v_gn_apply).  ws: t2v_group_norm_cs_ws_floats.
 extern "C" int t2v_gn_stats_cs(const float* cs0, int c0, const float* cs1, int c1, int n_units, int rows_per_unit, int groups,

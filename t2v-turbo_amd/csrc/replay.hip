@@ -69,7 +69,7 @@ const Entry kTable[] = {
     T2V_ENTRY(t2v_sumpool2x2), T2V_ENTRY(t2v_gn_bwd2), T2V_ENTRY(t2v_layernorm_bwd), T2V_ENTRY(t2v_geglu_fwd), T2V_ENTRY(t2v_geglu_bwd),
     T2V_ENTRY(t2v_scatter2x), T2V_ENTRY(t2v_add_bf16), T2V_ENTRY(t2v_attn_temporal_bwd), T2V_ENTRY(t2v_adamw_step), T2V_ENTRY(t2v_ema_update),
     T2V_ENTRY(t2v_sumsq), T2V_ENTRY(t2v_gather_f32), T2V_ENTRY(t2v_attn_spatial_bwd), T2V_ENTRY(t2v_wgrad_tn), T2V_ENTRY(t2v_wgrad_tn_group),
-    T2V_ENTRY(t2v_transpose_pad_bf16), T2V_ENTRY(t2v_dropout_bf16), T2V_ENTRY(t2v_im2col_bf16), T2V_ENTRY(t2v_norm_affine_grad),
+    T2V_ENTRY(t2v_transpose_pad_bf16), T2V_ENTRY(t2v_dropout_bf16), T2V_ENTRY(t2v_im2col_bf16), T2V_ENTRY(t2v_gn_coef_cs), T2V_ENTRY(t2v_norm_affine_grad),
 };
 constexpr int kEntries = (int)(sizeof(kTable) / sizeof(kTable[0]));
 

@@ -1074,10 +1074,43 @@ class UNetEngine(_Engine):
             return self.linear(t, proj_in, ln=(blk0.norm1, ln1)), ln1, None
         return self.linear(t, proj_in), None, None
 
+    # The transformers' GroupNorm inside proj_in's panel fill (t2v_gemm_desc::gn_coef): the statistics launch writes the per-channel
+    # affine (t2v_gn_coef_cs), t2v_linear_pr applies it to the rows on their way into LDS — no apply pass, no normalised tensor.  Taken
+    # at the 320-channel level, where t2v_linear_pr ties with the tuned t2v_gemm tile on the N = C launch (T2V_GN_IN=0: off).
+    gn_in_fill = os.environ.get("T2V_GN_IN", "1") == "1"
+    gn_in_widths = (320,)
+
+    def _proj_in_gn_in(self, tr, x, units, rows_per_unit):
+        """proj_in(GroupNorm(x)) as statistics launch + ONE t2v_linear_pr launch, or None where that form does not apply."""
+        ops, norm, mod = self.ops, tr.norm, tr.proj_in
+        if (not self.gn_in_fill or not self.fuse_gn or x.C not in self.gn_in_widths or len(x.parts) != 1 or x.cs[0] is None
+                or not hasattr(ops, "gn_coef_cs") or not (isinstance(mod, nn.Linear) or isinstance(getattr(mod, "linear", None), nn.Linear))):
+            return None
+        G = norm.num_groups
+        if not ops.gn_coef_cs_supported(x.cs[0], None, x.C, 0, units, rows_per_unit, G):
+            return None
+        w, bias = self.pk.mat(mod), self.pk.bias(mod)
+        N = w.shape[0]
+        coef = self.buf(units, 2 * x.C, torch.float32)
+        out = self.buf(x.M, N)
+        kw = dict(M=x.M, N=N, bias=bias, residual=None, act=nt.ACT_NONE, gn_in=(coef, rows_per_unit))
+        if (not self.linear_pr or w.shape[1] != x.C or not hasattr(ops, "linear_pr_supported")
+                or ops.linear_pr_supported(x.t, w, out, **kw) != 1):
+            self.pool.put(coef, out)
+            return None
+        ops.gn_coef_cs(x.cs[0], None, x.C, 0, units, rows_per_unit, norm.eps, self.pk.f32(norm.weight), self.pk.f32(norm.bias), coef, G)
+        ops.linear_pr(x.t, self.pk.lpr(w), out, **kw)
+        self.pool.put(coef)
+        return out
+
     def _transformer(self, tr, x, units, rows_per_unit, temporal):
-        t = self.gn(x, tr.norm, units, rows_per_unit, False, then=self.pk.mat(tr.proj_in))
-        y, ln1, rs = self._proj_in_with_ln(t, tr.proj_in, tr.transformer_blocks, temporal)
-        self.pool.put(t)
+        y = self._proj_in_gn_in(tr, x, units, rows_per_unit) if not self.fuse_ln else None
+        if y is not None:
+            ln1 = rs = None
+        else:
+            t = self.gn(x, tr.norm, units, rows_per_unit, False, then=self.pk.mat(tr.proj_in))
+            y, ln1, rs = self._proj_in_with_ln(t, tr.proj_in, tr.transformer_blocks, temporal)
+            self.pool.put(t)
         for i, blk in enumerate(tr.transformer_blocks):
             if i > 0 and self.fold_ln:
                 rs = None   # (depth > 1: the previous block's feed-forward output carries no statistics; its norm1 is a launch)

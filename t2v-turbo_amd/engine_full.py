@@ -112,6 +112,17 @@ class FullTrainMixin:
     def _idx(self, key, make):
         return self.pk._memo(("full_idx",) + key, lambda: make().to(torch.int32).to(self.device).contiguous())
 
+    def full_wgrad(self, dy, xmat, out):
+        """out[R, C] = dy^T xmat by t2v_wgrad_tn, in row blocks of the output where one product's partial slabs would not fit the
+        split-K workspace (the widest leaf: 1 280 x 23 040 fp32 = 118 MB for the 2 560-channel 3x3 convs of the decoder half)."""
+        ops = self.ops
+        R_, C_ = out.shape
+        ws_bytes = getattr(ops, "SPLITK_WS_BYTES", 96 << 20)
+        max_rows = max(64, (ws_bytes // 4) // (4 * C_) // 64 * 64)      # at least four token splits per block
+        for r0 in range(0, R_, max_rows):
+            r1 = min(R_, r0 + max_rows)
+            ops.wgrad_tn(dy[:, r0:r1], xmat, out[r0:r1])
+
     def full_colsum(self, dy, dst, sum_rows):
         """dst[u][c] = sum of ``sum_rows`` consecutive rows of dy (fp32 [rows / sum_rows, C], a column slice of a wider buffer allowed)."""
         ops = self.ops
@@ -146,15 +157,15 @@ class FullTrainMixin:
             if perm is None:
                 g2 = self.fgrad(w).view(n, k)
                 c0 = x.parts[0].shape[1]
-                ops.wgrad_tn(d, x.parts[0], g2[:, :c0])
+                self.full_wgrad(d, x.parts[0], g2[:, :c0])
                 if x.p1 is not None:
-                    ops.wgrad_tn(d, x.p1, g2[:, c0:])
+                    self.full_wgrad(d, x.p1, g2[:, c0:])
                 self.full_bias_grad(b, d)
             else:
                 # packed output row j = original row perm[j] (GEGLU's [32 value | 32 gate] groups): gradient rows go back through the inverse
                 assert len(mods) == 1 and x.p1 is None
                 tmp = self.buf(n, k, torch.float32)
-                ops.wgrad_tn(d, x.parts[0], tmp)
+                self.full_wgrad(d, x.parts[0], tmp)
                 inv = torch.empty_like(perm)
                 inv[perm] = torch.arange(perm.numel())
                 idx_w = self._idx(("rows", id(mod), n, k), lambda: (inv[:, None] * k + torch.arange(k)[None, :]).reshape(-1))
@@ -177,7 +188,7 @@ class FullTrainMixin:
         xcol = self.buf(rows, taps * C)
         ops.im2col(x.parts[0], x.p1, mode, x.n_img, x.h, x.w, info.get("frames", 0), xcol)
         tmp = self.buf(dy.shape[1], taps * C, torch.float32)
-        ops.wgrad_tn(dy, xcol, tmp)
+        self.full_wgrad(dy, xcol, tmp)
         self.pool.put(xcol)
         # parameter layout [N, C, k...] <- tap-major [N', taps, C']
         idx = self._idx(("conv", n, cp, C, taps), lambda: ((torch.arange(n)[:, None, None] * taps + torch.arange(taps)[None, None, :]) * C

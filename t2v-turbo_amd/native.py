@@ -50,7 +50,7 @@ class GemmDesc(C.Structure):
         ("rowstat_out", C.c_void_p), ("ld_rowstat", C.c_int), ("colstat_out", C.c_void_p),
         ("lnf_stats", C.c_void_p), ("lnf_ld", C.c_int), ("lnf_nblk", C.c_int), ("lnf_eps", C.c_float), ("lnf_s", C.c_void_p),
         ("lora_t", C.c_void_p), ("ld_lora_t", C.c_int), ("lora_u", C.c_void_p), ("ld_lora_u", C.c_int), ("lora_n_leaf", C.c_int),
-        ("lora_scale", C.c_float), ("ln_in", C.c_int),
+        ("lora_scale", C.c_float), ("ln_in", C.c_int), ("gn_coef", C.c_void_p), ("gn_rows_per_unit", C.c_int),
     ]
 
 
@@ -231,6 +231,9 @@ _SIGS = {
     "t2v_wgrad_tn": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int,
                                C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
     "t2v_wgrad_tn_group": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "t2v_gn_coef_cs_supported": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "t2v_gn_coef_cs": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
     "t2v_im2col_rows": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "t2v_im2col_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_int, C.c_void_p]),
@@ -582,7 +585,7 @@ class HipOps:
     def _gemm_desc(self, a0, w, out, *, M, N, a1=None, mode=GEMM_LINEAR, n_img=0, h=0, wd=0, frames=0, bias=None,
                    rowvec=None, rowvec_div=0, residual=None, act=ACT_NONE, alpha=1.0, batch=1, batch_inner=1,
                    a_strides=(0, 0), w_strides=(0, 0), o_strides=(0, 0), tile_cfg=0, split_k=0, dropout=None, ln=None,
-                   rowstat=None, colstat=None, lnf=None, lora=None, tune_exact=False, ln_in=None):
+                   rowstat=None, colstat=None, lnf=None, lora=None, tune_exact=False, ln_in=None, gn_in=None):
         d = GemmDesc()
         d.a0, d.c0, d.lda0 = _p(a0), a0.shape[1], _row_stride(a0)
         if a1 is not None:
@@ -628,6 +631,10 @@ class HipOps:
             gamma, beta, eps = ln_in
             assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == a0.shape[1] == beta.numel()
             d.ln_gamma, d.ln_beta, d.ln_eps, d.ln_in = _p(gamma), _p(beta), float(eps), 1
+        if gn_in is not None:   # (coef fp32 [units, 2, K], rows per unit): GroupNorm affine of the A rows in t2v_linear_pr's panel fill
+            coef, rpu = gn_in
+            assert coef.dtype == torch.float32 and coef.is_contiguous() and coef.numel() == (M // rpu) * 2 * a0.shape[1]
+            d.gn_coef, d.gn_rows_per_unit = _p(coef), int(rpu)
         if rowstat is not None:   # fp32 [M, ld]: (sum, sumsq) per 32-column block of every output row
             assert rowstat.dtype == torch.float32 and rowstat.shape[0] == M
             d.rowstat_out, d.ld_rowstat = _p(rowstat), _row_stride(rowstat)
@@ -826,6 +833,14 @@ class HipOps:
                    v_head_stride, _p(kt), _row_stride(kt), _p(qt), _p(dot), _row_stride(qt), _p(dout), _row_stride(dout), _p(o),
                    _row_stride(o), _p(l2), _p(dsum), _row_stride(l2), _p(dq), _row_stride(dq), _p(dk), _row_stride(dk), _p(dv),
                    _row_stride(dv), n_img, seq, seq, heads, scale)
+
+    def gn_coef_cs_supported(self, cs0, cs1, c0, c1, n_units, rows_per_unit, groups=32):
+        return self.lib.t2v_gn_coef_cs_supported(_p(cs0), c0, _p(cs1), c1, n_units, rows_per_unit, groups) == 1
+
+    def gn_coef_cs(self, cs0, cs1, c0, c1, n_units, rows_per_unit, eps, gamma, beta, coef, groups=32):
+        """coef fp32 [n_units, 2, c0 + c1]: the GroupNorm's per-channel affine from the producers' column statistics (t2v_gn_coef_cs)."""
+        assert coef.dtype == torch.float32 and coef.is_contiguous() and coef.numel() == n_units * 2 * (c0 + c1)
+        self._call("t2v_gn_coef_cs", _p(cs0), c0, _p(cs1), c1, n_units, rows_per_unit, groups, float(eps), _p(gamma), _p(beta), _p(coef))
 
     # ---- base-weight gradients for full fine-tuning (csrc/full_grad.hip) -----------------------------------------------------------
     def im2col_rows(self, mode, n_img, h, w):

@@ -146,10 +146,14 @@ class EmuOps:
     # ---- t2v_linear_pr: short-K Linear on the fragment pack (csrc/linear_pr.hip) ---------------------------------------------------
     def linear_pr_supported(self, a0, wp, out, *, M, N, a1=None, mode=nt.GEMM_LINEAR, bias=None, rowvec=None, residual=None,
                             act=nt.ACT_NONE, alpha=1.0, batch=1, split_k=0, dropout=None, ln=None, rowstat=None, colstat=None, lnf=None,
-                            lora=None, ln_in=None, **_):
+                            lora=None, ln_in=None, gn_in=None, **_):
         """Mirror of lpr_prepare (csrc/linear_pr.hip): 0 not taken, 1 taken."""
         if ln_in is not None and residual is not None:
             return 0
+        if gn_in is not None:
+            bm = 160 if a0.shape[1] == 320 else 96
+            if residual is not None or ln_in is not None or act != nt.ACT_NONE or gn_in[1] % bm or M % gn_in[1]:
+                return 0
         if mode != nt.GEMM_LINEAR or a1 is not None or batch > 1 or alpha != 1.0 or split_k > 1 or out.dtype not in (self.act_dtype, torch.bfloat16):
             return 0
         if any(v is not None for v in (dropout, ln, rowstat, colstat, lnf, lora, rowvec)) or act not in (nt.ACT_NONE, nt.ACT_GEGLU):
@@ -164,6 +168,12 @@ class EmuOps:
         self._log("linear_pr")
         assert self.linear_pr_supported(a0, wp, out, **kw), "t2v_linear_pr would refuse this launch"
         kw.pop("tile_cfg", None)
+        gn_in = kw.pop("gn_in", None)
+        if gn_in is not None:   # GroupNorm affine of the rows in the panel fill: rows * coef[u][0] + coef[u][1]
+            coef, rpu = gn_in
+            K = a0.shape[1]
+            cf = coef.float().view(-1, 2, K)
+            a0 = (a0.float().view(-1, rpu, K) * cf[:, None, 0, :] + cf[:, None, 1, :]).reshape(-1, K).to(a0.dtype)
         ln_in = kw.pop("ln_in", None)
         if ln_in is not None:   # LayerNorm of the rows in the panel fill: normalised rows rounded to the activation dtype, as t2v_layernorm writes them
             gamma, beta, eps = ln_in
@@ -361,6 +371,27 @@ class EmuOps:
         stats = torch.stack([mean, 1.0 / torch.sqrt(var + eps)], dim=2).reshape(n_units, groups * 2)
         self.gn_apply(x0, x1, n_units, rows_per_unit, stats, gamma, beta, silu, out, groups)
         self.calls.pop()   # (one logical op)
+
+    @staticmethod
+    def gn_coef_cs_supported(cs0, cs1, c0, c1, n_units, rows_per_unit, groups=32):
+        """Shape rules of t2v_gn_coef_cs_supported that do not depend on the thread layout (the emulation takes every such shape)."""
+        cpg = (c0 + c1) // groups
+        return rows_per_unit % 32 == 0 and (c0 + c1) % groups == 0 and cpg % 2 == 0 and c0 % 2 == 0
+
+    def gn_coef_cs(self, cs0, cs1, c0, c1, n_units, rows_per_unit, eps, gamma, beta, coef, groups=32):
+        """coef [n_units, 2, C]: rstd gamma / beta - mean rstd gamma per channel, from the producers' column statistics."""
+        self._log("gn_coef_cs")
+        C = c0 + c1
+        cs = cs0.float().view(-1, c0, 2)
+        if cs1 is not None:
+            cs = torch.cat([cs, cs1.float().view(-1, c1, 2)], dim=1)
+        sums = cs.view(n_units, rows_per_unit // 32, groups, C // groups, 2).sum(dim=(1, 3))
+        cnt = rows_per_unit * (C // groups)
+        mean = sums[:, :, 0] / cnt
+        rstd = 1.0 / torch.sqrt((sums[:, :, 1] / cnt - mean * mean).clamp_min(0.0) + eps)
+        a = rstd.repeat_interleave(C // groups, dim=1) * gamma.float()[None, :]
+        b = beta.float()[None, :] - mean.repeat_interleave(C // groups, dim=1) * a
+        coef.view(n_units, 2, C).copy_(torch.stack([a, b], dim=1))
 
     def gn_stats_cs(self, cs0, cs1, c0, c1, n_units, rows_per_unit, eps, ws, stats, groups=32):
         """(mean, rstd) per (unit, group) from the producers' column statistics."""

@@ -275,7 +275,7 @@ def test_width_320_transformer_linears_take_the_panel_resident_route():
                 if p.abs().max() == 0:
                     p.normal_(0.0, 0.02)
         g = torch.Generator().manual_seed(5)
-        x = torch.randn(1, 4, 2, 8, 8, generator=g)
+        x = torch.randn(1, 4, 2, 16, 20, generator=g)   # (320 tokens per frame: statistics units that are whole 160-row panels, for gn_in)
         ts = torch.tensor([500])
         ctx = torch.randn(1, 7, 64, generator=g)
         ops = EmuOps()
@@ -295,9 +295,18 @@ def test_width_320_transformer_linears_take_the_panel_resident_route():
         with torch.no_grad():
             y1 = eng(x, ts, ctx, 16, None, None)
         assert ops.calls.count("layernorm") >= n_ln + 8 and ops.calls.count("linear_pr") == n_lpr and rel_l2(y1, y) < 1e-6
+        # GroupNorm in proj_in's panel fill (gn_in) at the 320-channel level: statistics launch + one linear_pr launch per transformer
+        n_gc = ops.calls.count("gn_coef_cs")
+        assert n_gc >= 2, n_gc
+        eng.ln_in_fill, eng.gn_in_fill = True, False
+        eng.plans.clear()
+        ops.calls.clear()
+        with torch.no_grad():
+            y2 = eng(x, ts, ctx, 16, None, None)
+        assert ops.calls.count("gn_coef_cs") == 0 and ops.calls.count("linear_pr") == n_lpr - n_gc and rel_l2(y2, y) < 2e-5   # (x a + b against (x - mean) rstd gamma + beta in fp32)
         eng.linear_pr = False
         eng.plans.clear()
         ops.calls.clear()
         with torch.no_grad():
             y0 = eng(x, ts, ctx, 16, None, None)
-        assert "linear_pr" not in ops.calls and rel_l2(y0, y) < 1e-6
+        assert "linear_pr" not in ops.calls and rel_l2(y0, y) < 2e-5 and rel_l2(y0, y2) < 1e-6

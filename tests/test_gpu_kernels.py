@@ -726,6 +726,36 @@ def test_linear_pr_layernorm_in_the_panel_fill(pair):
     _lpr_case(pair, M=333, K=640, N=1024, ln_in=True, ny=2, seed=26, lda=704, ldo=1152)
 
 
+def test_gn_coef_cs_and_groupnorm_in_the_panel_fill(pair):
+    """t2v_gn_coef_cs + t2v_linear_pr with gn_coef (x = proj_in(norm(x)) of the transformers as statistics launch + ONE GEMM launch) against
+    the emulated pair, at the 320-channel level's two unit layouts (16 frames of 2 560 rows; one clip of 40 960 rows)."""
+    from t2v_turbo_amd import native as nt
+    for units, rpu, seed in ((16, 2560, 51), (1, 40960, 52)):
+        M, K, N, G = units * rpu, 320, 320, 32
+        x = _rt(M, K, seed=seed) * (1.0 + (torch.arange(M)[:, None] // rpu) % 3) + 0.3
+        x = x.bfloat16().float()
+        w, b = _rt(N, K, seed=seed + 1, scale=K ** -0.5), _rt(N, seed=seed + 2)
+        gamma, beta = 1.0 + 0.2 * _rt(K, seed=seed + 3), 0.3 * _rt(K, seed=seed + 4)
+        cs = torch.stack([x.view(M // 32, 32, K).sum(dim=1), (x * x).view(M // 32, 32, K).sum(dim=1)], dim=2).contiguous()   # [M/32, K, 2]
+        outs = []
+        for side, ops in enumerate((pair.hip, pair.emu)):
+            dev = "cuda" if side == 0 else "cpu"
+            cvt = (lambda t: t.cuda().bfloat16().contiguous()) if side == 0 else (lambda t: t.clone())
+            f32 = lambda t: t.to(dev).float().contiguous()   # noqa: E731
+            coef = torch.full((units, 2 * K), float("nan"), device=dev)
+            assert ops.gn_coef_cs_supported(f32(cs), None, K, 0, units, rpu, G)
+            ops.gn_coef_cs(f32(cs), None, K, 0, units, rpu, 1e-6, f32(gamma), f32(beta), coef, G)
+            out = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16 if side == 0 else torch.float32)
+            wp = cvt(nt.pack_linear_pr(w.bfloat16()).float())
+            kw = dict(M=M, N=N, bias=f32(b), gn_in=(coef, rpu))
+            assert ops.linear_pr_supported(cvt(x), wp, out, **kw) == 1
+            ops.linear_pr(cvt(x), wp, out, **kw)
+            outs.append((coef.float().cpu(), out.float().cpu()))
+        torch.cuda.synchronize()
+        assert rel_l2(outs[0][0], outs[1][0]) < 1e-4
+        assert rel_l2(outs[0][1], outs[1][1]) < BF16_TOL
+
+
 def test_linear_pr_ragged_rows_strides_and_splits(pair):
     from t2v_turbo_amd import native as nt
     _lpr_case(pair, M=1000, K=320, N=1280, act=nt.ACT_GEGLU, seed=10)                 # ragged last panel

@@ -38,7 +38,7 @@ def sim():
     return ops
 
 
-def _case(sim, *, M, K, N, act=nt.ACT_NONE, bias=True, residual=False, ny=0, seed=0, lda=None, ldo=None, ln_in=False):
+def _case(sim, *, M, K, N, act=nt.ACT_NONE, bias=True, residual=False, ny=0, seed=0, lda=None, ldo=None, ln_in=False, gn_rpu=0):
     n_out = N // 2 if act == nt.ACT_GEGLU else N
     a_full = _rt(M, lda or K, seed=seed).bfloat16()
     if ln_in:   # rows with their own offsets and scales: a LayerNorm that mixed up rows or columns could not pass
@@ -52,6 +52,9 @@ def _case(sim, *, M, K, N, act=nt.ACT_NONE, bias=True, residual=False, ny=0, see
     kw = dict(M=M, N=N, bias=b, residual=res, act=act)
     if ln_in:
         kw["ln_in"] = (1.0 + 0.2 * _rt(K, seed=seed + 4), 0.3 * _rt(K, seed=seed + 5), 1e-5)
+    if gn_rpu:   # a per-(unit, channel) affine as t2v_gn_coef_cs writes it: [units][2][K]
+        units = M // gn_rpu
+        kw["gn_in"] = (torch.stack([1.0 + 0.3 * _rt(units, K, seed=seed + 6), 0.5 * _rt(units, K, seed=seed + 7)], dim=1).contiguous(), gn_rpu)
     outs = []
     sim.lib.t2v_linear_pr_force_split(ny)
     try:
@@ -107,6 +110,22 @@ def test_layernorm_in_the_panel_fill(sim):
     _case(sim, M=200, K=320, N=960, ln_in=True, seed=32, lda=384, ldo=1024)
     _case(sim, M=96 + 40, K=640, N=640, ln_in=True, bias=False, seed=33)
     _case(sim, M=128, K=640, N=1280, act=nt.ACT_GEGLU, ln_in=True, ny=2, seed=34)
+
+
+def test_groupnorm_affine_in_the_panel_fill(sim):
+    # gn_in: x = proj_in(norm(x)) of the transformers (attention.py:373-389,471-513): several statistics units (each a whole number of
+    # panels), both geometries, column splits; a unit that is not a whole number of panels is not taken
+    _case(sim, M=640, K=320, N=320, gn_rpu=320, seed=41)
+    _case(sim, M=320, K=320, N=640, gn_rpu=160, bias=False, seed=42, lda=384, ldo=704)
+    _case(sim, M=384, K=640, N=640, gn_rpu=192, ny=2, seed=43)
+    a = _rt(320, 320).bfloat16()
+    out = torch.empty(320, 320).bfloat16()
+    wp = nt.pack_linear_pr(_rt(320, 320).bfloat16())
+    coef = torch.zeros(2, 2, 320)
+    for ops in (sim, EMU):
+        assert ops.linear_pr_supported(a, wp, out, M=320, N=320, gn_in=(coef, 160)) == 1
+        assert ops.linear_pr_supported(a, wp, out, M=320, N=320, gn_in=(torch.zeros(4, 2, 320), 80)) == 0        # half a panel per unit
+        assert ops.linear_pr_supported(a, wp, out, M=320, N=320, gn_in=(coef, 160), residual=out) == 0
 
 
 def test_not_taken_cases(sim):
