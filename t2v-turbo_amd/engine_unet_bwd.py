@@ -292,6 +292,9 @@ class UNetGradEngine(FullTrainMixin, LoraTrainMixin, UNetEngine):
             st["seed"] = torch.full((1,), getattr(self, "_seed", 0), dtype=torch.int64, device=x.device)
             self.seed_t = st["seed"]
         if self.training_full:
+            if self.checkpoint_blocks:
+                raise NotImplementedError("native full fine-tuning with checkpoint_blocks (the leaf inputs a recomputed block saves again "
+                                          "are not covered by tests): leave T2V_NATIVE_CHECKPOINT off — the tape of a full-size step fits 288 GB")
             # plain leaves on packs of the current weights (re-filled in place per step: Packer.refresh); one fp32 gradient per parameter
             self.pk = Packer(self.adt, x.device)
             st["emb_all"] = emb_all.detach().to(x.device, torch.float32).clone().contiguous()
