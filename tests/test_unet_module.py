@@ -77,7 +77,8 @@ def test_bad_args_raise():
 
 def test_auto_route_decisions():
     """``UNetModel._auto_route`` (what a CUDA call lands on under ``native_mode = "auto"``): inference engine for no-grad eval
-    calls, gradient engine for a LoRA student (grad or not, train or eval), torch composite — named reason — for the rest."""
+    calls, gradient engine for a LoRA student (grad or not, train or eval) and for the full fine-tuning student, torch composite —
+    named reason — for the rest."""
     import warnings
     from t2v_turbo_amd import lora, unet3d
     from tests.util import tiny_unet_params
@@ -85,7 +86,14 @@ def test_auto_route_decisions():
     x, ctx, tc = torch.zeros(1, 4, 4, 8, 8), torch.zeros(1, 7, 128), torch.zeros(1, 256)
     with torch.no_grad():
         assert m._auto_route(x, ctx, tc, None) == ("infer", None)
-    assert m._auto_route(x, ctx, tc, None)[0] == "composite"          # every parameter trainable: full fine-tuning
+    assert m._auto_route(x, ctx, tc, None) == ("train_full", None)    # every parameter trainable, no LoRA: full fine-tuning (round 6: native)
+    assert m._auto_route(x, ctx.clone().requires_grad_(True), tc, None)[0] == "composite"   # ... but not with a gradient w.r.t. the context
+    m.native_full = False
+    assert m._auto_route(x, ctx, tc, None)[0] == "composite"          # T2V_NATIVE_FULL=0
+    del m.native_full
+    m.train()
+    assert m._auto_route(x, ctx, tc, None) == ("train_full", None)    # the v2 student is in train mode (temporal-conv dropouts live)
+    m.eval()
     m.requires_grad_(False)
     assert m._auto_route(x, ctx, tc, None) == ("infer", None)          # nothing wants a gradient
     assert m._auto_route(x.clone().requires_grad_(True), ctx, tc, None)[0] == "composite"   # input gradient without LoRA
