@@ -92,7 +92,7 @@ __device__ __forceinline__ void lpr_static_for(F&& f) {
 // (t2v_gemm_desc::ln_in), 2 the per-(unit, channel) affine of a GroupNorm whose statistics are known (t2v_gemm_desc::gn_coef)
 template <int TB, int KS, int EPI, int PRE>
 __global__ __launch_bounds__(kLprWaves * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void linear_pr_kernel(const LprParams p) {
-    constexpr int BM = 32 * TB, K = 16 * KS, D = kLprRing;
+    constexpr int BM = 32 * TB, K = 16 * KS, D = KS % kLprRing == 0 ? kLprRing : 4;   // (K = 512: 32 steps, a four-slot ring)
     // XPF: the weight ring runs on across chunk boundaries (the first D - 1 steps of the wave's next chunk are requested in this
     // chunk's last steps and land under its epilogue).  The GEGLU epilogue leaves the registers for that; the residual epilogue
     // (32 bytes of residual per block in flight beside the accumulators) does not: there the ring is primed at every chunk start.
@@ -487,7 +487,8 @@ static int g_lpr_debug = 0, g_lpr_force_ny = 0;
 extern "C" int t2v_linear_pr_debug(int bits) { g_lpr_debug = bits; return T2V_OK; }
 extern "C" int t2v_linear_pr_force_split(int ny) { g_lpr_force_ny = ny; return T2V_OK; }
 
-// Geometry.  cfg: 0 = not taken, 1 = K 320 on 160-row panels, 2 = K 640 on 96-row panels.
+// Geometry.  cfg: 0 = not taken, 1 = K 320 on 160-row panels, 2 = K 640 on 96-row panels, 3 = K 512 on 96-row panels (the 8-head
+// temporal transformer behind the entry conv, init_attn: openaimodel3d.py:441-452; GEGLU / plain epilogue, optional ln_in).
 static int lpr_prepare(const t2v_gemm_desc* dd, LprParams& p, int& cfg, int& tiles_m, int& ny) {
     cfg = 0;
     T2V_REQUIRE(dd && dd->a0 && dd->w && dd->out, T2V_EINVAL, "t2v_linear_pr: null pointer");
@@ -496,7 +497,7 @@ static int lpr_prepare(const t2v_gemm_desc* dd, LprParams& p, int& cfg, int& til
     if (d.mode != T2V_GEMM_LINEAR || d.a1 || d.c1 || d.batch > 1 || d.alpha != 1.0f || d.out_f32 || d.split_k > 1 || d.drop_thr || d.ln_out ||
         d.rowstat_out || d.colstat_out || d.lnf_stats || d.lora_t || d.rowvec || (d.act != T2V_ACT_NONE && d.act != T2V_ACT_GEGLU))
         return T2V_OK;
-    if (d.c0 != 320 && d.c0 != 640) return T2V_OK;
+    if (d.c0 != 320 && d.c0 != 640 && d.c0 != 512) return T2V_OK;
     if (d.M <= 0 || d.N <= 0 || d.N % 64 || d.lda0 % 8 || d.ldo % 8) return T2V_OK;
     if ((long long)d.M * d.ldo >= (1ll << 31) || (long long)d.M * d.ldr >= (1ll << 31) || (long long)d.N * d.c0 * 2 >= (1ll << 31)) return T2V_OK;   // 32-bit offsets in the kernel
     if (((uintptr_t)d.a0 | (uintptr_t)d.w | (uintptr_t)d.out) % 16) return T2V_OK;
@@ -507,6 +508,7 @@ static int lpr_prepare(const t2v_gemm_desc* dd, LprParams& p, int& cfg, int& til
         if (d.residual || ((uintptr_t)d.ln_gamma | (uintptr_t)d.ln_beta) % 16) return T2V_OK;
     }
     const int bm = d.c0 == 320 ? 160 : 96;
+    if (d.c0 == 512 && (d.residual || d.gn_coef)) return T2V_OK;
     if (d.gn_coef) {   // GroupNorm affine in the panel fill: every panel inside one statistics unit, not combined with ln_in / a residual
         T2V_REQUIRE(!d.ln_in && d.gn_rows_per_unit > 0, T2V_EINVAL, "t2v_linear_pr: gn_coef with ln_in, or without gn_rows_per_unit");
         if (d.residual || (uintptr_t)d.gn_coef % 16 || d.gn_rows_per_unit % bm || d.M % d.gn_rows_per_unit) return T2V_OK;
@@ -528,7 +530,7 @@ static int lpr_prepare(const t2v_gemm_desc* dd, LprParams& p, int& cfg, int& til
     ny = (p.chunks + p.chunks_per_y - 1) / p.chunks_per_y;
     if (d.c0 * bm * 2 + p.chunks_per_y * 256 > 160 * 1024) return T2V_OK;
     p.debug = g_lpr_debug;
-    cfg = d.c0 == 320 ? 1 : 2;
+    cfg = d.c0 == 320 ? 1 : (d.c0 == 640 ? 2 : 3);
     return T2V_OK;
 }
 
@@ -547,6 +549,11 @@ extern "C" int t2v_linear_pr(const t2v_gemm_desc* dd, void* stream) {
     T2V_REQUIRE(cfg > 0, T2V_ESHAPE, "t2v_linear_pr: this launch is not taken by the panel-resident kernel (ask t2v_linear_pr_supported first)");
     hipStream_t s = (hipStream_t)stream;
     const int epi = p.d.act == T2V_ACT_GEGLU ? 1 : (p.d.residual ? 2 : 0);
+    if (cfg == 3) {
+        T2V_REQUIRE(epi != 2 && !p.d.gn_coef, T2V_ESHAPE, "t2v_linear_pr: K = 512 takes the plain and the GEGLU epilogue (ask t2v_linear_pr_supported first)");
+        if (p.d.ln_in) return epi == 1 ? lpr_launch<3, 32, 1, 1>(p, tiles_m, ny, s) : lpr_launch<3, 32, 0, 1>(p, tiles_m, ny, s);
+        return epi == 1 ? lpr_launch<3, 32, 1>(p, tiles_m, ny, s) : lpr_launch<3, 32, 0>(p, tiles_m, ny, s);
+    }
     if (p.d.ln_in) {
         if (cfg == 1) return epi == 1 ? lpr_launch<5, 20, 1, 1>(p, tiles_m, ny, s) : lpr_launch<5, 20, 0, 1>(p, tiles_m, ny, s);
         return epi == 1 ? lpr_launch<3, 40, 1, 1>(p, tiles_m, ny, s) : lpr_launch<3, 40, 0, 1>(p, tiles_m, ny, s);

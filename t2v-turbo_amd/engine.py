@@ -443,7 +443,10 @@ class _Engine:
     # (profiles/r06_linear_pr_vs_gemm.csv): the GEGLU projection and the q | k | v / q | k launches of the 320- and 640-channel levels.
     # The N = C launches (to_out, proj_in / proj_out: one chunk per wave, HBM-bound) tie or lose there and stay on t2v_gemm.
     linear_pr = os.environ.get("T2V_LINEAR_PR", "1") == "1"
-    linear_pr_min_n = {320: int(os.environ.get("T2V_LPR_MIN_N_320", "640")), 640: int(os.environ.get("T2V_LPR_MIN_N_640", "1920"))}
+    linear_pr_min_n = {320: int(os.environ.get("T2V_LPR_MIN_N_320", "640")), 640: int(os.environ.get("T2V_LPR_MIN_N_640", "1920")),
+                       512: int(os.environ.get("T2V_LPR_MIN_N_512", "1536"))}   # (512: the 8-head temporal transformer behind the entry conv)
+    if os.environ.get("T2V_LPR_K512", "1") != "1":
+        del linear_pr_min_n[512]
 
     def _lpr_takes(self, a, w, out, kw):
         if not self.linear_pr or any(k in kw for k in ("ln", "lnf", "colstat", "rowstat")) or not hasattr(self.ops, "linear_pr_supported"):

@@ -158,7 +158,9 @@ class EmuOps:
             return 0
         if any(v is not None for v in (dropout, ln, rowstat, colstat, lnf, lora, rowvec)) or act not in (nt.ACT_NONE, nt.ACT_GEGLU):
             return 0
-        if a0.shape[1] not in (320, 640) or N % 64 or a0.stride(0) % 8 or out.stride(0) % 8:
+        if a0.shape[1] not in (320, 512, 640) or N % 64 or a0.stride(0) % 8 or out.stride(0) % 8:
+            return 0
+        if a0.shape[1] == 512 and (residual is not None or gn_in is not None):
             return 0
         if residual is not None and (act == nt.ACT_GEGLU or residual.stride(0) % 8 or M % 32):
             return 0

@@ -705,6 +705,8 @@ def test_linear_pr_unet_shapes_repeatable(pair):
     _lpr_case(pair, M=40960, K=320, N=640, bias=False, seed=3)
     _lpr_case(pair, M=10240, K=640, N=5120, act=nt.ACT_GEGLU, seed=4, repeat=3)
     _lpr_case(pair, M=10240, K=640, N=1920, bias=False, seed=5, repeat=2)
+    _lpr_case(pair, M=40960, K=512, N=4096, act=nt.ACT_GEGLU, ln_in=True, seed=14, repeat=2)   # init_attn: K = 512 on 96-row panels
+    _lpr_case(pair, M=40960, K=512, N=1536, bias=False, ln_in=True, seed=15)
 
 
 def test_linear_pr_residual_and_few_chunks(pair):

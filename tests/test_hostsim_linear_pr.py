@@ -97,6 +97,19 @@ def test_k640_on_96_row_panels(sim):
     _case(sim, M=96, K=640, N=1024, act=nt.ACT_GEGLU, seed=6)
 
 
+def test_k512_on_96_row_panels(sim):
+    # K = 512 (32 steps: the four-slot weight ring): q | k | v and the GEGLU projection of the 8-head temporal transformer behind the entry
+    # conv, with and without LayerNorm in the fill; a residual is not taken at this width
+    _case(sim, M=96 * 2 + 40, K=512, N=1536, bias=False, seed=51)
+    _case(sim, M=200, K=512, N=1024, act=nt.ACT_GEGLU, ln_in=True, seed=52)
+    _case(sim, M=96, K=512, N=1536, bias=False, ln_in=True, ny=2, seed=53)
+    a, out = _rt(96, 512).bfloat16(), torch.empty(96, 512).bfloat16()
+    wp = nt.pack_linear_pr(_rt(512, 512).bfloat16())
+    for ops in (sim, EMU):
+        assert ops.linear_pr_supported(a, wp, out, M=96, N=512) == 1
+        assert ops.linear_pr_supported(a, wp, out, M=96, N=512, residual=out) == 0
+
+
 def test_column_splits_over_workgroup_rows(sim):
     # blockIdx.y: each workgroup row walks its own run of chunks with its own bias slice (also a ragged last run: 20 chunks in 3)
     _case(sim, M=170, K=320, N=1280, act=nt.ACT_GEGLU, ny=2, seed=7)
