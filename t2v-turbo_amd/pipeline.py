@@ -84,13 +84,16 @@ class T2VTurboVC2Pipeline:
         context["timestep_cond"] = guidance_embedding(w, embedding_dim=256).to(device).to(self.dtype)
         ms_t_threshold = self.scheduler.config.num_train_timesteps * (1 - percentage)
         denoised = latents
+        if use_motion_cond:
+            # the motion-guidance embedding takes two values over the whole trajectory (motion_gs above the threshold, 0 below:
+            # pipeline/t2v_turbo_vc2_pipeline.py:190-204): both are made ONCE and put on the device here — a host-to-device copy inside
+            # the loop is a host / stream synchronisation per step (1 ms of launch overhead per step no longer hidden under the GPU's work)
+            mg_on, mg_off = (guidance_embedding(torch.full((bs,), float(v)), embedding_dim=256, dtype=torch.float32).to(device).to(self.dtype)
+                             for v in (motion_gs, 0.0))
         for i, t in enumerate(timesteps):
             ts = torch.full((bs,), int(t), device=device, dtype=torch.long)
             if use_motion_cond:
-                mg = torch.tensor(motion_gs).repeat(bs)
-                if t < ms_t_threshold:
-                    mg = torch.zeros_like(mg)
-                context["motion_cond"] = guidance_embedding(mg, embedding_dim=256, dtype=torch.float32).to(device).to(self.dtype)
+                context["motion_cond"] = mg_off if t < ms_t_threshold else mg_on
             model_pred = self.unet(latents, ts, **context)
             latents, denoised = self.scheduler.step(model_pred, i, t, latents, generator=generator, return_dict=False)
         if output_type == "latent":
