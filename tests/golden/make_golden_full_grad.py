@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """Golden FULL fine-tuning gradients from THE REFERENCE ITSELF (CPU, build container only; needs /root/reference):
 
-    python tests/golden/make_golden_full_grad.py        -> tests/golden/unet_tiny_full_grad.npz
+    python tests/golden/make_golden_full_grad.py               -> tests/golden/unet_tiny_full_grad.npz   (model_channels 64)
+    python tests/golden/make_golden_full_grad.py --width 128   -> tests/golden/unet_mid_full_grad.npz    (model_channels 128: 128-512-channel
+                                                                  levels, 2 / 4 / 8 heads; digests only)
 
 The student's backward of train_latent_t2v_turbo_v2.py (:669 ``unet.requires_grad_(True)``, :798-816 every parameter in an optimizer
 group, :1262 backward) at tiny width: the reference ``UNetModel`` with every parameter trainable, ``eval()`` (the temporal-conv dropouts
@@ -38,6 +40,7 @@ def digests(grads):
 
 
 def main():
+    width = int(sys.argv[sys.argv.index("--width") + 1]) if "--width" in sys.argv else 64
     import make_golden as mg
     mg.install_stubs()
     sys.path.insert(0, mg.REF)
@@ -46,7 +49,7 @@ def main():
 
     z = np.load(os.path.join(HERE, "unet_tiny.npz"))
     x, ts, ctx, tc = (torch.from_numpy(z[k]) for k in ("x", "ts", "ctx", "tc"))
-    m = UNetModel(**mg.tiny_unet_params())
+    m = UNetModel(**mg.tiny_unet_params(model_channels=width))
     m.load_state_dict(synth_state_dict(manifest_of(m)), strict=True)
     m.requires_grad_(True)
     m.eval()
@@ -58,7 +61,9 @@ def main():
     assert all(p.grad is not None for _, p in named)
     full = {"g_" + n.replace(".", "__"): p.grad.numpy() for n, p in named if n in KEEP_FULL}
     assert len(full) == len(KEEP_FULL), sorted(set(KEEP_FULL) - {n for n, _ in named})
-    np.savez_compressed(os.path.join(HERE, "unet_tiny_full_grad.npz"), out=out.detach().numpy(), dx=xg.grad.numpy(), r_out=r_out.numpy(),
+    if width != 64:
+        full = {}          # (the second anchor keeps the digests only)
+    np.savez_compressed(os.path.join(HERE, "unet_tiny_full_grad.npz" if width == 64 else "unet_mid_full_grad.npz"), width=np.int64(width), out=out.detach().numpy(), dx=xg.grad.numpy(), r_out=r_out.numpy(),
                         digests=digests([p.grad for _, p in named]), names=np.asarray([n for n, _ in named]), **full)
     print(len(named), "parameters,", sum(p.numel() for _, p in named), "elements; full gradients kept for", len(full))
 

@@ -665,6 +665,27 @@ def test_full_fine_tuning_on_device_vs_the_reference_gradient_fixture():
     assert float(cos.min()) > 0.97 and float(cos.median()) > 0.995
 
 
+def test_full_fine_tuning_mid_width_on_device_vs_the_reference_gradient_fixture():
+    """The same against tests/golden/unet_mid_full_grad.npz (the reference run at model_channels = 128: 128-512-channel levels, 2 / 4 / 8
+    heads, 228 M parameters): a second reference-generated anchor for the base-weight gradients between the tiny fixture and the full width."""
+    import warnings
+    from oracle.synth import manifest_of, synth_state_dict
+    from t2v_turbo_amd.unet3d import UNetModel
+    from tests.golden.make_golden_full_grad import SEED_R
+    from tests.test_unet_full_grad_cpu import _fixture_step, check_against_reference_fixture
+    g, gg = load("unet_tiny"), load("unet_mid_full_grad")
+    m = UNetModel(**tiny_unet_params(model_channels=int(gg["width"])))
+    m.load_state_dict(synth_state_dict(manifest_of(m)), strict=True)
+    m = m.requires_grad_(True).eval().cuda()
+    names = [n for n, _ in m.named_parameters()]
+    r_out = torch.randn(g["x"].shape, generator=torch.Generator().manual_seed(SEED_R))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        y, dx, grads = _fixture_step(m, g["x"].cuda(), g["ts"].cuda(), g["ctx"].cuda(), g["tc"].cuda(), r_out.cuda(), "auto")
+    assert m._engine_box.full is not None
+    check_against_reference_fixture(y.cpu(), dx.cpu(), [t.cpu() for t in grads], names, gg, OUT_TOL, DX_TOL, 0.10, (0.30, 0.06), 0.12)
+
+
 def test_full_fine_tuning_train_mode_runs_with_live_temporal_dropouts():
     """The v2 student is in train mode (:669): the TemporalConvBlock dropouts are live (counter-based masks, the same sites as LoRA
     training) — the route stays native, outputs and gradients are finite, and two calls draw different masks."""
