@@ -53,7 +53,7 @@ def _report(tag, rows, cos_min, ratio_tol):
     cs = [r[1] for r in rows]
     rt = [abs(r[2] - 1.0) for r in rows]
     worst = sorted(rows, key=lambda r: r[1])[:5]
-    print(f"[{tag}] {len(rows)} LoRA tensors: cosine min {min(cs):.4f} median {statistics.median(cs):.5f}; "
+    print(f"[{tag}] {len(rows)} gradient tensors: cosine min {min(cs):.4f} median {statistics.median(cs):.5f}; "
           f"|norm ratio - 1| max {max(rt):.3f} median {statistics.median(rt):.4f}; worst: "
           + ", ".join(f"{n} cos {c:.4f} ratio {q:.3f}" for n, c, q, _ in worst), flush=True)
     bad = [r for r in rows if r[1] < cos_min or abs(r[2] - 1.0) > ratio_tol]
@@ -710,3 +710,64 @@ def test_full_fine_tuning_train_mode_runs_with_live_temporal_dropouts():
         assert torch.isfinite(y).all() and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
         outs.append(y.detach().float().cpu())
     assert m._engine_box.full is not None and rel_l2(outs[0], outs[1]) > 1e-4
+
+
+def test_full_fine_tuning_at_full_width_vs_cpu_autograd():
+    """Row a20 at the WIDTH the reference trains at: the VideoCrafter2 UNet (1 413 M parameters), every parameter trainable, eval mode, a
+    2-frame latent (1,4,2,40,64) — every level, width and leaf kind of the 16-frame step (320 / 640 / 1 280-channel convs with their
+    im2col matrices, the 2 560-channel concat GroupNorms, the 10 240-column GEGLU pre-activation, row-blocked weight-gradient products);
+    forward + backward through the module route on the device against fp32 CPU autograd through the same module (checkpointed, as the
+    LoRA gate's oracle): output, d/d(latents) and the gradient of EVERY parameter by cosine and norm.  T2V_TEST_TRAIN_PARITY_FRAMES
+    raises the frame count."""
+    import copy
+    import warnings
+    import bench
+    from t2v_turbo_amd.unet3d import UNetModel
+    frames = int(os.environ.get("T2V_TEST_TRAIN_PARITY_FRAMES", "2"))
+    t0 = time.time()
+    dev = torch.device("cuda", 0)
+    m = bench.build_model(dev, torch.float32)
+    m.requires_grad_(True)
+    m.eval()
+    gen = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, frames, 40, 64, generator=gen)
+    ctx = torch.randn(1, 77, bench.VC2_UNET["context_dim"], generator=gen)
+    _, _, tc = bench.synth_inputs(dev, torch.float32)
+    ts = torch.tensor([999])
+    r_out = torch.randn(x.shape, generator=gen)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")      # the torch-composite route warns: it must not be taken
+        xg = x.to(dev).requires_grad_(True)
+        y = m(xg, ts.to(dev), context=ctx.to(dev), fps=16, timestep_cond=tc)
+        (y * r_out.to(dev)).sum().backward()
+    assert m._engine_box.full is not None
+    torch.cuda.synchronize()
+    got = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
+    y_d, dx_d = y.detach().float().cpu(), xg.grad.detach().float().cpu()
+    print(f"device step done (+{time.time() - t0:.0f}s)", flush=True)
+    # fp32 CPU autograd through the same module, checkpointed
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    sd = {k: v.detach().to("cpu", torch.float32) for k, v in m.state_dict().items()}
+    with torch.device("meta"):
+        ref = UNetModel(**dict(bench.VC2_UNET, use_checkpoint=True))
+    ref = ref.to_empty(device="cpu")
+    ref.load_state_dict(sd, strict=True)
+    ref.requires_grad_(True)
+    ref.eval()
+    ref.native_mode = "off"
+    xr = x.clone().requires_grad_(True)
+    y_r = ref(xr, ts, context=ctx, fps=16, timestep_cond=tc.detach().float().cpu())
+    (y_r * r_out).sum().backward()
+    print(f"host reference done (+{time.time() - t0:.0f}s)", flush=True)
+    e_out, e_dx = rel_l2(y_d, y_r.detach()), rel_l2(dx_d, xr.grad)
+    rows = []
+    for n, p in ref.named_parameters():
+        r, g = p.grad, got[n]
+        rn = float(r.double().norm())
+        if rn == 0.0:
+            assert float(g.abs().max()) < 1e-6, n
+            continue
+        rows.append((n, _cos(g, r), float(g.double().norm()) / rn, rn))
+    print(f"[full fine-tuning, full width, {frames} frames] out rel-L2 {e_out:.3e}  d/d(latents) rel-L2 {e_dx:.3e}", flush=True)
+    _report("full fine-tuning, full width", rows, 0.98, 0.12)
+    assert e_out < OUT_TOL and e_dx < DX_TOL
