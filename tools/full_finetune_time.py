@@ -26,12 +26,15 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--train", type=int, default=1, help="train mode (the TemporalConvBlock dropouts live), as the v2 script runs its student")
+    ap.add_argument("--native", type=int, default=1, help="0: the torch composite path over ATen kernels (native_mode = 'off'), for comparison")
     args = ap.parse_args()
     import bench
     dev = torch.device("cuda", 0)
     m = bench.build_model(dev, torch.float32)
     m.requires_grad_(True)
     m.train() if args.train else m.eval()
+    if not args.native:
+        m.native_mode = "off"
     x, ctx, tc = bench.synth_inputs(dev, torch.float32)
     x = x[:, :, :args.frames].contiguous()
     ts = torch.tensor([999], device=dev)
@@ -45,7 +48,8 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with warnings.catch_warnings():
-            warnings.simplefilter("error")    # the torch-composite route warns: it must not be taken
+            if args.native:
+                warnings.simplefilter("error")    # the torch-composite route warns: it must not be taken
             y = m(x, ts, context=ctx, fps=16, timestep_cond=tc)
         loss = y.float().pow(2).mean()
         loss.backward()
@@ -60,11 +64,13 @@ def main():
             out["all_grads_present"] = all(p.grad is not None for p in params)
             out["all_grads_finite"] = all(bool(torch.isfinite(p.grad).all()) for p in params)
             out["grad_norm"] = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)))
-    eng = m._engine_box.full
-    plan = next(iter(eng.plans.values()))
-    out.update(record_ms=round(times[0], 1), step_ms=[round(t, 1) for t in times[1:]], loss=float(loss),
-               launches={"forward": len(plan["rec"]), "backward": len(plan["rec_bwd"])}, plans=len(eng.plans),
-               peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), pool_gb=round(plan["pool_bytes"] / 2 ** 30, 1))
+    out.update(path="native gradient engine" if args.native else "torch composite (ATen kernels)", record_ms=round(times[0], 1),
+               step_ms=[round(t, 1) for t in times[1:]], loss=float(loss.detach()), peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
+    if args.native:
+        eng = m._engine_box.full
+        plan = next(iter(eng.plans.values()))
+        out.update(launches={"forward": len(plan["rec"]), "backward": len(plan["rec_bwd"])}, plans=len(eng.plans),
+                   pool_gb=round(plan["pool_bytes"] / 2 ** 30, 1))
     print(json.dumps(out))
 
 
