@@ -363,6 +363,48 @@ def distill_parity(student, params, sync, make_ops, cfg, dev, frames=4):
         student.train(was_training)
 
 
+def full_finetune_leg(dev, steps=3):
+    """The FULL fine-tuning student (train_latent_t2v_turbo_v2.py:669,798-816,1262: every UNet parameter trainable, no LoRA) at full width on
+    the bench latent, train mode: `unet(...)` + `loss.backward()` through the module route on the native gradient engine (engine_full.py),
+    an SGD-style update of every weight between steps so that the in-place pack refresh is inside the timed region.  Correctness of this
+    path: tests/test_gpu_train_parity.py::test_full_fine_tuning_* (the reference's own gradients at two widths; fp32 CPU autograd at
+    full width).  Correctness-first implementation (materialised im2col, one launch chain per leaf): a reported number, not a tuned one."""
+    import warnings
+    m = build_model(dev, torch.float32)
+    m.requires_grad_(True)
+    m.train()
+    x, ctx, tc = synth_inputs(dev, torch.float32)
+    ts = torch.tensor([999], device=dev)
+    params = list(m.parameters())
+    times = []
+    torch.cuda.reset_peak_memory_stats()
+    for step in range(steps + 1):   # step 0 records the two launch lists
+        for p_ in params:
+            p_.grad = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")    # the torch-composite route warns: it must not be taken
+            y = m(x, ts, context=ctx, fps=16, timestep_cond=tc)
+        y.float().pow(2).mean().backward()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+        with torch.no_grad():
+            for p_ in params:
+                p_.add_(p_.grad, alpha=-1e-6)
+    eng = m._engine_box.full
+    plan = next(iter(eng.plans.values()))
+    finite = all(p_.grad is not None and bool(torch.isfinite(p_.grad).all()) for p_ in params)
+    out = {"ms_per_step": round(min(times[1:]), 1), "ms_all": [round(t, 1) for t in times[1:]], "record_ms": round(times[0], 1),
+           "params_m": round(sum(p_.numel() for p_ in params) / 1e6, 1), "all_grads_finite": finite,
+           "launches": {"forward": len(plan["rec"]), "backward": len(plan["rec_bwd"])}, "plans": len(eng.plans),
+           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+           "what": "forward + backward of every UNet parameter (no LoRA), train mode, latent (1,4,16,40,64), weights updated between steps"}
+    del m, params, eng, plan
+    torch.cuda.empty_cache()
+    return out
+
+
 def distill_step_leg(teacher, dev, world=1, dry=False, parity=True):
     """BASELINE config C3: the v1 consistency-distillation step (train_t2v_turbo_v1_lora.py:978-1196) at full size, per-rank
     B=1 — LoRA r=64 student (fp32 master weights, train mode, bf16 engine) forward + target forward + backward on the native
@@ -551,6 +593,7 @@ def main():
     ap.add_argument("--breakdown", type=int, default=1)
     ap.add_argument("--distill", type=int, default=1, help="also time the v1 distillation step (config C3; on every rank at N > 1)")
     ap.add_argument("--distill-parity", type=int, default=1, help="gate the distillation leg on its gradient parity check (N = 1)")
+    ap.add_argument("--full-finetune", type=int, default=1, help="also time the full fine-tuning student step (v2 script's call pattern; rank 0, N = 1)")
     ap.add_argument("--dry-run-cpu", type=int, default=0, help="plumbing check on CPU: tiny widths, gloo, emulated kernels (not a measurement)")
     args = ap.parse_args()
 
@@ -721,6 +764,13 @@ def main():
         if rank == 0:
             result["distill_step"] = d
             log(f"distill leg: {d}")
+    if args.full_finetune and rank == 0 and world == 1 and not dry:
+        try:
+            with Watchdog(240, "full fine-tuning leg"):
+                result["full_finetune_step"] = full_finetune_leg(dev)
+        except Exception as e:  # noqa: BLE001 - optional leg, reported not fatal
+            result["full_finetune_step"] = {"error": repr(e)}
+        log(f"full fine-tuning leg: {result['full_finetune_step']}")
     rc = 0
     if rank == 0:
         print(json.dumps(result), flush=True)
