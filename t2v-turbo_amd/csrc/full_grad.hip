@@ -165,17 +165,36 @@ __global__ __launch_bounds__(256) void affine_grad_partial_kernel(const bf16_t* 
     for (int i = threadIdx.x; i < 2 * C; i += 256) dst[i] = ((red[i] + red[2 * C + i]) + red[4 * C + i]) + red[6 * C + i];
 }
 
-// out[u][c] = sum over the unit's blocks, in block order
-__global__ __launch_bounds__(256) void affine_grad_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dgamma,
-                                                                int ld_g, float* __restrict__ dbeta, int ld_b) {
-    const int u = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 2 * C) return;
-    const float* src = partial + (long long)u * nblk * 2 * C + i;
+// out[u][i] = sum over the unit's blocks.  Block (x, u) owns 64 consecutive values i (coalesced rows of the partial array); its 16
+// waves take the blocks b = wave, wave + 16, ... (four loads in flight per trip), meet in LDS and are added in wave order: a fixed
+// summation tree, deterministic.  (The first form walked all blocks with ONE thread per value: 116 us per call on ~1 000 blocks — a
+// third of the full fine-tuning step, profiles/r06_full_finetune_kernel_stats.csv.)
+constexpr int AGF_WAVES = 16;
+__global__ __launch_bounds__(AGF_WAVES * 64) void affine_grad_final_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ dgamma,
+                                                                           int ld_g, float* __restrict__ dbeta, int ld_b) {
+    __shared__ float red[AGF_WAVES][64];
+    const int u = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    const bool ok = i < 2 * C;
+    const float* src = partial + (long long)u * nblk * 2 * C + (ok ? i : 0);
+    const long long stride = 2LL * C;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += src[(long long)b * 2 * C];
-    if (i < C) { if (dgamma) dgamma[(long long)u * ld_g + i] = s; }
-    else if (dbeta) dbeta[(long long)u * ld_b + (i - C)] = s;
+    int b = wave;
+    for (; b + 3 * AGF_WAVES < nblk; b += 4 * AGF_WAVES) {
+        const float v0 = src[(long long)b * stride], v1 = src[(long long)(b + AGF_WAVES) * stride];
+        const float v2 = src[(long long)(b + 2 * AGF_WAVES) * stride], v3 = src[(long long)(b + 3 * AGF_WAVES) * stride];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; b < nblk; b += AGF_WAVES) s += src[(long long)b * stride];
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && ok) {
+        float t = red[0][lane];
+#pragma unroll
+        for (int w = 1; w < AGF_WAVES; ++w) t += red[w][lane];
+        if (i < C) { if (dgamma) dgamma[(long long)u * ld_g + i] = t; }
+        else if (dbeta) dbeta[(long long)u * ld_b + (i - C)] = t;
+    }
 }
 
 }  // namespace
@@ -279,8 +298,8 @@ extern "C" int t2v_norm_affine_grad(const void* x0, int c0, int ld0, const void*
     else T2V_AG_LAUNCH(2);
 #undef T2V_AG_LAUNCH
     T2V_CHECK_LAUNCH();
-    hipLaunchKernelGGL(affine_grad_final_kernel, dim3((2 * C + 255) / 256, (unsigned)n_out), dim3(256), 0, s, (const float*)ws, nblk, C, dgamma,
-                       ld_dgamma, dbeta, ld_dbeta);
+    hipLaunchKernelGGL(affine_grad_final_kernel, dim3((2 * C + 63) / 64, (unsigned)n_out), dim3(AGF_WAVES * 64), 0, s, (const float*)ws, nblk, C,
+                       dgamma, ld_dgamma, dbeta, ld_dbeta);
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }
