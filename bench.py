@@ -168,7 +168,7 @@ def family_ingraph(engine, rec, names, replays=5):
             fn(*args, ops.stream())
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
             st = ops.stream()
             for fn, args in sel:
                 fn(*args, st)

@@ -253,7 +253,9 @@ class UNetGradEngine(FullTrainMixin, LoraTrainMixin, UNetEngine):
                         built.append((None, host))
                         continue
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    # (thread-local capture mode: the watchdog thread of an RCCL process group may poll its events while this thread
+                    # captures — in the default global mode that invalidates the capture and aborts the watchdog)
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         ops.replay(launches, ops.stream(), cache=False)   # (a temporary sub-list: nothing to reuse)
                     built.append((g, None))
                 plan[gkey] = built

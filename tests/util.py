@@ -66,6 +66,12 @@ def run_isolated(module, func, timeout=900):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = f"import sys; sys.path.insert(0, {root!r}); import {module} as m; m.{func}()"
     p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=timeout)
+    if p.returncode < 0 and "BODY_OK" not in (p.stdout or ""):
+        # killed by a signal before the marker: an abort inside the runtime (round 6: RCCL's watchdog thread faulting on a HIP call
+        # while the engine captured a hipGraph in global capture mode, once in five suite runs — the engines capture in thread-local
+        # mode since).  ONE more attempt; an assertion or exception in the body (rc 1) is never retried.
+        print(f"{module}.{func}: child died with signal {-p.returncode} before BODY_OK, running it once more:\n{(p.stderr or '')[-1500:]}", flush=True)
+        p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=timeout)
     out = (p.stdout or "") + (p.stderr or "")
     print(out[-3000:], flush=True)
     if "BODY_OK" not in (p.stdout or ""):
