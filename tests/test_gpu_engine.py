@@ -332,7 +332,7 @@ def test_unet_full_width_c1_geometry_off_the_tuned_table():
     assert err_n < E2E_TOL and err_h < E2E_TOL, (err_n, err_h)
     # a fifth of the tokens per launch: the small geometry runs at a lower rate even on good tiles (fewer tiles than CUs at the lower
     # levels); the bounds only catch a tile choice that falls off a cliff, and a fallback that is worse than no fallback
-    assert tf8n > 0.25 * tf16 and ms8n < 1.05 * ms8h, (tf8n, tf16, ms8n, ms8h)
+    assert tf8n > 0.25 * tf16 and ms8n < 1.10 * ms8h, (tf8n, tf16, ms8n, ms8h)   # (measured: 4-5 % FASTER; 10 % of slack for a noisy box)
 
 
 def test_unet_full_width_motion_cond_config_c4_vs_oracle():
