@@ -458,8 +458,11 @@ int t2v_attn_spatial_bwd(const void* q, int ldq, const void* k, int ldk, const v
                          void* stream);
 /* t2v_wgrad_tn: out[R][C] (fp32, row stride ldo) = alpha * a[:, :R]^T b[:, :C] for two TOKEN-MAJOR bf16 operands a [M][lda],
  * b [M][ldb] — the token-contracted LoRA weight gradients (dU = s dy^T t, dD = G^T x) and per-clip column sums without transposed
- * operand copies.  The token range is split over workgroups (splits = 0: library choice); fp32 partial tiles go through the
- * caller's workspace ws (>= splits*R*C*4 bytes, the split count shrinks to fit) and are added in a fixed order. */
+ * operand copies, and the base-weight gradients of full fine-tuning (dW = dy^T x, dy^T xcol).  The token range is split over
+ * workgroups (splits = 0: library choice); fp32 partial tiles go through the caller's workspace ws (>= splits*R*C*4 bytes, the split
+ * count shrinks to fit) and are added in a fixed order.  With ONE split — a product with enough output tiles to fill the chip, or an
+ * output larger than the workspace — the tiles are written to `out` directly and ws is not touched.  Output tile 64 x 64, or
+ * 128 x 128 where both extents reach 128 and pad to multiples of 128 within 10 % (T2V_WGRAD_TILE128=0: always 64 x 64). */
 int t2v_wgrad_tn(const void* a, int lda, const void* b, int ldb, long long M, int R, int C, float alpha, float* out, int ldo, float* ws,
                  long long ws_bytes, int splits, void* stream);
 /* t2v_wgrad_tn_group: up to T2V_WGRAD_GROUP_MAX such products in one launch pair (main + fixed-order reduce): the weight gradients

@@ -64,7 +64,11 @@ __global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* __restrict__ 
 // statistics are two butterflies.  Block (bx, u) walks rows [bx * rows_per_blk, ...) of output row u; its four waves' register sums meet
 // in LDS in wave order; partial[(u * nblk + bx)][2][C].
 constexpr int AG_MAXJ = 5;   // C <= 64 * 8 * 5 = 2560 per launch (the widest GroupNorm: a 1280 + 1280 concat); plain column sums go out in column chunks
-template <int KIND>   // 0: GroupNorm statistics given, 1: LayerNorm (row statistics recomputed), 2: column sums of dy only
+// NJ = chunks per lane (1, 2, 3, 5 by width), UR = rows a wave has in flight per trip (4 / 2 / 1): the first form (NJ = 5 for every width, one
+// row per trip, the GroupNorm group of every element by an integer division per row) kept ~ 200 registers and 1.3 KB per wave in flight and
+// ran at ~ 1 TB/s (profiles/r06_full_finetune_kernel_stats.csv: 55 us per GroupNorm launch).  Rows are still taken in the order
+// r, r + 4, r + 8, ... per wave: the sums are bit-identical to the first form's.
+template <int KIND, int NJ, int UR>   // KIND 0: GroupNorm statistics given, 1: LayerNorm (row statistics recomputed), 2: column sums of dy only
 __global__ __launch_bounds__(256) void affine_grad_partial_kernel(const bf16_t* __restrict__ x0, int c0, int ld0, const bf16_t* __restrict__ x1,
                                                                   int c1, int ld1, long long sum_rows, int rows_per_blk, int rows_per_unit,
                                                                   int groups, const float* __restrict__ stats, float ln_eps,
@@ -75,74 +79,101 @@ __global__ __launch_bounds__(256) void affine_grad_partial_kernel(const bf16_t* 
     const int u = blockIdx.y, bx = blockIdx.x, nblk = gridDim.x;
     const long long r_begin = (long long)u * sum_rows + (long long)bx * rows_per_blk;
     const long long r_end = min((long long)(u + 1) * sum_rows, r_begin + rows_per_blk);
-    float ag[AG_MAXJ][8], ab[AG_MAXJ][8];
+    float ag[NJ][8], ab[NJ][8];
 #pragma unroll
-    for (int j = 0; j < AG_MAXJ; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; }
     const int cpg = KIND == 0 ? C / groups : 1;
     const float inv_c = 1.0f / (float)C;
-    for (long long r = r_begin + wave; r < r_end; r += 4) {
-        float xv[AG_MAXJ][8], dv[AG_MAXJ][8];
+    // GroupNorm: with >= 8 channels per group a chunk lies in at most two groups — the first one and where the second begins, once per lane
+    const bool two_groups = KIND == 0 && cpg >= 8;
+    int glo[NJ], eb[NJ];
 #pragma unroll
-        for (int j = 0; j < AG_MAXJ; ++j) {
-            const int ci = lane + 64 * j;
-            if (ci < cpr) {
-                unpack8(*(const uint4*)(dy + r * ldy + ci * 8), dv[j]);
-                if (KIND != 2) {
-                    const int c = ci * 8;
-                    unpack8(c < c0 ? *(const uint4*)(x0 + r * ld0 + c) : *(const uint4*)(x1 + r * ld1 + (c - c0)), xv[j]);
+    for (int j = 0; j < NJ; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        glo[j] = KIND == 0 ? c / cpg : 0;
+        eb[j] = KIND == 0 ? (glo[j] + 1) * cpg - c : 8;   // elements e >= eb are in group glo + 1
+    }
+    for (long long r0 = r_begin + wave; r0 < r_end; r0 += 4 * UR) {
+        uint4 xr[UR][NJ], dr[UR][NJ];
+#pragma unroll
+        for (int k = 0; k < UR; ++k) {
+            const long long r = r0 + 4 * k;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int ci = lane + 64 * j;
+                xr[k][j] = make_uint4(0u, 0u, 0u, 0u); dr[k][j] = make_uint4(0u, 0u, 0u, 0u);
+                if (r < r_end && ci < cpr) {
+                    dr[k][j] = *(const uint4*)(dy + r * ldy + ci * 8);
+                    if (KIND != 2) {
+                        const int c = ci * 8;
+                        xr[k][j] = c < c0 ? *(const uint4*)(x0 + r * ld0 + c) : *(const uint4*)(x1 + r * ld1 + (c - c0));
+                    }
                 }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { dv[j][e] = 0.f; xv[j][e] = 0.f; }
             }
         }
-        float mean = 0.f, rstd = 1.f;
-        if (KIND == 1) {
-            float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < AG_MAXJ; ++j)
+        for (int k = 0; k < UR; ++k) {
+            const long long r = r0 + 4 * k;
+            if (r >= r_end) break;
+            float xv[NJ][8], dv[NJ][8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) s += xv[j][e];
-            mean = wave_sum(s) * inv_c;
-            float q = 0.f;
+            for (int j = 0; j < NJ; ++j) { unpack8(dr[k][j], dv[j]); unpack8(xr[k][j], xv[j]); }
+            float mean = 0.f, rstd = 1.f;
+            if (KIND == 1) {
+                float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < AG_MAXJ; ++j)
-                if (lane + 64 * j < cpr) {
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float dlt = xv[j][e] - mean; q += dlt * dlt; }
-                }
-            rstd = rsqrtf(wave_sum(q) * inv_c + ln_eps);
-        }
-        const long long unit = KIND == 0 ? r / rows_per_unit : 0;
+                    for (int e = 0; e < 8; ++e) s += xv[j][e];
+                mean = wave_sum(s) * inv_c;
+                float q = 0.f;
 #pragma unroll
-        for (int j = 0; j < AG_MAXJ; ++j) {
-            const int ci = lane + 64 * j;
-            if (ci < cpr) {
-                float gm[8], bt[8];   // (re-read per row from L1: kept in registers beside the sums they would not fit at 2560 channels)
-                if (KIND != 2 && silu) {
-                    const float4 g0 = *(const float4*)(gamma + ci * 8), g1 = *(const float4*)(gamma + ci * 8 + 4);
-                    const float4 b0 = *(const float4*)(beta + ci * 8), b1 = *(const float4*)(beta + ci * 8 + 4);
-                    gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
-                    bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1.x; bt[5] = b1.y; bt[6] = b1.z; bt[7] = b1.w;
-                }
+                for (int j = 0; j < NJ; ++j)
+                    if (lane + 64 * j < cpr) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    float xh = 0.f, dz = dv[j][e];
-                    if (KIND == 0) {
-                        const float* st = stats + (unit * groups + (ci * 8 + e) / cpg) * 2;
-                        xh = (xv[j][e] - st[0]) * st[1];
-                    } else if (KIND == 1) {
-                        xh = (xv[j][e] - mean) * rstd;
+                        for (int e = 0; e < 8; ++e) { const float dlt = xv[j][e] - mean; q += dlt * dlt; }
                     }
-                    if (KIND != 2 && silu) {   // y = silu(z), z = xhat gamma + beta: dz = dy * sigma(z) (1 + z (1 - sigma(z)))
-                        const float z = xh * gm[e] + bt[e];
-                        const float sg = 1.0f / (1.0f + __expf(-z));
-                        dz *= sg * (1.0f + z * (1.0f - sg));
+                rstd = rsqrtf(wave_sum(q) * inv_c + ln_eps);
+            }
+            const long long unit = KIND == 0 ? r / rows_per_unit : 0;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int ci = lane + 64 * j;
+                if (ci < cpr) {
+                    float gm[8], bt[8];   // (re-read per row from L1: kept in registers beside the sums they would not fit at 2560 channels)
+                    if (KIND != 2 && silu) {
+                        const float4 g0 = *(const float4*)(gamma + ci * 8), g1 = *(const float4*)(gamma + ci * 8 + 4);
+                        const float4 b0 = *(const float4*)(beta + ci * 8), b1 = *(const float4*)(beta + ci * 8 + 4);
+                        gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w; gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
+                        bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w; bt[4] = b1.x; bt[5] = b1.y; bt[6] = b1.z; bt[7] = b1.w;
                     }
-                    ag[j][e] += dz * xh;
-                    ab[j][e] += dz;
+                    float2 s_lo = make_float2(0.f, 1.f), s_hi = s_lo;
+                    if (two_groups) {
+                        const float* st = stats + (unit * groups + glo[j]) * 2;
+                        s_lo = *(const float2*)st;
+                        if (eb[j] < 8) s_hi = *(const float2*)(st + 2);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float xh = 0.f, dz = dv[j][e];
+                        if (KIND == 0) {
+                            float2 st2;
+                            if (two_groups) st2 = e < eb[j] ? s_lo : s_hi;
+                            else st2 = *(const float2*)(stats + (unit * groups + (ci * 8 + e) / cpg) * 2);
+                            xh = (xv[j][e] - st2.x) * st2.y;
+                        } else if (KIND == 1) {
+                            xh = (xv[j][e] - mean) * rstd;
+                        }
+                        if (KIND != 2 && silu) {   // y = silu(z), z = xhat gamma + beta: dz = dy * sigma(z) (1 + z (1 - sigma(z)))
+                            const float z = xh * gm[e] + bt[e];
+                            const float sg = 1.0f / (1.0f + __expf(-z));
+                            dz *= sg * (1.0f + z * (1.0f - sg));
+                        }
+                        ag[j][e] += dz * xh;
+                        ab[j][e] += dz;
+                    }
                 }
             }
         }
@@ -150,7 +181,7 @@ __global__ __launch_bounds__(256) void affine_grad_partial_kernel(const bf16_t* 
     // the four waves' sums, added in wave order
     extern __shared__ float red[];   // [4][2][C]
 #pragma unroll
-    for (int j = 0; j < AG_MAXJ; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int ci = lane + 64 * j;
         if (ci < cpr) {
 #pragma unroll
@@ -286,16 +317,24 @@ extern "C" int t2v_norm_affine_grad(const void* x0, int c0, int ld0, const void*
     hipStream_t s = (hipStream_t)stream;
     const size_t smem = (size_t)8 * C * sizeof(float);
     dim3 grid(nblk, (unsigned)n_out);
-#define T2V_AG_LAUNCH(K)                                                                                                                      \
+#define T2V_AG_LAUNCH(K, NJ, UR)                                                                                                              \
     do {                                                                                                                                      \
         static bool attr_set = false;   /* (8 C floats of LDS: 80 KB at 2560 channels, above the 64 KB a launch gets unasked) */             \
-        if (!attr_set) { hipFuncSetAttribute((const void*)affine_grad_partial_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
-        hipLaunchKernelGGL(affine_grad_partial_kernel<K>, grid, dim3(256), smem, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, sum_rows, \
+        if (!attr_set) { hipFuncSetAttribute((const void*)affine_grad_partial_kernel<K, NJ, UR>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr_set = true; } \
+        hipLaunchKernelGGL((affine_grad_partial_kernel<K, NJ, UR>), grid, dim3(256), smem, s, (const bf16_t*)x0, c0, ld0, (const bf16_t*)x1, c1, ld1, sum_rows, \
                            rows_per_blk, rows_per_unit, groups, stats, ln_eps, gamma, beta, silu, (const bf16_t*)dy, ldy, ws);               \
     } while (0)
-    if (kind == 0) T2V_AG_LAUNCH(0);
-    else if (kind == 1) T2V_AG_LAUNCH(1);
-    else T2V_AG_LAUNCH(2);
+#define T2V_AG_BY_WIDTH(K)                                                                                                                    \
+    do {                                                                                                                                      \
+        if (C <= 512) T2V_AG_LAUNCH(K, 1, 4);                                                                                                 \
+        else if (C <= 1024) T2V_AG_LAUNCH(K, 2, 2);                                                                                           \
+        else if (C <= 1536) T2V_AG_LAUNCH(K, 3, 1);                                                                                           \
+        else T2V_AG_LAUNCH(K, 5, 1);                                                                                                          \
+    } while (0)
+    if (kind == 0) T2V_AG_BY_WIDTH(0);
+    else if (kind == 1) T2V_AG_BY_WIDTH(1);
+    else T2V_AG_BY_WIDTH(2);
+#undef T2V_AG_BY_WIDTH
 #undef T2V_AG_LAUNCH
     T2V_CHECK_LAUNCH();
     hipLaunchKernelGGL(affine_grad_final_kernel, dim3((2 * C + 63) / 64, (unsigned)n_out), dim3(AGF_WAVES * 64), 0, s, (const float*)ws, nblk, C,

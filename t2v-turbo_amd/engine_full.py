@@ -102,26 +102,30 @@ class FullTrainMixin:
         return x, info
 
     def fgrad(self, p):
-        """The fp32 gradient tensor of parameter ``p`` (allocated once per plan: recorded launches point at it)."""
+        """The fp32 gradient tensor of parameter ``p``: a view into the plan's gradient arena (one allocation for all parameters, made at the
+        first request: recorded launches point into it, and the hand-over to torch is ONE copy of the arena instead of one per tensor)."""
         g = self.plan["fgrads"].get(id(p))
         if g is None:
             assert id(p) in self.full_ids, "a leaf parameter that was not given to bind_full"
-            g = self.plan["fgrads"][id(p)] = torch.zeros(p.shape, dtype=torch.float32, device=self.device)
+            if self.plan.get("fgrad_arena") is None:
+                off, offs = 0, {}
+                for q in self.full_params:
+                    offs[id(q)] = off
+                    off += (q.numel() + 63) // 64 * 64        # (256-byte aligned views)
+                self.plan["fgrad_off"] = offs
+                self.plan["fgrad_arena"] = torch.zeros(off, dtype=torch.float32, device=self.device)
+            o = self.plan["fgrad_off"][id(p)]
+            g = self.plan["fgrads"][id(p)] = self.plan["fgrad_arena"][o:o + p.numel()].view(p.shape)
         return g
 
     def _idx(self, key, make):
         return self.pk._memo(("full_idx",) + key, lambda: make().to(torch.int32).to(self.device).contiguous())
 
     def full_wgrad(self, dy, xmat, out):
-        """out[R, C] = dy^T xmat by t2v_wgrad_tn, in row blocks of the output where one product's partial slabs would not fit the
-        split-K workspace (the widest leaf: 1 280 x 23 040 fp32 = 118 MB for the 2 560-channel 3x3 convs of the decoder half)."""
-        ops = self.ops
-        R_, C_ = out.shape
-        ws_bytes = getattr(ops, "SPLITK_WS_BYTES", 96 << 20)
-        max_rows = max(64, (ws_bytes // 4) // (4 * C_) // 64 * 64)      # at least four token splits per block
-        for r0 in range(0, R_, max_rows):
-            r1 = min(R_, r0 + max_rows)
-            ops.wgrad_tn(dy[:, r0:r1], xmat, out[r0:r1])
+        """out[R, C] = dy^T xmat by t2v_wgrad_tn (one launch pair, or one launch where the product has enough output tiles to fill the
+        chip without splitting the token range — then it needs no partial slabs, however large the output: 1 280 x 23 040 fp32 = 118 MB
+        for the 2 560-channel 3x3 convs of the decoder half)."""
+        self.ops.wgrad_tn(dy, xmat, out)
 
     def full_colsum(self, dy, dst, sum_rows):
         """dst[u][c] = sum of ``sum_rows`` consecutive rows of dy (fp32 [rows / sum_rows, C], a column slice of a wider buffer allowed)."""
@@ -215,9 +219,17 @@ class FullTrainMixin:
         self.pool.put(ws)
 
     def full_grads(self, params):
-        """Gradients of ``params`` after ``backward`` (copies: the engine's buffers are overwritten by the next step)."""
+        """Gradients of ``params`` after ``backward``: views into ONE copy of the gradient arena (the engine's own buffers are overwritten by
+        the next step; the copy lives as long as any of the returned tensors)."""
+        plan = self._last
+        if plan.get("fgrad_arena") is None:
+            return [None for _ in params]
+        flat = plan["fgrad_arena"].clone()
         out = []
         for p in params:
-            g = self._last["fgrads"].get(id(p))
-            out.append(None if g is None else g.clone())
+            if id(p) in plan["fgrads"]:
+                o = plan["fgrad_off"][id(p)]
+                out.append(flat[o:o + p.numel()].view(p.shape))
+            else:
+                out.append(None)
         return out

@@ -292,7 +292,9 @@ def test_attn_spatial_bwd_flash(ops, n_img, seq, heads):
 
 @pytest.mark.parametrize("M,R,C,lda,ldb,splits", [(200, 64, 64, 64, 64, 0), (40960, 320, 64, 384, 192, 0), (130, 4, 64, 64, 64, 3),
                                                   (10240, 576, 640, 576, 640, 0), (40960, 1, 320, 8, 320, 0),
-                                                  (40960, 64, 320, 64, 320, 0), (10240, 192, 640, 192, 640, 0), (2560, 2560, 64, 2560, 64, 0)])
+                                                  (40960, 64, 320, 64, 320, 0), (10240, 192, 640, 192, 640, 0), (2560, 2560, 64, 2560, 64, 0),
+                                                  # R, C >= 128: the 128 x 128 tile (full fine-tuning's base-weight gradients)
+                                                  (300, 250, 380, 256, 384, 2), (2560, 1280, 2880, 1280, 2880, 0), (40960, 320, 960, 320, 960, 0), (640, 1280, 3840, 1280, 3840, 0)])
 def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
     """Token-contracted weight gradient (csrc/wgrad_tn.hip) against the emulated definition."""
     hip, emu = ops
@@ -303,6 +305,24 @@ def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
     hip.wgrad_tn(_dev(a)[:, :R], _dev(b)[:, :C], o_h[:, :C], alpha=0.5, splits=splits)
     torch.cuda.synchronize()
     assert rel_l2(o_h[:, :C].cpu(), o_e) < 2e-4 and float(o_h[:, C:].min()) == 7.0
+
+
+@pytest.mark.parametrize("M,R,C,splits", [(2560, 1280, 1280, 0), (2560, 1280, 5760, 0), (2560, 1280, 11520, 0), (10240, 640, 1920, 5),
+                                          (40960, 320, 2880, 0)])
+def test_wgrad_tn_large_outputs(ops, M, R, C, splits):
+    """Full fine-tuning's base-weight products: 128 x 128 tiles where the extents pad to them within 10 %, the four-outputs-per-thread
+    reduction (bit-identical to the 64-per-block one an unaligned output takes), no reduction at one token split — against fp32 torch."""
+    hip, _ = ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    a = (torch.randn(M, R, device="cuda", generator=g) * 0.3).bfloat16()
+    b = (torch.randn(M, C, device="cuda", generator=g) * 0.3).bfloat16()
+    o_4, o_1 = torch.full((R, C + 4), 7.0, device="cuda"), torch.full((R, C + 3), 7.0, device="cuda")
+    hip.wgrad_tn(a, b, o_4[:, :C], alpha=0.5, splits=splits)
+    hip.wgrad_tn(a, b, o_1[:, :C], alpha=0.5, splits=splits)
+    ref = 0.5 * (a.float().t() @ b.float())
+    torch.cuda.synchronize()
+    assert torch.equal(o_4[:, :C], o_1[:, :C]) and float(o_4[:, C:].min()) == 7.0 and float(o_1[:, C:].min()) == 7.0
+    assert rel_l2(o_4[:, :C].cpu(), ref.cpu()) < 2e-4
 
 
 @pytest.mark.parametrize("M,N,n,cin", [(40960, 320, 3, 320), (2560, 1280, 1, 1280), (10240, 640, 2, 640), (308, 64, 3, 72)])

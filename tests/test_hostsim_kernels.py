@@ -295,7 +295,8 @@ def test_transpose_pad(ops, rows, cols, batch, ld_in):
 
 @pytest.mark.parametrize("M,R,C,lda,ldb,splits", [(200, 64, 64, 64, 64, 0), (1000, 320, 64, 384, 192, 0), (130, 4, 64, 64, 64, 3),
                                                   (77, 576, 200, 576, 200, 0), (640, 1, 320, 8, 320, 4), (64, 100, 36, 104, 40, 1),
-                                                  (300, 64, 320, 64, 320, 0), (500, 192, 320, 192, 320, 0)])   # (the 64 x 256 and 128 x 128 tile shapes)
+                                                  (300, 64, 320, 64, 320, 0), (500, 192, 320, 192, 320, 0),   # (R, C >= 128: the 128 x 128 tile)
+                                                  (300, 250, 380, 256, 384, 2), (129, 256, 384, 256, 392, 3)])   # (ragged last chunks / forced splits on the 128 x 128 tile)
 def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
     """Token-contracted weight gradient out = alpha a^T b on token-major operands (column slices, ragged R / C / M, forced and
     automatic token splits): fp32 result against the emulated definition."""
@@ -307,6 +308,22 @@ def test_wgrad_tn(ops, M, R, C, lda, ldb, splits):
     sim.wgrad_tn(_bf(a)[:, :R], _bf(b)[:, :C], o_s[:, :C], alpha=0.5, splits=splits)
     assert rel_l2(o_s[:, :C], o_e) < 1e-5 and float(o_s[:, C:].min()) == 7.0
 
+
+
+@pytest.mark.parametrize("M,R,C,splits", [(300, 256, 384, 3), (1100, 320, 256, 0), (200, 256, 256, 1), (700, 192, 344, 18)])
+def test_wgrad_tn_large_outputs(ops, M, R, C, splits):
+    """Outputs of >= 65 536 values with 16-byte aligned rows take the four-outputs-per-thread reduction (or, at one token split, no
+    reduction at all: the tiles are written to the output): bit-identical to the 64-outputs-per-block reduction an unaligned output
+    takes, and the emulated definition within fp32 rounding."""
+    sim, emu = ops
+    sim._ws = {}
+    a, b = _rt(M, R, seed=3, scale=0.3), _rt(M, C, seed=4, scale=0.3)
+    o_e, o_4, o_1 = torch.zeros(R, C), torch.full((R, C + 4), 7.0), torch.full((R, C + 3), 7.0)
+    emu.wgrad_tn(a, b, o_e, alpha=0.5)
+    sim.wgrad_tn(_bf(a), _bf(b), o_4[:, :C], alpha=0.5, splits=splits)
+    sim.wgrad_tn(_bf(a), _bf(b), o_1[:, :C], alpha=0.5, splits=splits)
+    assert torch.equal(o_4[:, :C], o_1[:, :C]) and float(o_4[:, C:].min()) == 7.0 and float(o_1[:, C:].min()) == 7.0
+    assert rel_l2(o_4[:, :C], o_e) < 1e-5
 
 
 # ---------------------------------------------------------------------------------- base-weight gradients (csrc/full_grad.hip)
@@ -351,6 +368,7 @@ def test_im2col_matches_unfold(ops, mode, n_img, h, w, frames, c0, c1):
 @pytest.mark.parametrize("kind,c0,c1,units,rows,silu,sum_rows", [
     (0, 64, 0, 2, 48, True, 96), (0, 32, 64, 3, 40, False, 120), (0, 320, 0, 1, 70, True, 70), (1, 64, 0, 1, 50, False, 50),
     (1, 320, 0, 1, 33, False, 33), (1, 1280, 0, 1, 9, False, 9), (2, 96, 0, 1, 60, False, 60), (2, 64, 0, 1, 60, False, 20),
+    (0, 640, 0, 2, 37, True, 74), (1, 640, 0, 1, 21, False, 21), (0, 960, 0, 1, 19, True, 19),   # two chunks per lane, two rows in flight per wave
     (0, 1280, 1280, 1, 20, True, 20), (2, 5120, 0, 1, 24, False, 24)])   # the widest GroupNorm (a 1280 + 1280 concat); column sums in 2048-column chunks
 def test_norm_affine_grad_against_autograd_style_sums(ops, kind, c0, c1, units, rows, silu, sum_rows):
     """t2v_norm_affine_grad: dgamma / dbeta of GroupNorm(+SiLU) (two-part input), of LayerNorm, plain column sums (bias gradients) and
