@@ -149,10 +149,11 @@ class Packer:
             self.makers[key] = fn
         return self.cache[key]
 
-    def refresh(self):
+    def refresh(self, ops=None):
         """Re-make every pack from the CURRENT parameters into the tensors that are already there (full fine-tuning: the weights move
         every optimizer step, the recorded launch lists keep pointing at the same packs).  Entries are re-made in the order they were
-        first made, so a pack derived from another cached pack (transposes, fragment packs) sees its refreshed source."""
+        first made, so a pack derived from another cached pack (transposes, fragment packs) sees its refreshed source.  ``ops``: the
+        op backend, for the packs that are a plain transpose of one refreshed before them."""
         def put(old, new):
             if isinstance(old, torch.Tensor):
                 if old.data_ptr() != new.data_ptr():
@@ -161,6 +162,7 @@ class Packer:
                 for o, n in zip(old, new):
                     put(o, n)
         by_id = None
+        done = set()
         for key, fn in list(self.makers.items()):
             kind = key[0]
             if kind == "full_idx":   # (index tables: no weights inside)
@@ -171,12 +173,25 @@ class Packer:
                 if by_id is None:
                     by_id = getattr(self, "_mods_by_id", None)
                 mod = None if by_id is None else by_id.get(key[1])
+                src = self.cache.get(("mat", key[1])) if kind == "mat_t" and ("mat", key[1]) in done else None
+                if (src is not None and ops is not None and hasattr(ops, "transpose") and src.dtype == self.cache[key].dtype
+                        and (src.dtype == torch.bfloat16 or not src.is_cuda)):   # (the library's transpose is bf16; the emulated backend takes any)
+                    # the data-gradient pack = the forward pack transposed, bf16 -> bf16 by the library's tiled transpose (the strided
+                    # fp32 -> bf16 copy ran at ~ 300 GB/s: 30 us per pack, 7 ms per full fine-tuning step)
+                    ops.transpose(src, src.shape[0], src.shape[1], self.cache[key])
+                    done.add(key)
+                    continue
                 if mod is not None:
                     w = self.wb(mod)[0].detach()
                     w2 = w.reshape(w.shape[0], -1)
                     self.cache[key].copy_(w2 if kind == "mat" else w2.t())
+                    done.add(key)
                     continue
-            put(self.cache[key], fn())
+            if getattr(fn, "into", False) and isinstance(self.cache[key], torch.Tensor):
+                fn(self.cache[key])      # (a maker that writes straight into the existing pack)
+            else:
+                put(self.cache[key], fn())
+            done.add(key)
 
     def f32(self, p):
         return None if p is None else self._memo(("f32", id(p)), lambda: p.detach().to(self.device, torch.float32).contiguous())
@@ -200,14 +215,25 @@ class Packer:
 
     def conv(self, mod):
         """[N, taps*Cin], tap-major: Conv2d [N,C,3,3] -> (ky,kx,c); Conv3d [N,C,3,1,1] -> (kt,c)."""
-        return self._memo(("conv", id(mod)), lambda: self._conv_tap_major(mod))
+        def make(out=None):
+            return self._conv_tap_major(mod, out)
+        make.into = True
+        return self._memo(("conv", id(mod)), make)
 
-    def _conv_tap_major(self, mod):
+    def _conv_tap_major(self, mod, out=None):
         w = self.wb(mod)[0]
         if w.dim() == 5:
             w = w[:, :, :, 0, 0].permute(0, 2, 1)
         else:
             w = w.permute(0, 2, 3, 1)
+        return self._permuted_into(w, out)
+
+    def _permuted_into(self, w, out=None):
+        """The [rows, -1] pack of the permuted weight view ``w`` — into ``out`` where that is the existing pack (``refresh``: cast and
+        permutation as ONE kernel straight into the pack, no temporary and no second copy)."""
+        if out is not None and tuple(out.shape) == (w.shape[0], w[0].numel()) and out.is_contiguous():
+            out.view(w.shape).copy_(w)
+            return out
         return w.reshape(w.shape[0], -1).to(self.device, self.wdtype).contiguous()
 
     def conv_slab(self, mod):
@@ -227,10 +253,11 @@ class Packer:
 
     def conv_dgrad(self, mod):
         """3x3 conv data gradient as a 3x3 conv over dy: w'[ci][(ky',kx'), co] = w[co][ci][2-ky'][2-kx']."""
-        def make():
+        def make(out=None):
             w = self.wb(mod)[0]          # [co, ci, 3, 3]
             wd = w.flip(2, 3).permute(1, 2, 3, 0)      # [ci, ky', kx', co]
-            return wd.reshape(wd.shape[0], -1).to(self.device, self.wdtype).contiguous()
+            return self._permuted_into(wd, out)
+        make.into = True
         return self._memo(("conv_dgrad", id(mod)), make)
 
     def small_conv_dgrad(self, mod, cin_pad, cout_pad=None):

@@ -83,7 +83,7 @@ class FullTrainMixin:
         if getattr(self, "_full_fp", None) is None:
             self._full_fp = fp
         elif fp != self._full_fp:
-            self.pk.refresh()
+            self.pk.refresh(self.ops)
             self._full_fp = fp
 
     # ---- forward side: keep the leaf's input ----------------------------------------------------------------------------

@@ -387,10 +387,11 @@ class UNetGradEngine(FullTrainMixin, LoraTrainMixin, UNetEngine):
 
     def tconv_dgrad_w(self, mod):
         """(3,1,1) conv data gradient as the same temporal conv over dy: w'[ci][(kt', co)] = w[co][ci][2 - kt']."""
-        def make():
+        def make(out=None):
             w = self.pk.wb(mod)[0]                                  # [co, ci, 3, 1, 1]
             wd = w[:, :, :, 0, 0].flip(2).permute(1, 2, 0)          # [ci, kt', co]
-            return wd.reshape(wd.shape[0], -1).to(self.device, self.adt).contiguous()
+            return self.pk._permuted_into(wd, out)
+        make.into = True
         return self.pk._memo(("tconv_dgrad", id(mod)), make)
 
     def mats_t(self, mods, tag):

@@ -715,7 +715,7 @@ def test_full_fine_tuning_train_mode_runs_with_live_temporal_dropouts():
 def test_full_fine_tuning_at_full_width_vs_cpu_autograd():
     """Row a20 at the WIDTH the reference trains at: the VideoCrafter2 UNet (1 413 M parameters), every parameter trainable, eval mode, a
     2-frame latent (1,4,2,40,64) — every level, width and leaf kind of the 16-frame step (320 / 640 / 1 280-channel convs with their
-    im2col matrices, the 2 560-channel concat GroupNorms, the 10 240-column GEGLU pre-activation, row-blocked weight-gradient products);
+    im2col matrices, the 2 560-channel concat GroupNorms, the 10 240-column GEGLU pre-activation, weight-gradient products larger than the split-K workspace);
     forward + backward through the module route on the device against fp32 CPU autograd through the same module (checkpointed, as the
     LoRA gate's oracle): output, d/d(latents) and the gradient of EVERY parameter by cosine and norm.  T2V_TEST_TRAIN_PARITY_FRAMES
     raises the frame count."""

@@ -88,12 +88,9 @@ def test_every_parameter_gradient_matches_autograd_and_survives_an_optimizer_ste
 def test_partially_frozen_network_and_auto_route():
     """requires_grad on a subset (the v2 script's temporal / other parameter groups can be trained separately): frozen parameters get no
     gradient, the others are unchanged; the auto route takes full fine-tuning only when a parameter is trainable."""
-    class SmallWorkspaceOps(EmuOps):
-        SPLITK_WS_BYTES = 1 << 16      # every weight-gradient product goes out in 64-row blocks of its output (engine_full.full_wgrad)
-
     g = load("unet_tiny")
     m = _student()
-    m._native_ops_factory = SmallWorkspaceOps
+    m._native_ops_factory = EmuOps
     x, ts, ctx, tc = g["x"], g["ts"], g["ctx"], g["tc"]
     r_out = torch.randn(g["y"].shape, generator=torch.Generator().manual_seed(4))
     for n, p in m.named_parameters():
