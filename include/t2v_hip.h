@@ -507,6 +507,14 @@ long long t2v_norm_affine_grad_ws_floats(long long rows, long long sum_rows, int
 int t2v_norm_affine_grad(const void* x0, int c0, int ld0, const void* x1, int c1, int ld1, long long rows, long long sum_rows, int kind,
                          int rows_per_unit, int groups, const float* stats, float ln_eps, const float* gamma, const float* beta, int silu,
                          const void* dy, int ldy, float* dgamma, int ld_dgamma, float* dbeta, int ld_dbeta, float* ws, void* stream);
+/* t2v_repack_conv_f32: a conv leaf's fp32 parameter w [N][C][taps] (taps = 9: (ky, kx) row-major, or 3: frame offsets; <= 9) into one of
+ * the bf16 packs the launch lists read, cast (round to nearest even) included:
+ *     kind 0   out[n][t * C + c] = w[n][c][t]                   the tap-major forward pack (t2v_gemm's K order), ldo >= taps * C
+ *     kind 1   out[c][(taps - 1 - t) * N + n] = w[n][c][t]      the data-gradient pack: the same conv over dy with channels and filters
+ *                                                               swapped and the taps mirrored, ldo >= taps * N
+ * Full fine-tuning re-makes every pack per optimizer step IN PLACE (the recorded launch lists keep their pointers); this replaces
+ * torch's permute / flip / cast chain for the conv leaves (70 % of the UNet's parameters). */
+int t2v_repack_conv_f32(const float* w, int N, int C, int taps, int kind, void* out, int ldo, void* stream);
 /* t2v_transpose_pad_bf16: out[b][c][r] = in[b][r][c] for r < rows and 0 for rows <= r < roundup(rows, 64) — the K-contiguous,
  * K-padded operand of the token-contracted weight-gradient GEMMs (dU = dy^T t, dD = G^T x) in one pass; 16-byte accesses on both
  * sides: cols % 8 == 0, ld_in % 8 == 0, ld_out % 8 == 0 and >= roundup(rows, 64), 16-byte aligned bases, batch strides % 8. */

@@ -15,6 +15,10 @@
 //    (openaimodel3d.py:223-254 in_layers / out_layers), or plain column sums of dy (kind 2: biases; per-clip sums = d(loss)/d(emb)).
 //    `sum_rows` consecutive rows make one output row u.  Two launches: per-block partial sums in a fixed order, then their sum in block
 //    order — deterministic, no float atomics.  HBM-bound: reads x and dy once.
+//  * t2v_repack_conv_f32 — the weights move every optimizer step, so the bf16 packs the recorded launch lists point at are re-made per step
+//    (engine.Packer.refresh): a conv leaf's fp32 parameter [N][C][taps] into its tap-major forward pack [N][taps][C] or its data-gradient
+//    pack [C][taps flipped][N], cast included, through an LDS tile so that both sides are coalesced (torch's strided cast-and-copy did
+//    37 us per pack, ~ 300 GB/s: profiles/r06_full_finetune_kernel_stats.csv).
 #include "common.h"
 
 namespace {
@@ -228,6 +232,39 @@ __global__ __launch_bounds__(AGF_WAVES * 64) void affine_grad_final_kernel(const
     }
 }
 
+// ---- conv weight packs from the fp32 parameter ------------------------------------------------------------------------------------------
+// kind 0: out[n][t][c] = w[n][c][t].  Block (c chunk of RP_C channels, n): reads RP_C * taps consecutive floats, writes taps runs of RP_C bf16.
+// kind 1: out[c][taps - 1 - t][n] = w[n][c][t] (the conv over dy that gives dx: channels and filters swapped, taps mirrored).  Block
+//         (c chunk of RP_DC channels, n chunk of RP_DN filters): per filter RP_DC * taps consecutive floats in, per (c, t) a run of RP_DN bf16 out.
+constexpr int RP_C = 256, RP_DC = 16, RP_DN = 64, RP_MAXT = 9;
+__global__ __launch_bounds__(256) void repack_conv_fwd_kernel(const float* __restrict__ w, int C, int taps, bf16_t* __restrict__ out, int ldo) {
+    __shared__ float tile[RP_C * RP_MAXT];
+    const int n = blockIdx.y, c0 = blockIdx.x * RP_C, nc = min(RP_C, C - c0);
+    const float* src = w + ((long long)n * C + c0) * taps;
+    for (int i = threadIdx.x; i < nc * taps; i += 256) tile[i] = src[i];
+    __syncthreads();
+    bf16_t* dst = out + (long long)n * ldo + c0;
+    for (int i = threadIdx.x; i < nc * taps; i += 256) {
+        const int t = i / nc, c = i - t * nc;
+        dst[(long long)t * C + c] = f2bf(tile[c * taps + t]);
+    }
+}
+__global__ __launch_bounds__(256) void repack_conv_dgrad_kernel(const float* __restrict__ w, int N, int C, int taps, bf16_t* __restrict__ out, int ldo) {
+    __shared__ float tile[RP_DN][RP_DC * RP_MAXT + 1];
+    const int c0 = blockIdx.x * RP_DC, n0 = blockIdx.y * RP_DN, nc = min(RP_DC, C - c0), nn = min(RP_DN, N - n0);
+    const int run = nc * taps;
+    for (int i = threadIdx.x; i < nn * run; i += 256) {
+        const int j = i / run, k = i - j * run;
+        tile[j][k] = w[((long long)(n0 + j) * C + c0) * taps + k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < run * nn; i += 256) {
+        const int k = i / nn, j = i - k * nn;          // k = c * taps + t of the source
+        const int c = k / taps, t = k - c * taps;
+        out[(long long)(c0 + c) * ldo + (long long)(taps - 1 - t) * N + n0 + j] = f2bf(tile[j][k]);
+    }
+}
+
 }  // namespace
 
 extern "C" long long t2v_im2col_rows(int mode, int n_img, int h, int w) {
@@ -339,6 +376,23 @@ extern "C" int t2v_norm_affine_grad(const void* x0, int c0, int ld0, const void*
     T2V_CHECK_LAUNCH();
     hipLaunchKernelGGL(affine_grad_final_kernel, dim3((2 * C + 63) / 64, (unsigned)n_out), dim3(AGF_WAVES * 64), 0, s, (const float*)ws, nblk, C,
                        dgamma, ld_dgamma, dbeta, ld_dbeta);
+    T2V_CHECK_LAUNCH();
+    return T2V_OK;
+}
+
+extern "C" int t2v_repack_conv_f32(const float* w, int N, int C, int taps, int kind, void* out, int ldo, void* stream) {
+    T2V_REQUIRE(w && out && N > 0 && C > 0 && taps >= 1 && taps <= RP_MAXT && (kind == 0 || kind == 1), T2V_EINVAL,
+                "t2v_repack_conv_f32: bad argument (taps <= 9, kind 0 = forward pack, 1 = data-gradient pack)");
+    T2V_REQUIRE(ldo >= taps * (kind == 0 ? C : N), T2V_ESHAPE, "t2v_repack_conv_f32: ldo smaller than a pack row");
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == 0) {
+        T2V_REQUIRE(N <= 65535, T2V_ESHAPE, "t2v_repack_conv_f32: grid");
+        hipLaunchKernelGGL(repack_conv_fwd_kernel, dim3((C + RP_C - 1) / RP_C, N), dim3(256), 0, s, w, C, taps, (bf16_t*)out, ldo);
+    } else {
+        T2V_REQUIRE((N + RP_DN - 1) / RP_DN <= 65535, T2V_ESHAPE, "t2v_repack_conv_f32: grid");
+        hipLaunchKernelGGL(repack_conv_dgrad_kernel, dim3((C + RP_DC - 1) / RP_DC, (N + RP_DN - 1) / RP_DN), dim3(256), 0, s, w, N, C, taps,
+                           (bf16_t*)out, ldo);
+    }
     T2V_CHECK_LAUNCH();
     return T2V_OK;
 }

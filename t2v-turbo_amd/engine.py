@@ -153,7 +153,9 @@ class Packer:
         """Re-make every pack from the CURRENT parameters into the tensors that are already there (full fine-tuning: the weights move
         every optimizer step, the recorded launch lists keep pointing at the same packs).  Entries are re-made in the order they were
         first made, so a pack derived from another cached pack (transposes, fragment packs) sees its refreshed source.  ``ops``: the
-        op backend, for the packs that are a plain transpose of one refreshed before them."""
+        op backend, for the packs the library re-makes itself (transposes of a refreshed pack, conv packs).
+        (Measured and not kept: the backward-only packs issued behind the forward's launches — 139.1 / 135.9 vs 139.8 / 135.2 ms per
+        step, profiles/r06_full_finetune_wgrad_affine_rework_ab.jsonl.)"""
         def put(old, new):
             if isinstance(old, torch.Tensor):
                 if old.data_ptr() != new.data_ptr():
@@ -167,6 +169,9 @@ class Packer:
             kind = key[0]
             if kind == "full_idx":   # (index tables: no weights inside)
                 continue
+            alias = getattr(fn, "param", None)
+            if alias is not None and isinstance(self.cache[key], torch.Tensor) and alias.data_ptr() == self.cache[key].data_ptr():
+                continue                 # (an fp32 parameter on the device IS its pack: nothing to re-make)
             if kind in ("mat", "mat_t") and len(key) == 2:
                 # the two most common packs straight from the parameter into the existing tensor: ONE cast-and-copy kernel instead of a
                 # cast into a temporary plus a device-to-device copy (1 100 of the 1 500 packs of the full-width UNet)
@@ -188,17 +193,27 @@ class Packer:
                     done.add(key)
                     continue
             if getattr(fn, "into", False) and isinstance(self.cache[key], torch.Tensor):
-                fn(self.cache[key])      # (a maker that writes straight into the existing pack)
+                fn(self.cache[key], ops)      # (a maker that writes straight into the existing pack)
             else:
                 put(self.cache[key], fn())
             done.add(key)
 
     def f32(self, p):
-        return None if p is None else self._memo(("f32", id(p)), lambda: p.detach().to(self.device, torch.float32).contiguous())
+        if p is None:
+            return None
+        def make():
+            return p.detach().to(self.device, torch.float32).contiguous()
+        make.param = p       # (``refresh`` skips the pack while it still IS the parameter's storage)
+        return self._memo(("f32", id(p)), make)
 
     def bias(self, mod):
         b = self.wb(mod)[1]
-        return None if b is None else self._memo(("bias", id(mod)), lambda: b.detach().to(self.device, torch.float32).contiguous())
+        if b is None:
+            return None
+        def make():
+            return b.detach().to(self.device, torch.float32).contiguous()
+        make.param = b
+        return self._memo(("bias", id(mod)), make)
 
     def _remember(self, mod):
         if not hasattr(self, "_mods_by_id"):
@@ -215,18 +230,39 @@ class Packer:
 
     def conv(self, mod):
         """[N, taps*Cin], tap-major: Conv2d [N,C,3,3] -> (ky,kx,c); Conv3d [N,C,3,1,1] -> (kt,c)."""
-        def make(out=None):
-            return self._conv_tap_major(mod, out)
+        def make(out=None, ops=None):
+            return self._conv_tap_major(mod, out, ops)
         make.into = True
         return self._memo(("conv", id(mod)), make)
 
-    def _conv_tap_major(self, mod, out=None):
+    def _conv_tap_major(self, mod, out=None, ops=None):
         w = self.wb(mod)[0]
+        if self._repacked(w, out, ops, 0):
+            return out
         if w.dim() == 5:
             w = w[:, :, :, 0, 0].permute(0, 2, 1)
         else:
             w = w.permute(0, 2, 3, 1)
         return self._permuted_into(w, out)
+
+    @staticmethod
+    def _repacked(w, out, ops, kind):
+        """``refresh`` on the device: the conv parameter -> its existing bf16 pack by the library's repack kernel (t2v_repack_conv_f32;
+        kind 0 forward pack, 1 data-gradient pack).  False where that does not apply (first making, CPU tensors, a merged LoRA weight)."""
+        if out is None or ops is None or not hasattr(ops, "repack_conv") or w.dtype != torch.float32 or not w.is_contiguous():
+            return False
+        if os.environ.get("T2V_REPACK_NATIVE", "1") != "1":     # (A/B switch: torch's permute / flip / cast chain)
+            return False
+        if w.dim() == 5 and (w.shape[3] != 1 or w.shape[4] != 1):
+            return False
+        n, c = w.shape[0], w.shape[1]
+        taps = w.numel() // (n * c)
+        if taps > 9 or tuple(out.shape) != ((n, taps * c) if kind == 0 else (c, taps * n)) or not out.is_contiguous():
+            return False
+        if out.is_cuda and out.dtype != torch.bfloat16:
+            return False
+        ops.repack_conv(w, out, kind)
+        return True
 
     def _permuted_into(self, w, out=None):
         """The [rows, -1] pack of the permuted weight view ``w`` — into ``out`` where that is the existing pack (``refresh``: cast and
@@ -253,8 +289,10 @@ class Packer:
 
     def conv_dgrad(self, mod):
         """3x3 conv data gradient as a 3x3 conv over dy: w'[ci][(ky',kx'), co] = w[co][ci][2-ky'][2-kx']."""
-        def make(out=None):
+        def make(out=None, ops=None):
             w = self.wb(mod)[0]          # [co, ci, 3, 3]
+            if self._repacked(w, out, ops, 1):
+                return out
             wd = w.flip(2, 3).permute(1, 2, 3, 0)      # [ci, ky', kx', co]
             return self._permuted_into(wd, out)
         make.into = True

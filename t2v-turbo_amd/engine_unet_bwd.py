@@ -387,8 +387,10 @@ class UNetGradEngine(FullTrainMixin, LoraTrainMixin, UNetEngine):
 
     def tconv_dgrad_w(self, mod):
         """(3,1,1) conv data gradient as the same temporal conv over dy: w'[ci][(kt', co)] = w[co][ci][2 - kt']."""
-        def make(out=None):
+        def make(out=None, ops=None):
             w = self.pk.wb(mod)[0]                                  # [co, ci, 3, 1, 1]
+            if self.pk._repacked(w, out, ops, 1):
+                return out
             wd = w[:, :, :, 0, 0].flip(2).permute(1, 2, 0)          # [ci, kt', co]
             return self.pk._permuted_into(wd, out)
         make.into = True

@@ -237,6 +237,7 @@ _SIGS = {
     "t2v_im2col_rows": (C.c_longlong, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "t2v_im2col_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_int, C.c_void_p]),
+    "t2v_repack_conv_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "t2v_norm_affine_grad_ws_floats": (C.c_longlong, [C.c_longlong, C.c_longlong, C.c_int]),
     "t2v_norm_affine_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_int,
                                        C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
@@ -850,6 +851,15 @@ class HipOps:
         """out[m][tap * C + c] = x[src(m, tap)][c] (bf16; x = [x0 | x1] on the (n_img, h, w) input grid) for a conv gather mode of ``gemm``."""
         self._call("t2v_im2col_bf16", _p(x0), x0.shape[1], _row_stride(x0), _p(x1), 0 if x1 is None else x1.shape[1],
                    0 if x1 is None else _row_stride(x1), int(mode), n_img, h, w, frames, _p(out), _row_stride(out))
+
+    def repack_conv(self, w, out, kind):
+        """out (bf16 pack, in place) from the fp32 conv parameter w [N, C, k...]: kind 0 = tap-major forward pack [N, taps * C],
+        kind 1 = data-gradient pack [C, taps * N] with mirrored taps (t2v_repack_conv_f32)."""
+        N, Cc = w.shape[0], w.shape[1]
+        taps = w.numel() // (N * Cc)
+        assert w.dtype == torch.float32 and w.is_contiguous() and out.dtype == torch.bfloat16
+        assert tuple(out.shape) == ((N, taps * Cc) if kind == 0 else (Cc, taps * N))
+        self._call("t2v_repack_conv_f32", _p(w), N, Cc, taps, kind, _p(out), _row_stride(out))
 
     def norm_affine_grad_ws_floats(self, rows, sum_rows, channels):
         return int(self.lib.t2v_norm_affine_grad_ws_floats(int(rows), int(sum_rows), int(channels)))

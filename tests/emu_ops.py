@@ -546,6 +546,16 @@ class EmuOps:
             return n_img * 4 * h * w
         return -1
 
+    def repack_conv(self, w, out, kind):
+        """t2v_repack_conv_f32: kind 0 out[n][t*C + c] = w[n][c][t]; kind 1 out[c][(taps-1-t)*N + n] = w[n][c][t]."""
+        self._log("repack_conv")
+        N, Cc = w.shape[0], w.shape[1]
+        w3 = w.detach().reshape(N, Cc, -1)
+        if kind == 0:
+            out.copy_(w3.permute(0, 2, 1).reshape(N, -1))
+        else:
+            out.copy_(w3.flip(2).permute(1, 2, 0).reshape(Cc, -1))
+
     def im2col(self, x0, x1, mode, n_img, h, w, frames, out):
         """out[m][tap * C + c] = x[src(m, tap)][c]: F.unfold of the (padded / upsampled) image, re-ordered tap-major."""
         self._log("im2col")

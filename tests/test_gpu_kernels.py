@@ -783,6 +783,21 @@ def test_im2col_on_device(pair, mode, n_img, h, w, frames, c0, c1):
     assert torch.equal(o_h.float().cpu(), o_e)
 
 
+@pytest.mark.parametrize("N,C,taps,kind", [(320, 320, 9, 0), (1280, 2560, 9, 0), (1280, 2560, 9, 1), (320, 320, 3, 1), (640, 1920, 3, 0),
+                                           (4, 320, 9, 1), (70, 300, 9, 0), (130, 33, 3, 1)])
+def test_repack_conv_on_device(pair, N, C, taps, kind):
+    """t2v_repack_conv_f32 at the UNet's conv leaves (3x3 incl. the 2 560-channel concat inputs, (3,1,1), the 4-filter exit conv) and two
+    ragged shapes: bit-identical to the torch permute / flip / cast chain that first makes the packs."""
+    w = _rt(N, C * taps, seed=7).reshape(N, C, 3, 3) if taps == 9 else _rt(N, C * taps, seed=7).reshape(N, C, 3, 1, 1)
+    shape = (N, taps * C) if kind == 0 else (C, taps * N)
+    o_e = torch.zeros(shape)
+    pair.emu.repack_conv(w, o_e, kind)
+    o_h = torch.full(shape, float("nan"), dtype=torch.bfloat16, device="cuda")
+    pair.hip.repack_conv(w.cuda(), o_h, kind)
+    torch.cuda.synchronize()
+    assert torch.equal(o_h.float().cpu(), o_e.bfloat16().float())
+
+
 @pytest.mark.parametrize("kind,c0,c1,units,rows,silu,sum_rows", [
     (0, 320, 0, 16, 2560, True, 40960), (0, 640, 320, 1, 10240, True, 10240), (0, 1280, 0, 16, 160, False, 2560), (1, 320, 0, 1, 40960, False, 40960),
     (1, 1280, 0, 1, 2560, False, 2560), (2, 320, 0, 1, 40960, False, 40960), (2, 2560, 0, 1, 4096, False, 4096), (2, 640, 0, 1, 20480, False, 10240)])

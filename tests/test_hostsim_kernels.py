@@ -365,6 +365,22 @@ def test_im2col_matches_unfold(ops, mode, n_img, h, w, frames, c0, c1):
     assert torch.allclose(y, ref, atol=1e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize("N,C,taps,kind", [(5, 24, 9, 0), (70, 300, 9, 0), (3, 8, 3, 0), (70, 20, 9, 1), (130, 33, 3, 1), (64, 16, 9, 1)])
+def test_repack_conv(ops, N, C, taps, kind):
+    """t2v_repack_conv_f32: the fp32 conv parameter into the tap-major forward pack / the mirrored data-gradient pack, bit-identical to the
+    torch permute + cast chain the packs are first made with (ragged channel and filter chunks, 3 and 9 taps, a padded pack row)."""
+    sim, emu = ops
+    w = _rt(N, C * taps, seed=7).reshape(N, C, 3, 3) if taps == 9 else _rt(N, C * taps, seed=7).reshape(N, C, 3, 1, 1)
+    shape = (N, taps * C) if kind == 0 else (C, taps * N)
+    o_e = torch.zeros(shape)
+    emu.repack_conv(w, o_e, kind)
+    wide = torch.full((shape[0], shape[1] + 8), 3.0, dtype=torch.bfloat16)
+    o_s = wide[:, :shape[1]]
+    sim.lib.t2v_repack_conv_f32  # (exported)
+    sim._call("t2v_repack_conv_f32", w.data_ptr(), N, C, taps, kind, o_s.data_ptr(), o_s.stride(0))
+    assert torch.equal(o_s.float(), o_e.bfloat16().float()) and float(wide[:, shape[1]:].float().min()) == 3.0
+
+
 @pytest.mark.parametrize("kind,c0,c1,units,rows,silu,sum_rows", [
     (0, 64, 0, 2, 48, True, 96), (0, 32, 64, 3, 40, False, 120), (0, 320, 0, 1, 70, True, 70), (1, 64, 0, 1, 50, False, 50),
     (1, 320, 0, 1, 33, False, 33), (1, 1280, 0, 1, 9, False, 9), (2, 96, 0, 1, 60, False, 60), (2, 64, 0, 1, 60, False, 20),
