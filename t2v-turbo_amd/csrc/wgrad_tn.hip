@@ -153,13 +153,19 @@ __device__ __forceinline__ void wgrad_tile(const bf16_t* __restrict__ a, int lda
 
 template <int T>
 __global__ __launch_bounds__(256) void wgrad_tn_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb, long long M,
-                                                       int R, int C, long long tok_per_split, float* __restrict__ ws, long long ld_ws, float scale) {
+                                                       int R, int C, long long tok_per_split, float* __restrict__ ws, long long ld_ws, float scale,
+                                                       int y_fast) {
     __shared__ __attribute__((aligned(16))) bf16_t sa[WT_TOK][WtGeom<T>::PITCH];
     __shared__ __attribute__((aligned(16))) bf16_t sb[WT_TOK][WtGeom<T>::PITCH];
     // (linear id = x fastest: the order the dispatcher walks the grid in)
     const int nb = gridDim.x * gridDim.y * gridDim.z;
     const int id = xcd_contiguous((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, nb);
-    const int bx = id % gridDim.x, by = (id / gridDim.x) % gridDim.y, bz = id / (gridDim.x * gridDim.y);
+    // Consecutive ids (one XCD, resident together, walking the token range at the same pace) should cover a near-SQUARE patch of the tile
+    // grid: a patch of h x w tiles streams h + w operand column blocks for h w tiles.  With the row of tiles as the fast axis a patch
+    // was 1 x ~100: every tile its own block of the wide operand, re-read from the memory side once per tile row (counters, 640 x 5 760
+    // over 10 240 tokens: 1.17 GB fetched for 131 MB of operands, profiles/r06_wgrad_tile_pmc.csv) — so the SHORTER grid axis runs fastest.
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int bx = y_fast ? (id / gy) % gx : id % gx, by = y_fast ? id % gy : (id / gx) % gy, bz = id / (gx * gy);
     const long long m_begin = (long long)bz * tok_per_split;
     const long long m_end = m_begin + tok_per_split < M ? m_begin + tok_per_split : M;
     wgrad_tile<T>(a, lda, b, ldb, R, C, by * WtGeom<T>::TILE, bx * WtGeom<T>::TILE, m_begin, m_end, ws + (long long)bz * R * C, ld_ws, scale, sa, sb);
@@ -320,12 +326,14 @@ extern "C" int t2v_wgrad_tn(const void* a, int lda, const void* b, int ldb, long
     float* dst = splits == 1 ? out : ws;
     const long long ld_slab = splits == 1 ? ldo : C;
     const float scale = splits == 1 ? alpha : 1.0f;
+    static const bool yfast_on = getenv("T2V_WGRAD_YFAST") == nullptr || atoi(getenv("T2V_WGRAD_YFAST")) != 0;
+    const int y_fast = yfast_on && grid.y <= grid.x;
     if (tile == 128)
         hipLaunchKernelGGL(wgrad_tn_kernel<2>, grid, dim3(256), 0, s, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, M, R, C, tok_per_split, dst,
-                           ld_slab, scale);
+                           ld_slab, scale, y_fast);
     else
         hipLaunchKernelGGL(wgrad_tn_kernel<1>, grid, dim3(256), 0, s, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, M, R, C, tok_per_split, dst,
-                           ld_slab, scale);
+                           ld_slab, scale, y_fast);
     T2V_CHECK_LAUNCH();
     if (splits == 1) return T2V_OK;
     if (C % 4 == 0 && ldo % 4 == 0 && (uintptr_t)out % 16 == 0 && (long long)R * C >= (1 << 16))
