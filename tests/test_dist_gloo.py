@@ -120,3 +120,52 @@ def test_two_rank_native_student_allreduce_matches_single_process(tmp_path):
     got2 = torch.load(out2)
     assert got2["info"]["segments"] == 0 and got2["info"]["rest"] is None
     assert float((got["flat"] - got2["flat"]).norm() / got2["flat"].norm()) < 1e-6
+
+
+# ---- full fine-tuning (row a20) at world size 2 ----------------------------------------------------------------------------------------
+def _full_student():
+    from tests.test_unet_full_grad_cpu import _student as make
+    return make()      # every parameter trainable, no LoRA (train_latent_t2v_turbo_v2.py:669,798-816)
+
+
+def _full_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    m = _full_student()
+    if rank == 1:  # perturb, then rank 0's weights must win
+        with torch.no_grad():
+            next(m.parameters()).add_(1.0)
+    broadcast_parameters(m)
+    params = list(m.parameters())
+    sync = FlatGradSync(params)
+    sync.zero_()
+    from tests.emu_ops import EmuOps
+    m._native_ops_factory = EmuOps     # the native gradient engine's dataflow with base-weight gradients (engine_full.py), one engine per rank
+    m.native_mode = "train"
+    loss = _loss(m, rank, l2=True)
+    loss.backward()
+    assert m._engine_box.full is not None and m._engine_box.full.training_full, "the full fine-tuning route was not taken"
+    sync.all_reduce_mean()
+    if rank == 0:
+        torch.save({"flat": sync.flat.clone(), "loss": loss.detach()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_full_fine_tuning_allreduce_matches_single_process(tmp_path):
+    """Full fine-tuning data-parallel over two ranks: each rank's forward / backward of EVERY UNet parameter on the native gradient
+    engine (its gradients reach torch as views of one arena copy), ONE flat all-reduce averages them — against single-process autograd
+    of the mean loss through the torch module."""
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_full_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out)
+    m = _full_student()
+    m.native_mode = "off"
+    params = list(m.parameters())
+    l0, l1 = _loss(m, 0, l2=True), _loss(m, 1, l2=True)
+    ((l0 + l1) / 2).backward()
+    ref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    assert got["flat"].numel() == ref.numel()
+    assert float((got["flat"] - ref).norm() / ref.norm()) < 3e-4
+    assert abs(float(got["loss"]) - float(l0.detach())) < 1e-5
