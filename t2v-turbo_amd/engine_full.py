@@ -20,6 +20,8 @@ lists — raw device pointers — stay valid and nothing is re-recorded.
 Correctness first: im2col is materialised (2 taps C bytes per output row) and every leaf's gradient is its own launches; the step is
 not a measured configuration of bench.py.  Verified on CPU against torch autograd through the module (tests/test_unet_full_grad_cpu.py),
 on the host simulator per kernel, and on MI355X against the imported reference's own parameter gradients (tests/golden/unet_tiny_full_grad.npz)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -83,8 +85,46 @@ class FullTrainMixin:
         if getattr(self, "_full_fp", None) is None:
             self._full_fp = fp
         elif fp != self._full_fp:
-            self.pk.refresh(self.ops)
+            self._refresh()
             self._full_fp = fp
+
+    # The refresh is ~ 2 000 small launches (torch copies / casts, library transposes and repacks) over FIXED tensors — the parameters'
+    # storages in, the packs out — so after one eager pass it is captured as ONE hipGraph and replayed per optimizer step: the host's
+    # 15-17 ms of issuing it (tools/r6_gpu_calls/README.md, call 40) go.  The graph holds raw pointers: it is dropped and re-captured
+    # when a parameter was re-homed or a pack was added; T2V_REFRESH_GRAPH=0 keeps the eager loop.
+    refresh_graph = os.environ.get("T2V_REFRESH_GRAPH", "1") == "1"
+
+    def _refresh(self):
+        dev = getattr(self, "device", None)
+        if not (self.refresh_graph and getattr(self.ops, "is_native", False) and dev is not None and dev.type == "cuda"):
+            self.pk.refresh(self.ops)
+            return
+        from .nn_util import walk_parameters
+        sig = (len(self.pk.makers), tuple(p.data_ptr() for p in walk_parameters(self.model)))
+        st = getattr(self, "_refresh_state", None)
+        if st is not None and st["sig"] == sig and st["graph"] is not None:
+            st["graph"].replay()
+            return
+        if st is None or st["sig"] != sig:
+            self.pk.refresh(self.ops)               # first pass for this set of tensors: eager (it also warms the allocator)
+            self._refresh_state = {"sig": sig, "graph": None, "failed": False}
+            return
+        if st["failed"]:
+            self.pk.refresh(self.ops)
+            return
+        try:                                         # second pass: capture, then run the captured pass
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize(dev)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.pk.refresh(self.ops)
+            g.replay()
+            st["graph"] = g
+        except Exception as e:  # noqa: BLE001 - a maker the capture cannot take (host read-back, pageable copy): stay eager, say so once
+            import warnings
+            warnings.warn(f"pack refresh not capturable as a hipGraph ({type(e).__name__}: {e}); staying with the eager pass")
+            st["failed"] = True
+            torch.cuda.synchronize(dev)
+            self.pk.refresh(self.ops)
 
     # ---- forward side: keep the leaf's input ----------------------------------------------------------------------------
     def full_save(self, mods, x, **info):
