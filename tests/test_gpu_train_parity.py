@@ -649,23 +649,30 @@ def test_full_fine_tuning_on_device_vs_the_reference_gradient_fixture():
             y, dx, grads = _fixture_step(m, *args, "auto")
         assert m._engine_box.full is not None and len(m._engine_box.full.plans) == 1
         check_against_reference_fixture(y.cpu(), dx.cpu(), [t.cpu() for t in grads], names, gg, OUT_TOL, DX_TOL, 0.10, (0.30, 0.06), 0.12)
-    # every weight moves (an optimizer step): same plan, new packs
+    # every weight moves (an optimizer step), three times: same plan, new packs — the first refresh runs eagerly, the second is captured
+    # as one hipGraph, the third replays it (engine_full._refresh)
     plan = next(iter(m._engine_box.full.plans.values()))
     gen = torch.Generator().manual_seed(5)
-    with torch.no_grad():
-        for p, q in zip(ref.parameters(), m.parameters()):
-            d = torch.randn(p.shape, generator=gen) * 0.03 * float(p.abs().mean() + 1e-3)
-            p.add_(d)
-            q.add_(d.cuda())
-    y_r, dx_r, g_r = _fixture_step(ref, g["x"], g["ts"], g["ctx"], g["tc"], r_out, "off")
-    y, dx, grads = _fixture_step(m, *args, "auto")
-    assert next(iter(m._engine_box.full.plans.values())) is plan
-    assert rel_l2(y_r, gg["out"]) > 1e-3, "the update must change the output for this check to mean anything"
-    assert rel_l2(y.cpu(), y_r) < OUT_TOL and rel_l2(dx.cpu(), dx_r) < DX_TOL
-    cos = torch.tensor([float(torch.nn.functional.cosine_similarity(a.cpu().double().reshape(1, -1), b.double().reshape(1, -1)))
-                        for a, b in zip(grads, g_r) if float(b.abs().max()) > 0])
-    print(f"[full fine-tuning, after the update] gradient cosine min {float(cos.min()):.4f} median {float(cos.median()):.4f}", flush=True)
-    assert float(cos.min()) > 0.97 and float(cos.median()) > 0.995
+    y_prev = gg["out"]
+    for upd in range(3):
+        with torch.no_grad():
+            for p, q in zip(ref.parameters(), m.parameters()):
+                d = torch.randn(p.shape, generator=gen) * 0.03 * float(p.abs().mean() + 1e-3)
+                p.add_(d)
+                q.add_(d.cuda())
+        y_r, dx_r, g_r = _fixture_step(ref, g["x"], g["ts"], g["ctx"], g["tc"], r_out, "off")
+        y, dx, grads = _fixture_step(m, *args, "auto")
+        assert next(iter(m._engine_box.full.plans.values())) is plan
+        assert rel_l2(y_r, y_prev) > 1e-3, "the update must change the output for this check to mean anything"
+        y_prev = y_r
+        assert rel_l2(y.cpu(), y_r) < OUT_TOL and rel_l2(dx.cpu(), dx_r) < DX_TOL, upd
+        cos = torch.tensor([float(torch.nn.functional.cosine_similarity(a.cpu().double().reshape(1, -1), b.double().reshape(1, -1)))
+                            for a, b in zip(grads, g_r) if float(b.abs().max()) > 0])
+        print(f"[full fine-tuning, after update {upd + 1}] gradient cosine min {float(cos.min()):.4f} median {float(cos.median()):.4f}", flush=True)
+        assert float(cos.min()) > 0.97 and float(cos.median()) > 0.995, upd
+    eng = m._engine_box.full
+    if eng.refresh_graph:
+        assert eng._refresh_state["graph"] is not None and not eng._refresh_state["failed"], "the pack refresh was not captured"
 
 
 def test_full_fine_tuning_mid_width_on_device_vs_the_reference_gradient_fixture():
